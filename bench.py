@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py — BN254 G1 multi_exp throughput on MI355X (BASELINE.json configs[1]).
+
+A "step" is one 2^log2n-point MSM (the reference's MockEccChip::multi_exp,
+halo2-snark-aggregator-api/src/mock/arith/ecc.rs:106-129) over synthetic inputs that are already
+resident in HBM: bases P_i = k_i*G (Montgomery affine table built on the GPU), scalars s_i canonical
+32-byte integers, both derived from a seeded PRNG, so the expected result (sum k_i s_i)*G is known.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--log2n 20]
+
+N > 1: launched by torch.distributed.run, one rank per GPU.  Independent proofs shard one-per-GPU (each
+rank runs its own MSMs: weak scaling, no data-path collective), then the per-rank accumulators are
+exchanged with ONE all-gather over RCCL and folded locally (RCCL has no user-defined reduction over
+group elements) — that exchange is inside the timed region.
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import __graft_entry__ as entry  # noqa: E402
+
+R_MOD = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+ALGO_BYTES_PER_POINT = 96        # 64-B affine base + 32-B scalar
+
+
+def gen_scalars(seed: int, n: int):
+    """n uniform Fr elements: 512-bit draws reduced mod r (the from_bytes_wide rule,
+    mock/transcript_encode.rs:14-21).  Returns (list of ints, uint8 array [n,32])."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    raw = rng.bytes(64 * n)
+    vals = [int.from_bytes(raw[64 * i:64 * i + 64], "little") % R_MOD for i in range(n)]
+    buf = b"".join(v.to_bytes(32, "little") for v in vals)
+    return vals, np.frombuffer(buf, dtype=np.uint8).reshape(n, 32)
+
+
+def cpu_baseline(bases_aff: bytes, scalars: bytes, sample: int):
+    """Oracle leg (checker code, oracle/): the restated reference algorithm — n independent
+    double-and-add scalar muls, one thread — timed on this box's host cores on a bounded sample."""
+    from oracle import cref
+    cref.lib()
+    t0 = time.perf_counter()
+    out = cref.multi_exp_naive(bases_aff[:64 * sample], scalars[:32 * sample], sample)
+    dt = time.perf_counter() - t0
+    return sample / dt, dt, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--log2n", type=int, default=20)
+    ap.add_argument("--window", type=int, default=0)
+    ap.add_argument("--cpu-sample", type=int, default=1 << 16)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path is the product; there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    pkg = entry.load_package()
+    eng = pkg.H2Agg(local_rank)
+    stream = torch.cuda.current_stream(dev)
+    eng.set_stream(stream.cuda_stream)
+    if args.window:
+        eng.msm_configure(window_bits=args.window)
+
+    n = 1 << args.log2n
+    seed = 0x48324147
+    ks, k_np = gen_scalars(seed + 2 * rank, n)          # base discrete logs (distinct proof per rank)
+    ss, s_np = gen_scalars(seed + 2 * rank + 1, n)
+    d_k = torch.from_numpy(k_np.copy()).to(dev)
+    d_s = torch.from_numpy(s_np.copy()).to(dev)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    table = eng.bases_generate(d_k.data_ptr(), n)       # P_i = k_i*G, stays in HBM (64 MiB at 2^20)
+    t_gen = time.perf_counter() - t0
+    d_out = torch.zeros((max(args.steps, args.warmup, 1), 96), dtype=torch.uint8, device=dev)
+
+    def step(i):
+        eng.g1_msm_device_async(table, d_s.data_ptr(), n, d_out[i].data_ptr())
+
+    def exchange():
+        """all-gather of the per-rank accumulators + local fold (the only collective on the path)"""
+        if dist is None:
+            return None
+        mine = d_out[0].contiguous()
+        gathered = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+        return torch.stack(gathered)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for i in range(args.warmup):
+        step(i)
+    exchange()
+    barrier()
+
+    # ---- correctness of what is being timed (self-check through a different kernel: k*G ladder)
+    total = sum(k * s for k, s in zip(ks, ss)) % R_MOD
+    got = eng.g1_batch_to_affine(bytes(d_out[0].cpu().numpy().tobytes()))
+    g_aff = (1).to_bytes(32, "little") + (2).to_bytes(32, "little")
+    want = eng.g1_batch_to_affine(eng.g1_batch_scalar_mul(g_aff, total.to_bytes(32, "little")))
+    if got != want:
+        raise SystemExit("rank %d: MSM result does not match (sum k_i s_i)*G — refusing to report a number" % rank)
+
+    eng.profile_reset()
+    eng.profile_enable(True)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    gathered = exchange()
+    barrier()
+    dt = time.perf_counter() - t0
+    eng.profile_enable(False)
+
+    folded_ok = True
+    if gathered is not None:
+        folded = eng.g1_sum(bytes(gathered.cpu().numpy().tobytes()))     # W = sum of per-rank accumulators
+        folded_ok = len(folded) == 96
+
+    t_all = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if dist is not None:
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+    dt_max = float(t_all.item())
+
+    if rank == 0:
+        stages = eng.profile_stages()
+        dom_name, (dom_ms, dom_cnt) = max(stages.items(), key=lambda kv: kv[1][0])
+        dom_avg_s = dom_ms / max(dom_cnt, 1) * 1e-3
+        achieved = ALGO_BYTES_PER_POINT * n / dom_avg_s / 1e9
+        value = world * n * args.steps / dt_max
+        out = {
+            "metric": "BN254 G1 MSM points/sec",
+            "value": value,
+            "unit": "points/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt_max / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32x8-montgomery (254-bit prime-field integers)",
+            "data": "synthetic",
+            "config": {
+                "workload": "standalone 2^%d-point BN254 G1 MSM, uniform Fr scalars, bases k_i*G resident in HBM "
+                            "(BASELINE.json configs[1]); one MSM (= one proof's multi_exp) per rank per step" % args.log2n,
+                "points_per_msm": n,
+                "window_bits": args.window or "auto",
+                "proofs_per_sec": world * args.steps / dt_max,
+                "exchange": "none (1 GPU)" if world == 1 else "1 all-gather of %d x 96 B + local fold" % world,
+                "bases_generate_s": t_gen,
+                "verified": "(sum k_i s_i)*G" + ("" if folded_ok else " FOLD-FAILED"),
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": dom_name,
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "avg_kernel_ms": dom_avg_s * 1e3,
+                "note": "MSM is integer-VALU-bound (v_mad_u64_u32 chains), not HBM-bound: the algorithmic "
+                        "96 B/point is a tiny fraction of peak by construction (SURVEY.md §8d)",
+                "stages_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in stages.items()},
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            sample = min(args.cpu_sample, n)
+            bases_aff = eng.bases_download(table, 0, sample)
+            rate, secs, cpu_out = cpu_baseline(bases_aff, bytes(s_np[:sample].tobytes()), sample)
+            gpu_same = eng.g1_batch_to_affine(eng.g1_msm_preloaded(table, bytes(s_np[:sample].tobytes())))
+            out["cpu_baseline"] = {
+                "value": rate,
+                "unit": "points/s",
+                "cores": 1,
+                "kind": "port",
+                "sample": "first %d points of the same workload, oracle/bn254_ref.c oracle_multi_exp_naive "
+                          "(restated reference algorithm: n double-and-add scalar muls, 1 thread), %.1f s; "
+                          "host has %d cores; cargo/rustc absent so the reference itself cannot run" % (
+                              sample, secs, os.cpu_count() or 0),
+                "matches_gpu": cpu_out == gpu_same,
+            }
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,242 @@
+"""halo2-snark-aggregator_amd — MI355X (gfx950) backend for the pure-calculation hot path of
+scroll-tech/halo2-snark-aggregator (BN254 G1 multi_exp + multi-open evaluation).
+
+This module is a thin ctypes binding of the C ABI in include/h2agg.h (libh2agg.so, built from
+csrc/*.hip by build_ext.py).  All arithmetic happens in HIP kernels; there is NO CPU fallback:
+`load_library()` raises if the shared object is missing and `H2Agg()` raises if no HIP device is
+usable.  The directory name contains a hyphen (it mirrors the reference's crate naming), so import it
+with `importlib` — see tests/conftest.py / __graft_entry__.py (`load_package()`).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional, Sequence
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libh2agg.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "h2agg.h")
+
+OK, ERR_INVALID, ERR_DIV_ZERO, ERR_EMPTY, ERR_HIP, ERR_NONCANONICAL, ERR_NOMEM = range(7)
+OP_ADD, OP_SUB, OP_MUL, OP_SQR, OP_INV = range(5)
+
+IDENTITY_JAC = (0).to_bytes(32, "little") + (1).to_bytes(32, "little") + (0).to_bytes(32, "little")
+
+
+class H2AggError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__("h2agg error %d: %s" % (code, msg))
+        self.code = code
+
+
+class EmptyMultiExp(H2AggError):
+    """multi_exp of zero pairs — the reference panics (`acc.unwrap()`, mock/arith/ecc.rs:128)."""
+
+
+class DivisionByZero(H2AggError, ZeroDivisionError):
+    """inversion of zero — the reference panics (`invert().unwrap()`, mock/arith/field.rs:113)."""
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen libh2agg.so and declare every prototype.  Fails loudly if the extension is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libh2agg.so is not built (%s). Run `python __graft_entry__.py build` — the HIP extension is "
+            "required, there is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    u8p, vp, sz, i32, u64 = C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint64
+    ctxp = C.c_void_p
+    protos = {
+        "h2agg_create": (i32, [i32, C.POINTER(ctxp)]),
+        "h2agg_destroy": (None, [ctxp]),
+        "h2agg_last_error": (C.c_char_p, [ctxp]),
+        "h2agg_set_stream": (i32, [ctxp, vp]),
+        "h2agg_synchronize": (i32, [ctxp]),
+        "h2agg_describe": (C.c_char_p, [ctxp]),
+        "h2agg_fr_batch_op": (i32, [ctxp, i32, u8p, u8p, sz, vp]),
+        "h2agg_fr_mul_add_accumulate": (i32, [ctxp, u8p, sz, u8p, vp]),
+        "h2agg_fr_sum_with_coeff_and_constant": (i32, [ctxp, u8p, u8p, sz, u8p, vp]),
+        "h2agg_g1_batch_add": (i32, [ctxp, u8p, u8p, sz, i32, vp]),
+        "h2agg_g1_batch_scalar_mul": (i32, [ctxp, u8p, u8p, sz, vp]),
+        "h2agg_g1_batch_to_affine": (i32, [ctxp, u8p, sz, vp]),
+        "h2agg_g1_sum": (i32, [ctxp, u8p, sz, vp]),
+        "h2agg_g1_msm": (i32, [ctxp, u8p, u8p, sz, vp]),
+        "h2agg_eval_flat": (i32, [ctxp, u8p, u8p, u8p, sz, vp]),
+        "h2agg_bases_upload": (i32, [ctxp, u8p, sz, C.POINTER(u64)]),
+        "h2agg_bases_generate": (i32, [ctxp, vp, sz, C.POINTER(u64)]),
+        "h2agg_bases_download": (i32, [ctxp, u64, sz, sz, vp]),
+        "h2agg_bases_free": (i32, [ctxp, u64]),
+        "h2agg_g1_msm_preloaded": (i32, [ctxp, u64, u8p, sz, vp]),
+        "h2agg_g1_msm_device": (i32, [ctxp, u64, vp, sz, vp]),
+        "h2agg_g1_msm_device_async": (i32, [ctxp, u64, vp, sz, vp]),
+        "h2agg_msm_configure": (i32, [ctxp, i32, i32, i32]),
+        "h2agg_profile_enable": (i32, [ctxp, i32]),
+        "h2agg_profile_reset": (i32, [ctxp]),
+        "h2agg_profile_stage_count": (i32, [ctxp]),
+        "h2agg_profile_stage_name": (C.c_char_p, [ctxp, i32]),
+        "h2agg_profile_stage_get": (i32, [ctxp, i32, C.POINTER(C.c_double), C.POINTER(u64)]),
+    }
+    for name, (res, args) in protos.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    lib._h2agg_protos = tuple(protos)
+    _lib = lib
+    return lib
+
+
+def exported_symbols() -> Sequence[str]:
+    return load_library()._h2agg_protos
+
+
+class H2Agg:
+    """One context = one GPU, single-thread-affine (mirrors `MockEccChip::default()` +
+    `MockFieldChip::default()` + `MockChipCtx::default()`, verify_circuit.rs:115-118)."""
+
+    def __init__(self, device: int = 0):
+        self._lib = load_library()
+        self._ctx = C.c_void_p()
+        rc = self._lib.h2agg_create(int(device), C.byref(self._ctx))
+        if rc != OK:
+            self._ctx = None
+            raise H2AggError(rc, "h2agg_create(device=%d) failed: a HIP device is required (no CPU mode)" % device)
+        self.device = device
+
+    # ------------------------------------------------------------------ plumbing
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._lib.h2agg_destroy(self._ctx)
+            self._ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc == OK:
+            return
+        msg = (self._lib.h2agg_last_error(self._ctx) or b"").decode()
+        if rc == ERR_EMPTY:
+            raise EmptyMultiExp(rc, msg)
+        if rc == ERR_DIV_ZERO:
+            raise DivisionByZero(rc, msg)
+        raise H2AggError(rc, msg)
+
+    def describe(self) -> str:
+        return self._lib.h2agg_describe(self._ctx).decode()
+
+    def set_stream(self, stream_ptr: Optional[int]):
+        self._check(self._lib.h2agg_set_stream(self._ctx, stream_ptr))
+
+    def synchronize(self):
+        self._check(self._lib.h2agg_synchronize(self._ctx))
+
+    # ------------------------------------------------------------------ Fr
+    def fr_batch_op(self, op: int, a: bytes, b: Optional[bytes] = None) -> bytes:
+        n = len(a) // 32
+        out = C.create_string_buffer(32 * n) if n else C.create_string_buffer(1)
+        self._check(self._lib.h2agg_fr_batch_op(self._ctx, op, a, b, n, out))
+        return out.raw[:32 * n]
+
+    def fr_mul_add_accumulate(self, v: bytes, b: bytes) -> bytes:
+        out = C.create_string_buffer(32)
+        self._check(self._lib.h2agg_fr_mul_add_accumulate(self._ctx, v, len(v) // 32, b, out))
+        return out.raw
+
+    def fr_sum_with_coeff_and_constant(self, x: bytes, coeff: bytes, b: bytes) -> bytes:
+        out = C.create_string_buffer(32)
+        self._check(self._lib.h2agg_fr_sum_with_coeff_and_constant(self._ctx, x, coeff, len(x) // 32, b, out))
+        return out.raw
+
+    # ------------------------------------------------------------------ G1 batch
+    def g1_batch_add(self, a_jac: bytes, b_jac: bytes, subtract: bool = False) -> bytes:
+        n = len(a_jac) // 96
+        out = C.create_string_buffer(max(96 * n, 1))
+        self._check(self._lib.h2agg_g1_batch_add(self._ctx, a_jac, b_jac, n, int(subtract), out))
+        return out.raw[:96 * n]
+
+    def g1_batch_scalar_mul(self, bases_aff: bytes, scalars: bytes) -> bytes:
+        n = len(scalars) // 32
+        out = C.create_string_buffer(max(96 * n, 1))
+        self._check(self._lib.h2agg_g1_batch_scalar_mul(self._ctx, bases_aff, scalars, n, out))
+        return out.raw[:96 * n]
+
+    def g1_batch_to_affine(self, jac: bytes) -> bytes:
+        n = len(jac) // 96
+        out = C.create_string_buffer(max(64 * n, 1))
+        self._check(self._lib.h2agg_g1_batch_to_affine(self._ctx, jac, n, out))
+        return out.raw[:64 * n]
+
+    def g1_sum(self, jac: bytes) -> bytes:
+        out = C.create_string_buffer(96)
+        self._check(self._lib.h2agg_g1_sum(self._ctx, jac, len(jac) // 96, out))
+        return out.raw
+
+    # ------------------------------------------------------------------ MSM
+    def g1_msm(self, bases_aff: bytes, scalars: bytes) -> bytes:
+        out = C.create_string_buffer(96)
+        self._check(self._lib.h2agg_g1_msm(self._ctx, bases_aff, scalars, len(scalars) // 32, out))
+        return out.raw
+
+    def eval_flat(self, pts_aff: bytes, scalars: bytes, has_scalar: bytes) -> bytes:
+        out = C.create_string_buffer(96)
+        self._check(self._lib.h2agg_eval_flat(self._ctx, pts_aff, scalars, has_scalar, len(has_scalar), out))
+        return out.raw
+
+    def bases_upload(self, bases_aff: bytes) -> int:
+        h = C.c_uint64()
+        self._check(self._lib.h2agg_bases_upload(self._ctx, bases_aff, len(bases_aff) // 64, C.byref(h)))
+        return h.value
+
+    def bases_generate(self, d_k_scalars_ptr: int, n: int) -> int:
+        h = C.c_uint64()
+        self._check(self._lib.h2agg_bases_generate(self._ctx, d_k_scalars_ptr, n, C.byref(h)))
+        return h.value
+
+    def bases_download(self, handle: int, first: int, n: int) -> bytes:
+        out = C.create_string_buffer(max(64 * n, 1))
+        self._check(self._lib.h2agg_bases_download(self._ctx, handle, first, n, out))
+        return out.raw[:64 * n]
+
+    def bases_free(self, handle: int):
+        self._check(self._lib.h2agg_bases_free(self._ctx, handle))
+
+    def g1_msm_preloaded(self, handle: int, scalars: bytes) -> bytes:
+        out = C.create_string_buffer(96)
+        self._check(self._lib.h2agg_g1_msm_preloaded(self._ctx, handle, scalars, len(scalars) // 32, out))
+        return out.raw
+
+    def g1_msm_device(self, handle: int, d_scalars_ptr: int, n: int) -> bytes:
+        out = C.create_string_buffer(96)
+        self._check(self._lib.h2agg_g1_msm_device(self._ctx, handle, d_scalars_ptr, n, out))
+        return out.raw
+
+    def g1_msm_device_async(self, handle: int, d_scalars_ptr: int, n: int, d_out_ptr: int):
+        self._check(self._lib.h2agg_g1_msm_device_async(self._ctx, handle, d_scalars_ptr, n, d_out_ptr))
+
+    # ------------------------------------------------------------------ tuning / measurement
+    def msm_configure(self, window_bits: int = 0, reduce_segment: int = 0, big_bucket_threshold: int = 0):
+        self._check(self._lib.h2agg_msm_configure(self._ctx, window_bits, reduce_segment, big_bucket_threshold))
+
+    def profile_enable(self, on: bool = True):
+        self._check(self._lib.h2agg_profile_enable(self._ctx, int(on)))
+
+    def profile_reset(self):
+        self._check(self._lib.h2agg_profile_reset(self._ctx))
+
+    def profile_stages(self):
+        """-> {stage name: (total_ms, launches)}"""
+        out = {}
+        for i in range(self._lib.h2agg_profile_stage_count(self._ctx)):
+            ms, cnt = C.c_double(), C.c_uint64()
+            self._check(self._lib.h2agg_profile_stage_get(self._ctx, i, C.byref(ms), C.byref(cnt)))
+            out[self._lib.h2agg_profile_stage_name(self._ctx, i).decode()] = (ms.value, cnt.value)
+        return out

@@ -1,0 +1,306 @@
+// Batched Fr / G1 kernels (HBM-shaped: one element per lane, 16-byte vector loads, grid-stride).
+// Each kernel names the reference operation it stands behind.
+#pragma once
+#include "g1.cuh"
+
+namespace h2agg {
+
+// status bits a kernel may raise (atomicOr into ctx->d_flags)
+enum : uint32_t { FLAG_NONCANONICAL = 1u, FLAG_DIV_ZERO = 2u };
+
+constexpr int BLOCK = 256;
+
+// ------------------------------------------------------------------ block-wide reductions through LDS
+// SoA layout lds[k * BLOCK + tid] (k = limb index) keeps every ds access conflict-free.
+template <int NLIMB>
+FP_INLINE void lds_put(uint32_t* lds, int tid, const uint32_t* v) {
+#pragma unroll
+    for (int k = 0; k < NLIMB; ++k) lds[k * BLOCK + tid] = v[k];
+}
+template <int NLIMB>
+FP_INLINE void lds_get(const uint32_t* lds, int tid, uint32_t* v) {
+#pragma unroll
+    for (int k = 0; k < NLIMB; ++k) v[k] = lds[k * BLOCK + tid];
+}
+FP_INLINE void lds_put_xyzz(uint32_t* lds, int tid, const G1XYZZ& p) {
+    lds_put<8>(lds, tid, p.x.l);
+    lds_put<8>(lds + 8 * BLOCK, tid, p.y.l);
+    lds_put<8>(lds + 16 * BLOCK, tid, p.zz.l);
+    lds_put<8>(lds + 24 * BLOCK, tid, p.zzz.l);
+}
+FP_INLINE G1XYZZ lds_get_xyzz(const uint32_t* lds, int tid) {
+    G1XYZZ p;
+    lds_get<8>(lds, tid, p.x.l);
+    lds_get<8>(lds + 8 * BLOCK, tid, p.y.l);
+    lds_get<8>(lds + 16 * BLOCK, tid, p.zz.l);
+    lds_get<8>(lds + 24 * BLOCK, tid, p.zzz.l);
+    return p;
+}
+// Sum of one XYZZ point per thread over a BLOCK-thread workgroup; result valid in thread 0.
+// lds must hold 32 * BLOCK words.
+__device__ __noinline__ G1XYZZ block_sum_xyzz(G1XYZZ v, uint32_t* lds) {
+    const int tid = threadIdx.x;
+    lds_put_xyzz(lds, tid, v);
+    __syncthreads();
+#pragma unroll 1
+    for (int s = BLOCK / 2; s >= 1; s >>= 1) {
+        if (tid < s) {
+            G1XYZZ o = lds_get_xyzz(lds, tid + s);
+            v = xyzz_add(v, o);
+            lds_put_xyzz(lds, tid, v);
+        }
+        __syncthreads();
+    }
+    return v;
+}
+__device__ __noinline__ Fr block_sum_fr(Fr v, uint32_t* lds) {
+    const int tid = threadIdx.x;
+    lds_put<8>(lds, tid, v.l);
+    __syncthreads();
+#pragma unroll 1
+    for (int s = BLOCK / 2; s >= 1; s >>= 1) {
+        if (tid < s) {
+            Fr o;
+            lds_get<8>(lds, tid + s, o.l);
+            v = fp_add<FrParams>(v, o);
+            lds_put<8>(lds, tid, v.l);
+        }
+        __syncthreads();
+    }
+    return v;
+}
+
+// ------------------------------------------------------------------ Fr element-wise
+// MockFieldChip::{add,sub,mul,square,div(->inverse)}  mock/arith/field.rs:39-55, 98-122
+__global__ void __launch_bounds__(BLOCK) k_fr_batch_op(int op, const uint8_t* __restrict__ a,
+                                                       const uint8_t* __restrict__ b, size_t n,
+                                                       uint8_t* __restrict__ out, uint32_t* flags) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        Fr x = fp_load<FrParams>(a + 32 * i);
+        uint32_t bad = !fp_is_canonical<FrParams>(x);
+        Fr y = Fr::zero();
+        if (op <= 2) {
+            y = fp_load<FrParams>(b + 32 * i);
+            bad |= !fp_is_canonical<FrParams>(y);
+        }
+        if (bad) atomicOr(flags, FLAG_NONCANONICAL);
+        Fr z;
+        switch (op) {
+        case 0: z = fp_add<FrParams>(x, y); break;  // add/sub are representation-agnostic
+        case 1: z = fp_sub<FrParams>(x, y); break;
+        case 2: z = fp_mul<FrParams>(fp_to_mont<FrParams>(x), y); break;  // (xR)*y/R = xy
+        case 3: z = fp_mul<FrParams>(fp_to_mont<FrParams>(x), x); break;
+        default:
+            if (x.is_zero()) atomicOr(flags, FLAG_DIV_ZERO);
+            z = fp_from_mont<FrParams>(fp_inv<FrParams>(fp_to_mont<FrParams>(x)));
+            break;
+        }
+        fp_store<FrParams>(out + 32 * i, z);
+    }
+}
+
+// x^e for a small runtime exponent (Montgomery in/out)
+__device__ __noinline__ Fr fr_pow_u64(Fr x, uint64_t e) {
+    Fr acc = Fr::one();
+#pragma unroll 1
+    for (int bit = 63; bit >= 0; --bit) {
+        acc = fp_sqr<FrParams>(acc);
+        if ((e >> bit) & 1) acc = fp_mul<FrParams>(acc, x);
+    }
+    return acc;
+}
+
+// ArithFieldChip::mul_add_accumulate default: acc = acc*b + v_i  (arith/field.rs:68-81)
+// Horner over n terms = sum v_i b^(n-1-i).  One workgroup: the sequence is left-padded with zeros to
+// BLOCK chunks of L terms, thread t Horner-evaluates chunk t, then thread 0 Horner-combines the BLOCK
+// partials with base b^L.
+__global__ void __launch_bounds__(BLOCK) k_fr_horner(const uint8_t* __restrict__ v, size_t n,
+                                                     const uint8_t* __restrict__ b_in, uint8_t* __restrict__ out,
+                                                     uint32_t* flags) {
+    __shared__ uint32_t lds[8 * BLOCK];
+    const int tid = threadIdx.x;
+    const size_t L = (n + BLOCK - 1) / BLOCK;
+    const size_t pad = L * BLOCK - n;
+    Fr b = fp_load<FrParams>(b_in);
+    uint32_t bad = !fp_is_canonical<FrParams>(b);
+    b = fp_to_mont<FrParams>(b);
+    Fr acc = Fr::zero();
+#pragma unroll 1
+    for (size_t k = 0; k < L; ++k) {
+        size_t g = (size_t)tid * L + k;  // index in the padded sequence
+        Fr x = Fr::zero();
+        if (g >= pad) {
+            x = fp_load<FrParams>(v + 32 * (g - pad));
+            bad |= !fp_is_canonical<FrParams>(x);
+            x = fp_to_mont<FrParams>(x);
+        }
+        acc = fp_add<FrParams>(fp_mul<FrParams>(acc, b), x);
+    }
+    if (bad) atomicOr(flags, FLAG_NONCANONICAL);
+    lds_put<8>(lds, tid, acc.l);
+    __syncthreads();
+    if (tid == 0) {
+        Fr bl = fr_pow_u64(b, (uint64_t)L);
+        Fr r = Fr::zero();
+#pragma unroll 1
+        for (int t = 0; t < BLOCK; ++t) {
+            Fr h;
+            lds_get<8>(lds, t, h.l);
+            r = fp_add<FrParams>(fp_mul<FrParams>(r, bl), h);
+        }
+        fp_store<FrParams>(out, fp_from_mont<FrParams>(r));
+    }
+}
+
+// MockFieldChip::sum_with_coeff_and_constant: b + sum x_i*coeff_i  (mock/arith/field.rs:124-135)
+__global__ void __launch_bounds__(BLOCK) k_fr_sum_coeff(const uint8_t* __restrict__ x, const uint8_t* __restrict__ cf,
+                                                        size_t n, const uint8_t* __restrict__ b_in,
+                                                        uint8_t* __restrict__ out, uint32_t* flags) {
+    __shared__ uint32_t lds[8 * BLOCK];
+    Fr acc = Fr::zero();  // canonical-domain accumulator: (xR)*c/R = x*c canonical
+    uint32_t bad = 0;
+    for (size_t i = threadIdx.x; i < n; i += BLOCK) {
+        Fr a = fp_load<FrParams>(x + 32 * i);
+        Fr c = fp_load<FrParams>(cf + 32 * i);
+        bad |= !fp_is_canonical<FrParams>(a) | !fp_is_canonical<FrParams>(c);
+        acc = fp_add<FrParams>(acc, fp_mul<FrParams>(fp_to_mont<FrParams>(a), c));
+    }
+    Fr tot = block_sum_fr(acc, lds);
+    if (threadIdx.x == 0) {
+        Fr b = fp_load<FrParams>(b_in);
+        bad |= !fp_is_canonical<FrParams>(b);
+        fp_store<FrParams>(out, fp_add<FrParams>(tot, b));
+    }
+    if (bad) atomicOr(flags, FLAG_NONCANONICAL);
+}
+
+// ------------------------------------------------------------------ G1 element-wise
+FP_INLINE uint32_t jac_noncanonical(const uint8_t* p) {
+    return !fp_is_canonical<FqParams>(fp_load<FqParams>(p)) | !fp_is_canonical<FqParams>(fp_load<FqParams>(p + 32)) |
+           !fp_is_canonical<FqParams>(fp_load<FqParams>(p + 64));
+}
+
+// MockEccChip::add / sub  (mock/arith/ecc.rs:30-46)
+__global__ void __launch_bounds__(BLOCK) k_g1_batch_add(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b,
+                                                        size_t n, int subtract, uint8_t* __restrict__ out,
+                                                        uint32_t* flags) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        if (jac_noncanonical(a + 96 * i) | jac_noncanonical(b + 96 * i)) atomicOr(flags, FLAG_NONCANONICAL);
+        G1XYZZ p = xyzz_from_jac(jac_load_canonical(a + 96 * i));
+        G1XYZZ q = xyzz_from_jac(jac_load_canonical(b + 96 * i));
+        if (subtract) q = xyzz_neg(q);
+        jac_store_canonical(out + 96 * i, jac_from_xyzz(xyzz_add(p, q)));
+    }
+}
+
+// canonical affine (64 B) -> Montgomery affine; identity (0,0) stays (0,0)
+FP_INLINE G1Affine affine_load_canonical(const uint8_t* p, uint32_t& bad) {
+    G1Affine r;
+    Fq x = fp_load<FqParams>(p), y = fp_load<FqParams>(p + 32);
+    bad |= !fp_is_canonical<FqParams>(x) | !fp_is_canonical<FqParams>(y);
+    r.x = fp_to_mont<FqParams>(x);
+    r.y = fp_to_mont<FqParams>(y);
+    return r;
+}
+
+// s * P, MSB-first double-and-add on the canonical 256-bit scalar (the reference's `G1 * Fr`)
+__device__ __noinline__ G1XYZZ g1_scalar_mul(const G1Affine& base, const Fr& s /* canonical */) {
+    G1XYZZ acc = G1XYZZ::identity();
+    Fr k = s;
+#pragma unroll 1
+    for (int it = 0; it < 256; ++it) {
+        acc = xyzz_double(acc);
+        const uint32_t top = k.l[7] >> 31;
+#pragma unroll
+        for (int i = 7; i > 0; --i) k.l[i] = (k.l[i] << 1) | (k.l[i - 1] >> 31);
+        k.l[0] <<= 1;
+        if (top) xyzz_add_affine(acc, base);
+    }
+    return acc;
+}
+
+// MockEccChip::scalar_mul / scalar_mul_constant  (mock/arith/ecc.rs:88-104)
+__global__ void __launch_bounds__(BLOCK) k_g1_batch_scalar_mul(const uint8_t* __restrict__ bases,
+                                                               const uint8_t* __restrict__ scalars, size_t n,
+                                                               uint8_t* __restrict__ out, uint32_t* flags) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        uint32_t bad = 0;
+        G1Affine p = affine_load_canonical(bases + 64 * i, bad);
+        Fr s = fp_load<FrParams>(scalars + 32 * i);
+        bad |= !fp_is_canonical<FrParams>(s);
+        if (bad) atomicOr(flags, FLAG_NONCANONICAL);
+        jac_store_canonical(out + 96 * i, jac_from_xyzz(g1_scalar_mul(p, s)));
+    }
+}
+
+FP_INLINE G1Affine affine_from_xyzz(const G1XYZZ& p) {
+    G1Affine r;
+    if (p.is_identity()) {
+        r.x = Fq::zero();
+        r.y = Fq::zero();
+        return r;
+    }
+    // 1/ZZ = ZZZ^2 / ZZ^4 ... one inversion of ZZZ gives both: 1/ZZZ = i; 1/ZZ = i^2 * ZZ^2 ... use
+    // i = 1/(ZZ*ZZZ): 1/ZZ = i*ZZZ, 1/ZZZ = i*ZZ.
+    Fq i = fp_inv<FqParams>(FQ_MUL(p.zz, p.zzz));
+    r.x = FQ_MUL(p.x, FQ_MUL(i, p.zzz));
+    r.y = FQ_MUL(p.y, FQ_MUL(i, p.zz));
+    return r;
+}
+
+// MockEccChip::to_value = to_affine  (mock/arith/ecc.rs:64-66)
+__global__ void __launch_bounds__(BLOCK) k_g1_batch_to_affine(const uint8_t* __restrict__ in, size_t n,
+                                                              uint8_t* __restrict__ out, uint32_t* flags) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        if (jac_noncanonical(in + 96 * i)) atomicOr(flags, FLAG_NONCANONICAL);
+        G1Affine a = affine_from_xyzz(xyzz_from_jac(jac_load_canonical(in + 96 * i)));
+        fp_store<FqParams>(out + 64 * i, fp_from_mont<FqParams>(a.x));
+        fp_store<FqParams>(out + 64 * i + 32, fp_from_mont<FqParams>(a.y));
+    }
+}
+
+// sum of n Jacobian points, one workgroup
+__global__ void __launch_bounds__(BLOCK) k_g1_sum(const uint8_t* __restrict__ in, size_t n, uint8_t* __restrict__ out,
+                                                  uint32_t* flags) {
+    __shared__ uint32_t lds[32 * BLOCK];
+    G1XYZZ acc = G1XYZZ::identity();
+    for (size_t i = threadIdx.x; i < n; i += BLOCK) {
+        if (jac_noncanonical(in + 96 * i)) atomicOr(flags, FLAG_NONCANONICAL);
+        acc = xyzz_add(acc, xyzz_from_jac(jac_load_canonical(in + 96 * i)));
+    }
+    G1XYZZ tot = block_sum_xyzz(acc, lds);
+    if (threadIdx.x == 0) jac_store_canonical(out, jac_from_xyzz(tot));
+}
+
+// ------------------------------------------------------------------ base tables (device resident, Montgomery)
+__global__ void __launch_bounds__(BLOCK) k_bases_to_mont(const uint8_t* __restrict__ in, size_t n,
+                                                         uint8_t* __restrict__ out, uint32_t* flags) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        uint32_t bad = 0;
+        G1Affine p = affine_load_canonical(in + 64 * i, bad);
+        if (bad) atomicOr(flags, FLAG_NONCANONICAL);
+        affine_store(out + 64 * i, p);
+    }
+}
+__global__ void __launch_bounds__(BLOCK) k_bases_from_mont(const uint8_t* __restrict__ in, size_t n,
+                                                           uint8_t* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        G1Affine p = affine_load(in + 64 * i);
+        fp_store<FqParams>(out + 64 * i, fp_from_mont<FqParams>(p.x));
+        fp_store<FqParams>(out + 64 * i + 32, fp_from_mont<FqParams>(p.y));
+    }
+}
+// bases[i] = k_i * G   (scalar_mul_constant with the generator, then to_affine; Montgomery output)
+__global__ void __launch_bounds__(BLOCK) k_bases_generate(const uint8_t* __restrict__ k, size_t n,
+                                                          uint8_t* __restrict__ out, uint32_t* flags) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        Fr s = fp_load<FrParams>(k + 32 * i);
+        if (!fp_is_canonical<FrParams>(s)) atomicOr(flags, FLAG_NONCANONICAL);
+        G1Affine g;
+        g.x = Fq::one();
+        g.y = FQ_DBL(Fq::one());
+        affine_store(out + 64 * i, affine_from_xyzz(g1_scalar_mul(g, s)));
+    }
+}
+
+}  // namespace h2agg

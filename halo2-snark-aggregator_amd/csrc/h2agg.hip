@@ -1,0 +1,654 @@
+// libh2agg.so — context management and the C ABI declared in include/h2agg.h.
+// Everything numeric runs in the HIP kernels of batch_kernels.cuh / msm_kernels.cuh; there is no CPU
+// arithmetic path in this library (a context cannot be created without a HIP device).
+#include "../../include/h2agg.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "msm_kernels.cuh"
+
+using namespace h2agg;
+
+namespace {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+enum Stage { ST_COUNT = 0, ST_SCAN, ST_SCATTER, ST_ACCUM, ST_ACCUM_BIG, ST_REDUCE, ST_WINDOW_SUM, ST_FINAL, ST_N };
+const char* const STAGE_NAMES[ST_N] = {"msm_count",          "msm_scan",   "msm_scatter",    "msm_accumulate",
+                                       "msm_accumulate_big", "msm_reduce", "msm_window_sum", "msm_final"};
+
+struct Table {
+    uint8_t* d = nullptr;  // Montgomery affine, 64 B / point
+    size_t n = 0;
+};
+
+}  // namespace
+
+struct h2agg_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::string desc;
+    int cu_count = 0;
+
+    // grow-only device workspace
+    DevBuf in_a, in_b, in_c, out, tmp_bases;                      // host-buffer entry points
+    DevBuf hist, offs, cursor, blocksum, entries, buckets, segsum, wsum, big_list, small;  // MSM
+    uint32_t* d_flags = nullptr;      // in `small`: [0] status flags, [1] big_count
+    uint8_t* d_res_xyzz = nullptr;    // in `small` + 64
+    uint8_t* d_res_jac = nullptr;     // in `small` + 256
+    uint8_t* h_pinned = nullptr;      // 4 KiB pinned staging for small results / flags
+
+    std::map<uint64_t, Table> tables;
+    uint64_t next_handle = 1;
+
+    // tuning
+    int cfg_c = 0, cfg_seg = 0, cfg_big = 0;
+
+    // profiling
+    bool profiling = false;
+    hipEvent_t ev[ST_N][2] = {};
+    bool ev_used[ST_N] = {};
+    double stage_ms[ST_N] = {};
+    uint64_t stage_launches[ST_N] = {};
+};
+
+namespace {
+
+int fail(h2agg_ctx* c, int code, const std::string& msg) {
+    if (c) c->err = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                              \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return fail(ctx, H2AGG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
+    } while (0)
+
+int ensure(h2agg_ctx* c, DevBuf& b, size_t bytes) {
+    if (bytes <= b.cap) return H2AGG_OK;
+    if (b.p) HIP_TRY(c, hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) return fail(c, H2AGG_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    b.cap = want;
+    return H2AGG_OK;
+}
+
+#define TRY(expr)                      \
+    do {                               \
+        int rc_ = (expr);              \
+        if (rc_ != H2AGG_OK) return rc_; \
+    } while (0)
+
+int grid_for(const h2agg_ctx* c, size_t n) {
+    size_t blocks = (n + BLOCK - 1) / BLOCK;
+    size_t cap = (size_t)c->cu_count * 8;
+    if (blocks > cap) blocks = cap;
+    if (blocks < 1) blocks = 1;
+    return (int)blocks;
+}
+
+int clear_flags(h2agg_ctx* c) { HIP_TRY(c, hipMemsetAsync(c->d_flags, 0, 8, c->stream)); return H2AGG_OK; }
+
+// synchronise and translate device status flags
+int finish(h2agg_ctx* c) {
+    HIP_TRY(c, hipMemcpyAsync(c->h_pinned + 2048, c->d_flags, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint32_t f;
+    memcpy(&f, c->h_pinned + 2048, 4);
+    if (f & FLAG_DIV_ZERO) return fail(c, H2AGG_ERR_DIV_ZERO, "inversion of zero (reference: invert().unwrap() panics)");
+    if (f & FLAG_NONCANONICAL) return fail(c, H2AGG_ERR_NONCANONICAL, "input integer >= modulus");
+    return H2AGG_OK;
+}
+
+int choose_window(size_t n) {
+    int lg = 0;
+    while (((size_t)1 << (lg + 1)) <= n) ++lg;
+    int c = lg - 4;
+    if (c < 3) c = 3;
+    if (c > 16) c = 16;
+    return c;
+}
+
+MsmPlan make_plan(const h2agg_ctx* c, size_t n) {
+    MsmPlan p;
+    p.c = c->cfg_c ? c->cfg_c : choose_window(n);
+    p.W = (255 + p.c - 1) / p.c;
+    p.NB = 1u << (p.c - 1);
+    p.NBT = (uint32_t)p.W * p.NB;
+    uint32_t seg = c->cfg_seg ? (uint32_t)c->cfg_seg : 16u;
+    if (seg > p.NB) seg = p.NB;
+    p.seg = seg;
+    p.spw = p.NB / seg;
+    p.big = c->cfg_big ? (uint32_t)c->cfg_big : 256u;
+    return p;
+}
+
+struct StageTimer {
+    h2agg_ctx* c;
+    int st;
+    StageTimer(h2agg_ctx* c_, int st_) : c(c_), st(st_) {
+        if (c->profiling) {
+            hipEventRecord(c->ev[st][0], c->stream);
+        }
+    }
+    ~StageTimer() {
+        if (c->profiling) {
+            hipEventRecord(c->ev[st][1], c->stream);
+            c->ev_used[st] = true;
+        }
+    }
+};
+
+void profile_collect(h2agg_ctx* c) {
+    if (!c->profiling) return;
+    hipStreamSynchronize(c->stream);
+    for (int s = 0; s < ST_N; ++s) {
+        if (!c->ev_used[s]) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->ev[s][0], c->ev[s][1]) == hipSuccess) {
+            c->stage_ms[s] += ms;
+            c->stage_launches[s] += 1;
+        }
+        c->ev_used[s] = false;
+    }
+}
+
+// The MSM proper.  d_bases: Montgomery affine table; d_scalars: canonical 32-B scalars (device).
+// Result: c->d_res_xyzz (Montgomery XYZZ) and, if d_out_jac != nullptr, canonical Jacobian there.
+int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size_t n, uint8_t* d_out_jac) {
+    if (n >= ((size_t)1 << 31)) return fail(c, H2AGG_ERR_INVALID, "n must be < 2^31");
+    const MsmPlan p = make_plan(c, n);
+    const size_t nent = n * (size_t)p.W;
+    if (nent >= ((size_t)1 << 32)) return fail(c, H2AGG_ERR_INVALID, "n * windows must be < 2^32");
+    const uint32_t nscanblocks = (p.NBT + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;
+    if (nscanblocks > (uint32_t)SCAN_PER_BLOCK) return fail(c, H2AGG_ERR_INVALID, "too many buckets");
+    const uint32_t nseg_total = (uint32_t)p.W * p.spw;
+    TRY(ensure(c, c->hist, (size_t)p.NBT * 4));
+    TRY(ensure(c, c->offs, (size_t)p.NBT * 4));
+    TRY(ensure(c, c->cursor, (size_t)p.NBT * 4));
+    TRY(ensure(c, c->blocksum, (size_t)nscanblocks * 4));
+    TRY(ensure(c, c->entries, nent * 4));
+    TRY(ensure(c, c->buckets, (size_t)p.NBT * 128));
+    TRY(ensure(c, c->segsum, (size_t)nseg_total * 128));
+    TRY(ensure(c, c->wsum, (size_t)p.W * 128));
+    TRY(ensure(c, c->big_list, (size_t)p.NBT * 4));
+    uint32_t* hist = (uint32_t*)c->hist.p;
+    uint32_t* offs = (uint32_t*)c->offs.p;
+    uint32_t* cursor = (uint32_t*)c->cursor.p;
+    uint32_t* blocksum = (uint32_t*)c->blocksum.p;
+    uint32_t* entries = (uint32_t*)c->entries.p;
+    uint8_t* buckets = (uint8_t*)c->buckets.p;
+    uint8_t* segsum = (uint8_t*)c->segsum.p;
+    uint8_t* wsum = (uint8_t*)c->wsum.p;
+    uint32_t* big_list = (uint32_t*)c->big_list.p;
+    uint32_t* big_count = c->d_flags + 1;
+    hipStream_t st = c->stream;
+    const int g = grid_for(c, n);
+
+    {
+        StageTimer t(c, ST_COUNT);
+        HIP_TRY(c, hipMemsetAsync(hist, 0, (size_t)p.NBT * 4, st));
+        HIP_TRY(c, hipMemsetAsync(big_count, 0, 4, st));
+        hipLaunchKernelGGL(k_msm_count, dim3(g), dim3(BLOCK), 0, st, d_scalars, n, p.c, p.W, p.NB, hist, c->d_flags);
+    }
+    {
+        StageTimer t(c, ST_SCAN);
+        hipLaunchKernelGGL(k_scan_local, dim3(nscanblocks), dim3(BLOCK), 0, st, hist, p.NBT, offs, blocksum);
+        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(BLOCK), 0, st, blocksum, nscanblocks);
+        hipLaunchKernelGGL(k_scan_add, dim3((p.NBT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, offs, cursor, p.NBT,
+                           blocksum);
+    }
+    {
+        StageTimer t(c, ST_SCATTER);
+        hipLaunchKernelGGL(k_msm_scatter, dim3(g), dim3(BLOCK), 0, st, d_scalars, n, p.c, p.W, p.NB, cursor, entries);
+    }
+    {
+        StageTimer t(c, ST_ACCUM);
+        hipLaunchKernelGGL(k_msm_accumulate, dim3((p.NBT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d_bases, entries,
+                           offs, hist, p.NBT, p.big, buckets, big_list, big_count);
+    }
+    {
+        StageTimer t(c, ST_ACCUM_BIG);
+        size_t maxbig = nent / ((size_t)p.big + 1) + 1;
+        size_t cap = (size_t)c->cu_count * 4;
+        if (maxbig > cap) maxbig = cap;
+        hipLaunchKernelGGL(k_msm_accumulate_big, dim3((unsigned)maxbig), dim3(BLOCK), 0, st, d_bases, entries, offs,
+                           hist, buckets, big_list, big_count);
+    }
+    {
+        StageTimer t(c, ST_REDUCE);
+        hipLaunchKernelGGL(k_msm_reduce_segments, dim3((nseg_total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, buckets,
+                           p.NB, p.seg, p.spw, nseg_total, segsum);
+    }
+    {
+        StageTimer t(c, ST_WINDOW_SUM);
+        hipLaunchKernelGGL(k_msm_window_sum, dim3(p.W), dim3(BLOCK), 0, st, segsum, p.spw, wsum);
+    }
+    {
+        StageTimer t(c, ST_FINAL);
+        hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, st, wsum, p.c, p.W, c->d_res_xyzz, d_out_jac);
+    }
+    HIP_TRY(c, hipGetLastError());
+    profile_collect(c);
+    return H2AGG_OK;
+}
+
+int set_identity_jac(uint8_t out[96]) {
+    memset(out, 0, 96);
+    out[32] = 1;
+    return 0;
+}
+
+int fetch_result_jac(h2agg_ctx* c, uint8_t out[96]) {
+    HIP_TRY(c, hipMemcpyAsync(c->h_pinned, c->d_res_jac, 96, hipMemcpyDeviceToHost, c->stream));
+    TRY(finish(c));
+    memcpy(out, c->h_pinned, 96);
+    return H2AGG_OK;
+}
+
+int bind(h2agg_ctx* c) {
+    if (!c) return H2AGG_ERR_INVALID;
+    hipError_t e = hipSetDevice(c->device);
+    if (e != hipSuccess) return fail(c, H2AGG_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return H2AGG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int h2agg_create(int device_ordinal, h2agg_ctx** out) {
+    if (!out) return H2AGG_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (device_ordinal < 0 || hipGetDeviceCount(&count) != hipSuccess || device_ordinal >= count)
+        return H2AGG_ERR_HIP;  // no CPU mode: a HIP device is required
+    if (hipSetDevice(device_ordinal) != hipSuccess) return H2AGG_ERR_HIP;
+    h2agg_ctx* c = new h2agg_ctx();
+    c->device = device_ordinal;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) {
+        delete c;
+        return H2AGG_ERR_HIP;
+    }
+    c->cu_count = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    char buf[256];
+    snprintf(buf, sizeof buf, "h2agg 0.1 %s cu=%d", prop.gcnArchName, c->cu_count);
+    c->desc = buf;
+    if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_pinned, 4096) != hipSuccess || ensure(c, c->small, 1024) != H2AGG_OK) {
+        h2agg_destroy(c);
+        return H2AGG_ERR_HIP;
+    }
+    c->stream = c->own_stream;
+    c->d_flags = (uint32_t*)c->small.p;
+    c->d_res_xyzz = (uint8_t*)c->small.p + 64;
+    c->d_res_jac = (uint8_t*)c->small.p + 256;
+    for (int s = 0; s < ST_N; ++s)
+        for (int k = 0; k < 2; ++k) hipEventCreate(&c->ev[s][k]);
+    hipMemset(c->small.p, 0, 1024);
+    *out = c;
+    return H2AGG_OK;
+}
+
+void h2agg_destroy(h2agg_ctx* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->in_a, &c->in_b,   &c->in_c,    &c->out,    &c->tmp_bases, &c->hist,     &c->offs, &c->cursor,
+                      &c->blocksum, &c->entries, &c->buckets, &c->segsum, &c->wsum,      &c->big_list, &c->small};
+    for (DevBuf* b : bufs)
+        if (b->p) hipFree(b->p);
+    for (auto& kv : c->tables)
+        if (kv.second.d) hipFree(kv.second.d);
+    if (c->h_pinned) hipHostFree(c->h_pinned);
+    for (int s = 0; s < ST_N; ++s)
+        for (int k = 0; k < 2; ++k)
+            if (c->ev[s][k]) hipEventDestroy(c->ev[s][k]);
+    if (c->own_stream) hipStreamDestroy(c->own_stream);
+    delete c;
+}
+
+const char* h2agg_last_error(const h2agg_ctx* c) { return c ? c->err.c_str() : "null context"; }
+const char* h2agg_describe(h2agg_ctx* c) { return c ? c->desc.c_str() : ""; }
+
+int h2agg_set_stream(h2agg_ctx* c, void* hip_stream) {
+    TRY(bind(c));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    return H2AGG_OK;
+}
+
+int h2agg_synchronize(h2agg_ctx* c) {
+    TRY(bind(c));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return H2AGG_OK;
+}
+
+// ---------------------------------------------------------------- Fr
+int h2agg_fr_batch_op(h2agg_ctx* c, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {
+    TRY(bind(c));
+    if (op < H2AGG_OP_ADD || op > H2AGG_OP_INV) return fail(c, H2AGG_ERR_INVALID, "unknown field op");
+    if (n == 0) return H2AGG_OK;
+    const bool binary = op <= H2AGG_OP_MUL;
+    if (!a || !out || (binary && !b)) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    TRY(ensure(c, c->in_a, 32 * n));
+    TRY(ensure(c, c->out, 32 * n));
+    HIP_TRY(c, hipMemcpyAsync(c->in_a.p, a, 32 * n, hipMemcpyHostToDevice, c->stream));
+    if (binary) {
+        TRY(ensure(c, c->in_b, 32 * n));
+        HIP_TRY(c, hipMemcpyAsync(c->in_b.p, b, 32 * n, hipMemcpyHostToDevice, c->stream));
+    }
+    TRY(clear_flags(c));
+    hipLaunchKernelGGL(k_fr_batch_op, dim3(grid_for(c, n)), dim3(BLOCK), 0, c->stream, op, (const uint8_t*)c->in_a.p,
+                       (const uint8_t*)c->in_b.p, n, (uint8_t*)c->out.p, c->d_flags);
+    HIP_TRY(c, hipMemcpyAsync(out, c->out.p, 32 * n, hipMemcpyDeviceToHost, c->stream));
+    return finish(c);
+}
+
+int h2agg_fr_mul_add_accumulate(h2agg_ctx* c, const uint8_t* v, size_t n, const uint8_t b[32], uint8_t out[32]) {
+    TRY(bind(c));
+    if ((n && !v) || !b || !out) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    TRY(ensure(c, c->in_a, 32 * n + 32));
+    TRY(ensure(c, c->in_b, 32));
+    TRY(ensure(c, c->out, 32));
+    if (n) HIP_TRY(c, hipMemcpyAsync(c->in_a.p, v, 32 * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->in_b.p, b, 32, hipMemcpyHostToDevice, c->stream));
+    TRY(clear_flags(c));
+    hipLaunchKernelGGL(k_fr_horner, dim3(1), dim3(BLOCK), 0, c->stream, (const uint8_t*)c->in_a.p, n,
+                       (const uint8_t*)c->in_b.p, (uint8_t*)c->out.p, c->d_flags);
+    HIP_TRY(c, hipMemcpyAsync(out, c->out.p, 32, hipMemcpyDeviceToHost, c->stream));
+    return finish(c);
+}
+
+int h2agg_fr_sum_with_coeff_and_constant(h2agg_ctx* c, const uint8_t* x, const uint8_t* coeff, size_t n,
+                                         const uint8_t b[32], uint8_t out[32]) {
+    TRY(bind(c));
+    if ((n && (!x || !coeff)) || !b || !out) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    TRY(ensure(c, c->in_a, 32 * n + 32));
+    TRY(ensure(c, c->in_b, 32 * n + 32));
+    TRY(ensure(c, c->in_c, 32));
+    TRY(ensure(c, c->out, 32));
+    if (n) {
+        HIP_TRY(c, hipMemcpyAsync(c->in_a.p, x, 32 * n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->in_b.p, coeff, 32 * n, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(c, hipMemcpyAsync(c->in_c.p, b, 32, hipMemcpyHostToDevice, c->stream));
+    TRY(clear_flags(c));
+    hipLaunchKernelGGL(k_fr_sum_coeff, dim3(1), dim3(BLOCK), 0, c->stream, (const uint8_t*)c->in_a.p,
+                       (const uint8_t*)c->in_b.p, n, (const uint8_t*)c->in_c.p, (uint8_t*)c->out.p, c->d_flags);
+    HIP_TRY(c, hipMemcpyAsync(out, c->out.p, 32, hipMemcpyDeviceToHost, c->stream));
+    return finish(c);
+}
+
+// ---------------------------------------------------------------- G1 batch
+int h2agg_g1_batch_add(h2agg_ctx* c, const uint8_t* a, const uint8_t* b, size_t n, int subtract, uint8_t* out) {
+    TRY(bind(c));
+    if (n == 0) return H2AGG_OK;
+    if (!a || !b || !out) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    TRY(ensure(c, c->in_a, 96 * n));
+    TRY(ensure(c, c->in_b, 96 * n));
+    TRY(ensure(c, c->out, 96 * n));
+    HIP_TRY(c, hipMemcpyAsync(c->in_a.p, a, 96 * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->in_b.p, b, 96 * n, hipMemcpyHostToDevice, c->stream));
+    TRY(clear_flags(c));
+    hipLaunchKernelGGL(k_g1_batch_add, dim3(grid_for(c, n)), dim3(BLOCK), 0, c->stream, (const uint8_t*)c->in_a.p,
+                       (const uint8_t*)c->in_b.p, n, subtract, (uint8_t*)c->out.p, c->d_flags);
+    HIP_TRY(c, hipMemcpyAsync(out, c->out.p, 96 * n, hipMemcpyDeviceToHost, c->stream));
+    return finish(c);
+}
+
+int h2agg_g1_batch_scalar_mul(h2agg_ctx* c, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t* out) {
+    TRY(bind(c));
+    if (n == 0) return H2AGG_OK;
+    if (!bases || !scalars || !out) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    TRY(ensure(c, c->in_a, 64 * n));
+    TRY(ensure(c, c->in_b, 32 * n));
+    TRY(ensure(c, c->out, 96 * n));
+    HIP_TRY(c, hipMemcpyAsync(c->in_a.p, bases, 64 * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->in_b.p, scalars, 32 * n, hipMemcpyHostToDevice, c->stream));
+    TRY(clear_flags(c));
+    hipLaunchKernelGGL(k_g1_batch_scalar_mul, dim3(grid_for(c, n)), dim3(BLOCK), 0, c->stream,
+                       (const uint8_t*)c->in_a.p, (const uint8_t*)c->in_b.p, n, (uint8_t*)c->out.p, c->d_flags);
+    HIP_TRY(c, hipMemcpyAsync(out, c->out.p, 96 * n, hipMemcpyDeviceToHost, c->stream));
+    return finish(c);
+}
+
+int h2agg_g1_batch_to_affine(h2agg_ctx* c, const uint8_t* in, size_t n, uint8_t* out) {
+    TRY(bind(c));
+    if (n == 0) return H2AGG_OK;
+    if (!in || !out) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    TRY(ensure(c, c->in_a, 96 * n));
+    TRY(ensure(c, c->out, 64 * n));
+    HIP_TRY(c, hipMemcpyAsync(c->in_a.p, in, 96 * n, hipMemcpyHostToDevice, c->stream));
+    TRY(clear_flags(c));
+    hipLaunchKernelGGL(k_g1_batch_to_affine, dim3(grid_for(c, n)), dim3(BLOCK), 0, c->stream,
+                       (const uint8_t*)c->in_a.p, n, (uint8_t*)c->out.p, c->d_flags);
+    HIP_TRY(c, hipMemcpyAsync(out, c->out.p, 64 * n, hipMemcpyDeviceToHost, c->stream));
+    return finish(c);
+}
+
+int h2agg_g1_sum(h2agg_ctx* c, const uint8_t* in, size_t n, uint8_t out[96]) {
+    TRY(bind(c));
+    if (!out || (n && !in)) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    TRY(ensure(c, c->in_a, 96 * n + 96));
+    if (n) HIP_TRY(c, hipMemcpyAsync(c->in_a.p, in, 96 * n, hipMemcpyHostToDevice, c->stream));
+    TRY(clear_flags(c));
+    hipLaunchKernelGGL(k_g1_sum, dim3(1), dim3(BLOCK), 0, c->stream, (const uint8_t*)c->in_a.p, n, c->d_res_jac,
+                       c->d_flags);
+    return fetch_result_jac(c, out);
+}
+
+// ---------------------------------------------------------------- base tables
+int h2agg_bases_upload(h2agg_ctx* c, const uint8_t* bases, size_t n, uint64_t* handle_out) {
+    TRY(bind(c));
+    if (!bases || !handle_out || n == 0) return fail(c, H2AGG_ERR_INVALID, "null buffer or n == 0");
+    Table t;
+    t.n = n;
+    if (hipMalloc((void**)&t.d, 64 * n) != hipSuccess) return fail(c, H2AGG_ERR_NOMEM, "hipMalloc(base table)");
+    int rc = ensure(c, c->tmp_bases, 64 * n);
+    if (rc == H2AGG_OK) {
+        hipError_t e = hipMemcpyAsync(c->tmp_bases.p, bases, 64 * n, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) rc = fail(c, H2AGG_ERR_HIP, hipGetErrorString(e));
+    }
+    if (rc == H2AGG_OK) rc = clear_flags(c);
+    if (rc == H2AGG_OK) {
+        hipLaunchKernelGGL(k_bases_to_mont, dim3(grid_for(c, n)), dim3(BLOCK), 0, c->stream,
+                           (const uint8_t*)c->tmp_bases.p, n, t.d, c->d_flags);
+        rc = finish(c);
+    }
+    if (rc != H2AGG_OK) {
+        hipFree(t.d);
+        return rc;
+    }
+    uint64_t h = c->next_handle++;
+    c->tables[h] = t;
+    *handle_out = h;
+    return H2AGG_OK;
+}
+
+int h2agg_bases_generate(h2agg_ctx* c, const void* d_k, size_t n, uint64_t* handle_out) {
+    TRY(bind(c));
+    if (!d_k || !handle_out || n == 0) return fail(c, H2AGG_ERR_INVALID, "null buffer or n == 0");
+    Table t;
+    t.n = n;
+    if (hipMalloc((void**)&t.d, 64 * n) != hipSuccess) return fail(c, H2AGG_ERR_NOMEM, "hipMalloc(base table)");
+    int rc = clear_flags(c);
+    if (rc == H2AGG_OK) {
+        size_t blocks = (n + BLOCK - 1) / BLOCK;
+        hipLaunchKernelGGL(k_bases_generate, dim3((unsigned)(blocks > 65535 * 16 ? 65535 * 16 : blocks)), dim3(BLOCK), 0,
+                           c->stream, (const uint8_t*)d_k, n, t.d, c->d_flags);
+        rc = finish(c);
+    }
+    if (rc != H2AGG_OK) {
+        hipFree(t.d);
+        return rc;
+    }
+    uint64_t h = c->next_handle++;
+    c->tables[h] = t;
+    *handle_out = h;
+    return H2AGG_OK;
+}
+
+int h2agg_bases_download(h2agg_ctx* c, uint64_t handle, size_t first, size_t n, uint8_t* out) {
+    TRY(bind(c));
+    auto it = c->tables.find(handle);
+    if (it == c->tables.end()) return fail(c, H2AGG_ERR_INVALID, "unknown base-table handle");
+    if (!out || first + n > it->second.n) return fail(c, H2AGG_ERR_INVALID, "range outside the table");
+    if (n == 0) return H2AGG_OK;
+    TRY(ensure(c, c->out, 64 * n));
+    hipLaunchKernelGGL(k_bases_from_mont, dim3(grid_for(c, n)), dim3(BLOCK), 0, c->stream, it->second.d + 64 * first,
+                       n, (uint8_t*)c->out.p);
+    HIP_TRY(c, hipMemcpyAsync(out, c->out.p, 64 * n, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return H2AGG_OK;
+}
+
+int h2agg_bases_free(h2agg_ctx* c, uint64_t handle) {
+    TRY(bind(c));
+    auto it = c->tables.find(handle);
+    if (it == c->tables.end()) return fail(c, H2AGG_ERR_INVALID, "unknown base-table handle");
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    hipFree(it->second.d);
+    c->tables.erase(it);
+    return H2AGG_OK;
+}
+
+// ---------------------------------------------------------------- MSM
+int h2agg_g1_msm_device_async(h2agg_ctx* c, uint64_t handle, const void* d_scalars, size_t n, void* d_out_jac) {
+    TRY(bind(c));
+    auto it = c->tables.find(handle);
+    if (it == c->tables.end()) return fail(c, H2AGG_ERR_INVALID, "unknown base-table handle");
+    if (!d_scalars || !d_out_jac) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    if (n == 0) return fail(c, H2AGG_ERR_EMPTY, "multi_exp of zero pairs (reference panics: mock/arith/ecc.rs:128)");
+    if (n > it->second.n) return fail(c, H2AGG_ERR_INVALID, "more scalars than bases in the table");
+    return msm_run(c, it->second.d, (const uint8_t*)d_scalars, n, (uint8_t*)d_out_jac);
+}
+
+int h2agg_g1_msm_device(h2agg_ctx* c, uint64_t handle, const void* d_scalars, size_t n, uint8_t out[96]) {
+    TRY(bind(c));
+    if (!out) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    set_identity_jac(out);
+    TRY(clear_flags(c));
+    TRY(h2agg_g1_msm_device_async(c, handle, d_scalars, n, c->d_res_jac));
+    return fetch_result_jac(c, out);
+}
+
+int h2agg_g1_msm_preloaded(h2agg_ctx* c, uint64_t handle, const uint8_t* scalars, size_t n, uint8_t out[96]) {
+    TRY(bind(c));
+    if (!out) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    set_identity_jac(out);
+    if (n == 0) return fail(c, H2AGG_ERR_EMPTY, "multi_exp of zero pairs (reference panics: mock/arith/ecc.rs:128)");
+    if (!scalars) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    TRY(ensure(c, c->in_b, 32 * n));
+    HIP_TRY(c, hipMemcpyAsync(c->in_b.p, scalars, 32 * n, hipMemcpyHostToDevice, c->stream));
+    return h2agg_g1_msm_device(c, handle, c->in_b.p, n, out);
+}
+
+int h2agg_g1_msm(h2agg_ctx* c, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[96]) {
+    TRY(bind(c));
+    if (!out) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    set_identity_jac(out);
+    if (n == 0) return fail(c, H2AGG_ERR_EMPTY, "multi_exp of zero pairs (reference panics: mock/arith/ecc.rs:128)");
+    if (!bases || !scalars) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    TRY(ensure(c, c->in_a, 64 * n));
+    TRY(ensure(c, c->in_b, 32 * n));
+    TRY(ensure(c, c->tmp_bases, 64 * n));
+    HIP_TRY(c, hipMemcpyAsync(c->in_a.p, bases, 64 * n, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->in_b.p, scalars, 32 * n, hipMemcpyHostToDevice, c->stream));
+    TRY(clear_flags(c));
+    hipLaunchKernelGGL(k_bases_to_mont, dim3(grid_for(c, n)), dim3(BLOCK), 0, c->stream, (const uint8_t*)c->in_a.p, n,
+                       (uint8_t*)c->tmp_bases.p, c->d_flags);
+    TRY(msm_run(c, (const uint8_t*)c->tmp_bases.p, (const uint8_t*)c->in_b.p, n, c->d_res_jac));
+    return fetch_result_jac(c, out);
+}
+
+int h2agg_eval_flat(h2agg_ctx* c, const uint8_t* pts, const uint8_t* scalars, const uint8_t* has_scalar, size_t n,
+                    uint8_t out[96]) {
+    TRY(bind(c));
+    if (!out) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    set_identity_jac(out);
+    if (n && (!pts || !scalars || !has_scalar)) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    // host-side partition of the flat list (evaluation.rs:189-196): entries with / without a scalar
+    std::vector<uint8_t> ps, ss, pn;
+    for (size_t i = 0; i < n; ++i) {
+        if (has_scalar[i]) {
+            ps.insert(ps.end(), pts + 64 * i, pts + 64 * i + 64);
+            ss.insert(ss.end(), scalars + 32 * i, scalars + 32 * i + 32);
+        } else {
+            pn.insert(pn.end(), pts + 64 * i, pts + 64 * i + 64);
+        }
+    }
+    const size_t m = ss.size() / 32, k = pn.size() / 64;
+    if (m == 0) return fail(c, H2AGG_ERR_EMPTY, "multi_exp of zero pairs (reference panics: mock/arith/ecc.rs:128)");
+    TRY(ensure(c, c->in_a, 64 * m));
+    TRY(ensure(c, c->in_b, 32 * m));
+    TRY(ensure(c, c->in_c, 64 * k + 64));
+    TRY(ensure(c, c->tmp_bases, 64 * m));
+    HIP_TRY(c, hipMemcpyAsync(c->in_a.p, ps.data(), 64 * m, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->in_b.p, ss.data(), 32 * m, hipMemcpyHostToDevice, c->stream));
+    if (k) HIP_TRY(c, hipMemcpyAsync(c->in_c.p, pn.data(), 64 * k, hipMemcpyHostToDevice, c->stream));
+    // pageable-host sources must stay alive until the copies are done
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    TRY(clear_flags(c));
+    hipLaunchKernelGGL(k_bases_to_mont, dim3(grid_for(c, m)), dim3(BLOCK), 0, c->stream, (const uint8_t*)c->in_a.p, m,
+                       (uint8_t*)c->tmp_bases.p, c->d_flags);
+    TRY(msm_run(c, (const uint8_t*)c->tmp_bases.p, (const uint8_t*)c->in_b.p, m, nullptr));
+    hipLaunchKernelGGL(k_eval_tail, dim3(1), dim3(BLOCK), 0, c->stream, (const uint8_t*)c->d_res_xyzz,
+                       (const uint8_t*)c->in_c.p, k, c->d_res_jac, c->d_flags);
+    return fetch_result_jac(c, out);
+}
+
+// ---------------------------------------------------------------- tuning / measurement
+int h2agg_msm_configure(h2agg_ctx* c, int window_bits, int reduce_segment, int big_bucket_threshold) {
+    if (!c) return H2AGG_ERR_INVALID;
+    if (window_bits != 0 && (window_bits < 2 || window_bits > 16))
+        return fail(c, H2AGG_ERR_INVALID, "window_bits must be 0 or in [2, 16]");
+    if (reduce_segment < 0 || (reduce_segment & (reduce_segment - 1)))
+        return fail(c, H2AGG_ERR_INVALID, "reduce_segment must be 0 or a power of two");
+    if (big_bucket_threshold < 0) return fail(c, H2AGG_ERR_INVALID, "big_bucket_threshold must be >= 0");
+    c->cfg_c = window_bits;
+    c->cfg_seg = reduce_segment;
+    c->cfg_big = big_bucket_threshold;
+    return H2AGG_OK;
+}
+
+int h2agg_profile_enable(h2agg_ctx* c, int enable) {
+    if (!c) return H2AGG_ERR_INVALID;
+    c->profiling = enable != 0;
+    return H2AGG_OK;
+}
+int h2agg_profile_reset(h2agg_ctx* c) {
+    if (!c) return H2AGG_ERR_INVALID;
+    for (int s = 0; s < ST_N; ++s) {
+        c->stage_ms[s] = 0;
+        c->stage_launches[s] = 0;
+    }
+    return H2AGG_OK;
+}
+int h2agg_profile_stage_count(h2agg_ctx*) { return ST_N; }
+const char* h2agg_profile_stage_name(h2agg_ctx*, int i) { return (i >= 0 && i < ST_N) ? STAGE_NAMES[i] : ""; }
+int h2agg_profile_stage_get(h2agg_ctx* c, int i, double* total_ms, uint64_t* launches) {
+    if (!c || i < 0 || i >= ST_N) return H2AGG_ERR_INVALID;
+    if (total_ms) *total_ms = c->stage_ms[i];
+    if (launches) *launches = c->stage_launches[i];
+    return H2AGG_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,277 @@
+// Pippenger bucket MSM over BN254 G1 for gfx950.
+//
+// Stands behind MockEccChip::multi_exp / ArithEccChip::multi_exp
+//   halo2-snark-aggregator-api/src/mock/arith/ecc.rs:106-129, halo2-snark-aggregator-api/src/arith/ecc.rs:42-60
+// which compute sum_i s_i * P_i as n independent 254-step double-and-add products.  The group element
+// is the same; the schedule is built for 64-lane wavefronts:
+//
+//   digits      each lane recodes one canonical scalar into W signed c-bit digits (carry chain in
+//               registers, the 256-bit value is shifted down c bits per window), coalesced 32-B reads
+//   count       histogram of (window, |digit|) keys              -> hist[W * 2^(c-1)]
+//   scan        exclusive prefix sum of hist                     -> offs[], cursor[]
+//   scatter     point index (| sign << 31) into its key's run    -> entries[n * W]
+//   accumulate  one lane per bucket walks its run: 64-B gathers of Montgomery affine bases, XYZZ mixed
+//               adds; buckets longer than `big` are handed to a workgroup each (LDS tree sum)
+//   reduce      per window sum_j (j+1) * B_j by running sums over segments of `seg` buckets, segment
+//               offsets folded in with a <= 15-bit double-and-add, then one workgroup per window
+//   final       Horner over the W window sums (c doublings each), canonical Jacobian out
+//
+// Point order inside a bucket is whatever the scatter's atomics produced; the result does not depend on
+// it because the arithmetic is exact.
+#pragma once
+#include "batch_kernels.cuh"
+
+namespace h2agg {
+
+struct MsmPlan {
+    int c;          // window bits
+    int W;          // number of windows, W*c >= 255
+    uint32_t NB;    // buckets per window = 2^(c-1)
+    uint32_t NBT;   // W * NB
+    uint32_t seg;   // buckets per reduce segment (power of two, <= NB)
+    uint32_t spw;   // segments per window = NB / seg
+    uint32_t big;   // bucket length above which a workgroup takes the bucket
+};
+
+// Signed-digit recode of a canonical scalar; calls f(window, bucket_index(0-based), negative) for every
+// non-zero digit.  Digits lie in [-2^(c-1), 2^(c-1)]; W*c >= 255 guarantees no carry out of the top window.
+template <class F>
+FP_INLINE void msm_for_each_digit(Fr s, int c, int W, F&& f) {
+    const uint32_t mask = (1u << c) - 1u;
+    const uint32_t half = 1u << (c - 1);
+    uint32_t carry = 0;
+#pragma unroll 1
+    for (int w = 0; w < W; ++w) {
+        uint32_t raw = (s.l[0] & mask) + carry;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) s.l[i] = (s.l[i] >> c) | (s.l[i + 1] << (32 - c));
+        s.l[7] >>= c;
+        const bool neg = raw > half;
+        carry = neg ? 1u : 0u;
+        const uint32_t mag = neg ? ((1u << c) - raw) : raw;
+        if (mag != 0) f(w, mag - 1u, neg);
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_msm_count(const uint8_t* __restrict__ scalars, size_t n, int c, int W,
+                                                     uint32_t NB, uint32_t* __restrict__ hist, uint32_t* flags) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        Fr s = fp_load<FrParams>(scalars + 32 * i);
+        if (!fp_is_canonical<FrParams>(s)) atomicOr(flags, FLAG_NONCANONICAL);
+        msm_for_each_digit(s, c, W, [&](int w, uint32_t b, bool) { atomicAdd(&hist[(uint32_t)w * NB + b], 1u); });
+    }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_msm_scatter(const uint8_t* __restrict__ scalars, size_t n, int c, int W,
+                                                       uint32_t NB, uint32_t* __restrict__ cursor,
+                                                       uint32_t* __restrict__ entries) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        Fr s = fp_load<FrParams>(scalars + 32 * i);
+        msm_for_each_digit(s, c, W, [&](int w, uint32_t b, bool neg) {
+            uint32_t pos = atomicAdd(&cursor[(uint32_t)w * NB + b], 1u);
+            entries[pos] = (uint32_t)i | (neg ? 0x80000000u : 0u);
+        });
+    }
+}
+
+// ------------------------------------------------------------------ exclusive scan (3 small kernels)
+constexpr int SCAN_PER_THREAD = 8;
+constexpr int SCAN_PER_BLOCK = BLOCK * SCAN_PER_THREAD;
+
+FP_INLINE uint32_t block_exclusive_scan_u32(uint32_t v, uint32_t* lds /* BLOCK words */, uint32_t& total) {
+    const int tid = threadIdx.x;
+    lds[tid] = v;
+    __syncthreads();
+#pragma unroll 1
+    for (int d = 1; d < BLOCK; d <<= 1) {
+        uint32_t t = (tid >= d) ? lds[tid - d] : 0u;
+        __syncthreads();
+        lds[tid] += t;
+        __syncthreads();
+    }
+    total = lds[BLOCK - 1];
+    return lds[tid] - v;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_scan_local(const uint32_t* __restrict__ in, uint32_t n,
+                                                      uint32_t* __restrict__ out, uint32_t* __restrict__ blocksum) {
+    __shared__ uint32_t lds[BLOCK];
+    const uint32_t base = blockIdx.x * SCAN_PER_BLOCK + threadIdx.x * SCAN_PER_THREAD;
+    uint32_t v[SCAN_PER_THREAD];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+        v[k] = (base + k < n) ? in[base + k] : 0u;
+        sum += v[k];
+    }
+    uint32_t total;
+    uint32_t off = block_exclusive_scan_u32(sum, lds, total);
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+        if (base + k < n) out[base + k] = off;
+        off += v[k];
+    }
+    if (threadIdx.x == 0) blocksum[blockIdx.x] = total;
+}
+// scans up to SCAN_PER_BLOCK block sums in place (exclusive)
+__global__ void __launch_bounds__(BLOCK) k_scan_blocks(uint32_t* __restrict__ blocksum, uint32_t nblocks) {
+    __shared__ uint32_t lds[BLOCK];
+    const uint32_t base = threadIdx.x * SCAN_PER_THREAD;
+    uint32_t v[SCAN_PER_THREAD];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+        v[k] = (base + k < nblocks) ? blocksum[base + k] : 0u;
+        sum += v[k];
+    }
+    uint32_t total;
+    uint32_t off = block_exclusive_scan_u32(sum, lds, total);
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
+        if (base + k < nblocks) blocksum[base + k] = off;
+        off += v[k];
+    }
+}
+__global__ void __launch_bounds__(BLOCK) k_scan_add(uint32_t* __restrict__ offs, uint32_t* __restrict__ cursor,
+                                                    uint32_t n, const uint32_t* __restrict__ blockoff) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i < n) {
+        uint32_t v = offs[i] + blockoff[i / SCAN_PER_BLOCK];
+        offs[i] = v;
+        cursor[i] = v;
+    }
+}
+
+// ------------------------------------------------------------------ bucket accumulation
+FP_INLINE G1Affine msm_gather(const uint8_t* __restrict__ bases, uint32_t e) {
+    G1Affine p = affine_load(bases + 64 * (size_t)(e & 0x7fffffffu));
+    if (e >> 31) p.y = fp_neg<FqParams>(p.y);
+    return p;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_msm_accumulate(const uint8_t* __restrict__ bases,
+                                                          const uint32_t* __restrict__ entries,
+                                                          const uint32_t* __restrict__ offs,
+                                                          const uint32_t* __restrict__ hist, uint32_t nbt, uint32_t big,
+                                                          uint8_t* __restrict__ buckets, uint32_t* __restrict__ big_list,
+                                                          uint32_t* __restrict__ big_count) {
+    const uint32_t key = blockIdx.x * BLOCK + threadIdx.x;
+    if (key >= nbt) return;
+    const uint32_t len = hist[key];
+    if (len > big) {
+        big_list[atomicAdd(big_count, 1u)] = key;
+        return;
+    }
+    const uint32_t* run = entries + offs[key];
+    G1XYZZ acc = G1XYZZ::identity();
+    if (len) {
+        G1Affine nxt = msm_gather(bases, run[0]);
+#pragma unroll 1
+        for (uint32_t k = 0; k < len; ++k) {
+            G1Affine cur = nxt;
+            if (k + 1 < len) nxt = msm_gather(bases, run[k + 1]);  // next gather in flight under this add
+            xyzz_add_affine(acc, cur);
+        }
+    }
+    xyzz_store(buckets + 128 * (size_t)key, acc);
+}
+
+// one workgroup per over-long bucket
+__global__ void __launch_bounds__(BLOCK) k_msm_accumulate_big(const uint8_t* __restrict__ bases,
+                                                              const uint32_t* __restrict__ entries,
+                                                              const uint32_t* __restrict__ offs,
+                                                              const uint32_t* __restrict__ hist,
+                                                              uint8_t* __restrict__ buckets,
+                                                              const uint32_t* __restrict__ big_list,
+                                                              const uint32_t* __restrict__ big_count) {
+    __shared__ uint32_t lds[32 * BLOCK];
+    const uint32_t nbig = *big_count;
+    for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {
+        const uint32_t key = big_list[b];
+        const uint32_t len = hist[key];
+        const uint32_t* run = entries + offs[key];
+        G1XYZZ acc = G1XYZZ::identity();
+#pragma unroll 1
+        for (uint32_t k = threadIdx.x; k < len; k += BLOCK) xyzz_add_affine(acc, msm_gather(bases, run[k]));
+        G1XYZZ tot = block_sum_xyzz(acc, lds);
+        if (threadIdx.x == 0) xyzz_store(buckets + 128 * (size_t)key, tot);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------ bucket reduction
+// k * P for a small k (< 2^16), MSB-first
+__device__ __noinline__ G1XYZZ xyzz_mul_small(const G1XYZZ& p, uint32_t k) {
+    G1XYZZ acc = G1XYZZ::identity();
+#pragma unroll 1
+    for (int bit = 31 - __clz((int)(k | 1u)); bit >= 0; --bit) {
+        acc = xyzz_double(acc);
+        if ((k >> bit) & 1u) acc = xyzz_add(acc, p);
+    }
+    return acc;
+}
+
+// segsum[w][s] = sum_{j in segment s} (j+1) * B[w][j]
+__global__ void __launch_bounds__(BLOCK) k_msm_reduce_segments(const uint8_t* __restrict__ buckets, uint32_t NB,
+                                                               uint32_t seg, uint32_t spw, uint32_t total,
+                                                               uint8_t* __restrict__ segsum) {
+    const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= total) return;
+    const uint32_t w = t / spw, sidx = t - w * spw;
+    const uint32_t a = sidx * seg;
+    const uint8_t* B = buckets + 128 * ((size_t)w * NB + a);
+    G1XYZZ running = G1XYZZ::identity(), acc = G1XYZZ::identity();
+#pragma unroll 1
+    for (int j = (int)seg - 1; j >= 0; --j) {
+        running = xyzz_add(running, xyzz_load(B + 128 * (size_t)j));
+        acc = xyzz_add(acc, running);
+    }
+    // sum (a + jj + 1) B = acc + a * running
+    if (a != 0 && !running.is_identity()) acc = xyzz_add(acc, xyzz_mul_small(running, a));
+    xyzz_store(segsum + 128 * (size_t)t, acc);
+}
+
+// wsum[w] = sum_s segsum[w][s]; one workgroup per window
+__global__ void __launch_bounds__(BLOCK) k_msm_window_sum(const uint8_t* __restrict__ segsum, uint32_t spw,
+                                                          uint8_t* __restrict__ wsum) {
+    __shared__ uint32_t lds[32 * BLOCK];
+    const uint32_t w = blockIdx.x;
+    G1XYZZ acc = G1XYZZ::identity();
+#pragma unroll 1
+    for (uint32_t s = threadIdx.x; s < spw; s += BLOCK)
+        acc = xyzz_add(acc, xyzz_load(segsum + 128 * ((size_t)w * spw + s)));
+    G1XYZZ tot = block_sum_xyzz(acc, lds);
+    if (threadIdx.x == 0) xyzz_store(wsum + 128 * (size_t)w, tot);
+}
+
+// result = sum_w 2^(c*w) * wsum[w]  (Horner, top window first).  Writes the XYZZ value (Montgomery, for
+// on-device consumers such as the eval tail) and the canonical Jacobian encoding of the C ABI.
+__global__ void k_msm_final(const uint8_t* __restrict__ wsum, int c, int W, uint8_t* __restrict__ out_xyzz,
+                            uint8_t* __restrict__ out_jac) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    G1XYZZ acc = xyzz_load(wsum + 128 * (size_t)(W - 1));
+#pragma unroll 1
+    for (int w = W - 2; w >= 0; --w) {
+#pragma unroll 1
+        for (int k = 0; k < c; ++k) acc = xyzz_double(acc);
+        acc = xyzz_add(acc, xyzz_load(wsum + 128 * (size_t)w));
+    }
+    if (out_xyzz) xyzz_store(out_xyzz, acc);
+    if (out_jac) jac_store_canonical(out_jac, jac_from_xyzz(acc));
+}
+
+// eval()'s tail (evaluation.rs:198-200): acc = msm_result + sum of the scalar-less points (canonical affine)
+__global__ void __launch_bounds__(BLOCK) k_eval_tail(const uint8_t* __restrict__ msm_xyzz,
+                                                     const uint8_t* __restrict__ pts_aff, size_t n,
+                                                     uint8_t* __restrict__ out_jac, uint32_t* flags) {
+    __shared__ uint32_t lds[32 * BLOCK];
+    G1XYZZ acc = G1XYZZ::identity();
+    if (threadIdx.x == 0 && msm_xyzz) acc = xyzz_load(msm_xyzz);
+    uint32_t bad = 0;
+    for (size_t i = threadIdx.x; i < n; i += BLOCK) xyzz_add_affine(acc, affine_load_canonical(pts_aff + 64 * i, bad));
+    if (bad) atomicOr(flags, FLAG_NONCANONICAL);
+    G1XYZZ tot = block_sum_xyzz(acc, lds);
+    if (threadIdx.x == 0) jac_store_canonical(out_jac, jac_from_xyzz(tot));
+}
+
+}  // namespace h2agg

@@ -1,0 +1,152 @@
+/* h2agg.h — C ABI of libh2agg.so: the MI355X (gfx950) backend for the "pure calculation context" hot
+ * path of scroll-tech/halo2-snark-aggregator.
+ *
+ * The reference has no FFI of its own (it is 100 % Rust).  The boundary this header
+ * defines is the one a GPU-backed implementation of the reference's plugin traits would bind: every
+ * entry point names the reference interface (file:line under /root/reference) whose arithmetic it
+ * replaces.  The Rust-side binding a maintainer would add is shown in INTEGRATION.md and
+ * halo2-snark-aggregator_amd/rust-shim/.
+ *
+ * Conventions
+ *   - plain C, no exceptions cross the boundary, caller owns every buffer;
+ *   - return 0 (H2AGG_OK) on success, otherwise an H2AGG_ERR_* code with a message available from
+ *     h2agg_last_error(); the Mock chips cannot construct their generic error type `E`, they panic —
+ *     the shim turns a non-zero status into a panic (mock/arith/field.rs:113, mock/arith/ecc.rs:128);
+ *   - a context is bound to ONE device and is single-thread-affine (the reference's chips are used
+ *     from one thread: SURVEY.md §8b); one context per (host thread, GPU);
+ *   - there is NO CPU mode: creating a context without a usable HIP device fails (H2AGG_ERR_HIP).
+ *
+ * Encodings (all little-endian, canonical = fully reduced integer, NOT Montgomery form)
+ *   FR / FQ      32 bytes, integer < modulus (what halo2curves `to_repr()` yields)
+ *   G1 affine    x || y, 64 bytes; identity = 64 zero bytes      (halo2curves G1Affine, `C`)
+ *   G1 jacobian  x || y || z, 96 bytes; identity has z = 0       (halo2curves G1, `C::CurveExt`)
+ *   Jacobian outputs are a valid representative of the result point, not a canonical one: compare
+ *   after h2agg_g1_batch_to_affine (the reference compares `to_affine()` values too,
+ *   halo2-snark-aggregator-circuit/src/verify_circuit.rs:180,200).
+ */
+#ifndef H2AGG_H
+#define H2AGG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct h2agg_ctx h2agg_ctx;
+
+enum {
+    H2AGG_OK = 0,
+    H2AGG_ERR_INVALID = 1,      /* bad argument (null pointer, unknown op, bad handle, bad window size) */
+    H2AGG_ERR_DIV_ZERO = 2,     /* inversion of zero: reference panics, mock/arith/field.rs:113 */
+    H2AGG_ERR_EMPTY = 3,        /* multi_exp of zero pairs: reference panics, mock/arith/ecc.rs:128 */
+    H2AGG_ERR_HIP = 4,          /* HIP runtime / device failure */
+    H2AGG_ERR_NONCANONICAL = 5, /* an input integer was >= its modulus */
+    H2AGG_ERR_NOMEM = 6
+};
+
+/* field ops of h2agg_fr_batch_op */
+enum { H2AGG_OP_ADD = 0, H2AGG_OP_SUB = 1, H2AGG_OP_MUL = 2, H2AGG_OP_SQR = 3, H2AGG_OP_INV = 4 };
+
+/* ---- lifetime -------------------------------------------------------------------------------------
+ * replaces: `MockEccChip::default()` / `MockFieldChip::default()` / `MockChipCtx::default()`
+ * (halo2-snark-aggregator-circuit/src/verify_circuit.rs:115-118). */
+int h2agg_create(int device_ordinal, h2agg_ctx** out);
+void h2agg_destroy(h2agg_ctx* ctx);
+const char* h2agg_last_error(const h2agg_ctx* ctx);
+/* Use an existing HIP stream (hipStream_t) for every launch of this context; NULL = the context's own. */
+int h2agg_set_stream(h2agg_ctx* ctx, void* hip_stream);
+/* Block until everything queued on the context's stream has finished. */
+int h2agg_synchronize(h2agg_ctx* ctx);
+/* Library / device description, e.g. "h2agg 0.1 gfx950 cu=256"; valid until the context is destroyed. */
+const char* h2agg_describe(h2agg_ctx* ctx);
+
+/* ---- Fr batch ops (host buffers) ------------------------------------------------------------------
+ * replaces: MockFieldChip::{add,sub,mul,square,div} element-wise over n operands
+ * (halo2-snark-aggregator-api/src/mock/arith/field.rs:39-55, 98-122).  `b` is ignored for SQR / INV.
+ * INV of 0 -> H2AGG_ERR_DIV_ZERO (reference: `invert().unwrap()` panics).  n == 0 is a no-op. */
+int h2agg_fr_batch_op(h2agg_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out);
+
+/* replaces: ArithFieldChip::mul_add_accumulate default (Horner: acc = acc*b + v_i, acc_0 = 0)
+ * (halo2-snark-aggregator-api/src/arith/field.rs:68-81). */
+int h2agg_fr_mul_add_accumulate(h2agg_ctx* ctx, const uint8_t* v, size_t n, const uint8_t b[32], uint8_t out[32]);
+
+/* replaces: MockFieldChip::sum_with_coeff_and_constant (acc = b + sum x_i*coeff_i)
+ * (halo2-snark-aggregator-api/src/mock/arith/field.rs:124-135). */
+int h2agg_fr_sum_with_coeff_and_constant(h2agg_ctx* ctx, const uint8_t* x, const uint8_t* coeff, size_t n,
+                                         const uint8_t b[32], uint8_t out[32]);
+
+/* ---- G1 batch ops (host buffers) ------------------------------------------------------------------
+ * replaces: MockEccChip::add / sub (`*a + *b`, `*a - *b`) over n Jacobian pairs
+ * (halo2-snark-aggregator-api/src/mock/arith/ecc.rs:30-46). */
+int h2agg_g1_batch_add(h2agg_ctx* ctx, const uint8_t* a_jac, const uint8_t* b_jac, size_t n, int subtract,
+                       uint8_t* out_jac);
+
+/* replaces: MockEccChip::scalar_mul / scalar_mul_constant (`rhs * lhs`) over n (affine base, scalar) pairs
+ * (halo2-snark-aggregator-api/src/mock/arith/ecc.rs:88-104); also the loop body of
+ * assign_instance_commitment (halo2-snark-aggregator-api/src/systems/halo2/verify.rs:623-635). */
+int h2agg_g1_batch_scalar_mul(h2agg_ctx* ctx, const uint8_t* bases_aff, const uint8_t* scalars, size_t n,
+                              uint8_t* out_jac);
+
+/* replaces: MockEccChip::to_value = `to_affine` (halo2-snark-aggregator-api/src/mock/arith/ecc.rs:64-66). */
+int h2agg_g1_batch_to_affine(h2agg_ctx* ctx, const uint8_t* in_jac, size_t n, uint8_t* out_aff);
+
+/* Sum of n Jacobian points (the local fold after the multi-GPU all-gather of partial (W_x, W_g),
+ * SURVEY.md §8e; arithmetic = MockEccChip::add, mock/arith/ecc.rs:30-37).  n == 0 -> identity. */
+int h2agg_g1_sum(h2agg_ctx* ctx, const uint8_t* in_jac, size_t n, uint8_t out_jac[96]);
+
+/* ---- multi-scalar multiplication ------------------------------------------------------------------
+ * replaces: MockEccChip::multi_exp / ArithEccChip::multi_exp default — sum_i scalars[i] * bases[i]
+ * (halo2-snark-aggregator-api/src/mock/arith/ecc.rs:106-129, .../arith/ecc.rs:42-60), called from
+ * EvaluationQuerySchema::eval (halo2-snark-aggregator-api/src/systems/halo2/evaluation.rs:197).
+ * The reference computes n independent double-and-add products; this computes the same group element
+ * with a Pippenger bucket method on the GPU.  n == 0 -> H2AGG_ERR_EMPTY (the reference panics); the
+ * output buffer is then set to the identity so a caller that prefers "empty sum = identity" can
+ * ignore that one status. */
+int h2agg_g1_msm(h2agg_ctx* ctx, const uint8_t* bases_aff, const uint8_t* scalars, size_t n, uint8_t out_jac[96]);
+
+/* replaces: eval()'s flat tail — multi_exp over the entries that carry a scalar, then `pchip.add` of
+ * every scalar-less point (halo2-snark-aggregator-api/src/systems/halo2/evaluation.rs:189-200).
+ * has_scalar[i] != 0 marks entries with a scalar.  No scalar-carrying entry -> H2AGG_ERR_EMPTY. */
+int h2agg_eval_flat(h2agg_ctx* ctx, const uint8_t* pts_aff, const uint8_t* scalars, const uint8_t* has_scalar,
+                    size_t n, uint8_t out_jac[96]);
+
+/* ---- device-resident bases / scalars (SRS-style fixed bases; inputs stay in HBM) ------------------
+ * A base table lives on the device in Montgomery form (64 B / point).  Used for the instance-commitment
+ * MSM against `params.g_lagrange` (halo2-snark-aggregator-api/src/systems/halo2/verify.rs:623-635) and
+ * for benchmarking with inputs already resident. */
+int h2agg_bases_upload(h2agg_ctx* ctx, const uint8_t* bases_aff, size_t n, uint64_t* handle_out);
+/* bases[i] = k_i * G for n canonical Fr scalars held in DEVICE memory (workload generation: the
+ * expected MSM is then (sum k_i * s_i) * G).  Arithmetic = scalar_mul_constant + to_affine. */
+int h2agg_bases_generate(h2agg_ctx* ctx, const void* d_k_scalars, size_t n, uint64_t* handle_out);
+int h2agg_bases_download(h2agg_ctx* ctx, uint64_t handle, size_t first, size_t n, uint8_t* out_aff);
+int h2agg_bases_free(h2agg_ctx* ctx, uint64_t handle);
+
+/* scalars in host memory, bases preloaded; uses the first n bases of the table */
+int h2agg_g1_msm_preloaded(h2agg_ctx* ctx, uint64_t bases_handle, const uint8_t* scalars, size_t n,
+                           uint8_t out_jac[96]);
+/* scalars in DEVICE memory (n x 32 B canonical); synchronous, result to host */
+int h2agg_g1_msm_device(h2agg_ctx* ctx, uint64_t bases_handle, const void* d_scalars, size_t n,
+                        uint8_t out_jac[96]);
+/* as above but asynchronous on the context's stream: the 96-byte canonical Jacobian result is written
+ * to DEVICE memory at d_out_jac; nothing is copied to the host and the call does not synchronise. */
+int h2agg_g1_msm_device_async(h2agg_ctx* ctx, uint64_t bases_handle, const void* d_scalars, size_t n,
+                              void* d_out_jac);
+
+/* ---- tuning / measurement -------------------------------------------------------------------------
+ * window_bits: Pippenger window c in [2, 16], 0 = choose from n.  Other knobs: 0 = default. */
+int h2agg_msm_configure(h2agg_ctx* ctx, int window_bits, int reduce_segment, int big_bucket_threshold);
+/* When enabled, every MSM stage is bracketed by HIP events on the context's stream and per-stage times
+ * are accumulated (this makes the async entry point synchronise at the end of each call). */
+int h2agg_profile_enable(h2agg_ctx* ctx, int enable);
+int h2agg_profile_reset(h2agg_ctx* ctx);
+/* Number of stages; name of stage i; accumulated milliseconds and launch count of stage i. */
+int h2agg_profile_stage_count(h2agg_ctx* ctx);
+const char* h2agg_profile_stage_name(h2agg_ctx* ctx, int i);
+int h2agg_profile_stage_get(h2agg_ctx* ctx, int i, double* total_ms, uint64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* H2AGG_H */

@@ -1,0 +1,244 @@
+"""GPU parity tests: every C-ABI entry point against the oracle on the same seeded inputs (bit-exact).
+
+Mirrors the reference's own checks for the pure-calculation context: the algebraic identities of
+halo2-ecc-circuit-lib/src/tests/five_native_ecc.rs:60-240 (add / mul / shamir incl. zero scalar and
+identity point) and the Mock-chip runs of halo2-snark-aggregator-api/src/tests/systems/halo2/*/.
+"""
+import pytest
+
+from oracle import bn254 as O, cref
+from tests.util import G_BYTES, fr_bytes, norm, points_from_scalars, rand_frs, to_jac_bytes
+
+pytestmark = pytest.mark.gpu
+
+
+# ------------------------------------------------------------------ Fr
+@pytest.mark.parametrize("op", [0, 1, 2, 3, 4])
+def test_fr_batch_op(eng, op):
+    rng = O.SplitMix64(100 + op)
+    n = 1000
+    a = rand_frs(rng, n - 6) + [0, 1, O.R - 1, 2, O.R - 2, 1]
+    b = rand_frs(rng, n - 6) + [0, O.R - 1, O.R - 1, 1, 3, 0]
+    if op == 4:
+        a = [x if x else 7 for x in a]
+    ab, bb = fr_bytes(a), fr_bytes(b)
+    got = eng.fr_batch_op(op, ab, bb if op <= 2 else None)
+    assert got == cref.field_batch_op(0, op, ab, bb if op <= 2 else None, n)
+
+
+def test_fr_inv_zero_is_an_error(eng, pkg):
+    # MockFieldChip::div: `b.invert().unwrap()` panics on zero (mock/arith/field.rs:113)
+    with pytest.raises(pkg.DivisionByZero):
+        eng.fr_batch_op(4, fr_bytes([5, 0, 9]))
+
+
+def test_fr_noncanonical_rejected(eng, pkg):
+    bad = (O.R).to_bytes(32, "little")
+    with pytest.raises(pkg.H2AggError) as ei:
+        eng.fr_batch_op(0, bad, fr_bytes([1]))
+    assert ei.value.code == pkg.ERR_NONCANONICAL
+
+
+def test_fr_empty_is_noop(eng):
+    assert eng.fr_batch_op(2, b"", b"") == b""
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 255, 256, 257, 1000, 5003])
+def test_fr_mul_add_accumulate(eng, n):
+    rng = O.SplitMix64(7 + n)
+    v = rand_frs(rng, n)
+    b = rng.fr()
+    acc = 0
+    for x in v:
+        acc = (acc * b + x) % O.R                       # arith/field.rs:68-81
+    assert eng.fr_mul_add_accumulate(fr_bytes(v), O.fe_to_bytes(b)) == O.fe_to_bytes(acc)
+    assert cref.fr_mul_add_accumulate(fr_bytes(v), n, O.fe_to_bytes(b)) == O.fe_to_bytes(acc)
+
+
+@pytest.mark.parametrize("n", [0, 1, 300, 1025])
+def test_fr_sum_with_coeff_and_constant(eng, n):
+    rng = O.SplitMix64(70 + n)
+    x, cf, b = rand_frs(rng, n), rand_frs(rng, n), rng.fr()
+    want = (b + sum(p * q for p, q in zip(x, cf))) % O.R   # mock/arith/field.rs:124-135
+    assert eng.fr_sum_with_coeff_and_constant(fr_bytes(x), fr_bytes(cf), O.fe_to_bytes(b)) == O.fe_to_bytes(want)
+
+
+# ------------------------------------------------------------------ G1 element-wise
+def _edge_pairs():
+    rng = O.SplitMix64(5)
+    ks = rand_frs(rng, 8)
+    pts = [O.scalar_mul(k, O.G1) for k in ks]
+    P, Q = pts[0], pts[1]
+    pairs = [(P, Q), (P, P), (P, O.neg(P)), (O.INF, P), (P, O.INF), (O.INF, O.INF), (O.G1, O.G1), (Q, O.neg(Q))]
+    return pairs
+
+
+@pytest.mark.parametrize("subtract", [False, True])
+def test_g1_batch_add_edges(eng, subtract):
+    pairs = _edge_pairs()
+    rng = O.SplitMix64(11)
+    a = b"".join(O.jac_to_bytes(p, rng.fr() % O.P or 1) for p, _ in pairs)
+    b = b"".join(O.jac_to_bytes(q, rng.fr() % O.P or 1) for _, q in pairs)
+    got = norm(eng, eng.g1_batch_add(a, b, subtract))
+    want = b"".join(O.aff_to_bytes(O.sub(p, q) if subtract else O.add(p, q)) for p, q in pairs)
+    assert got == want
+    assert norm(None, cref.g1_batch_add(a, b, len(pairs), subtract)) == want
+
+
+def test_g1_batch_add_random(eng):
+    rng = O.SplitMix64(12)
+    n = 700
+    pa, pb = points_from_scalars(rand_frs(rng, n)), points_from_scalars(rand_frs(rng, n))
+    za = [rng.fr() % O.P or 1 for _ in range(n)]
+    zb = [1 if i % 3 == 0 else (rng.fr() % O.P or 1) for i in range(n)]
+    a, b = to_jac_bytes(pa, za), to_jac_bytes(pb, zb)
+    assert norm(eng, eng.g1_batch_add(a, b)) == norm(None, cref.g1_batch_add(a, b, n))
+
+
+def test_g1_add_identity_five_native_ecc(eng):
+    # five_native_ecc.rs:60-88: s1*G + s2*G == (s1+s2)*G
+    rng = O.SplitMix64(13)
+    s1, s2 = rng.fr(), rng.fr()
+    j = eng.g1_batch_scalar_mul(G_BYTES * 3, fr_bytes([s1, s2, s1 + s2]))
+    lhs = norm(eng, eng.g1_batch_add(j[:96], j[96:192]))
+    assert lhs == norm(eng, j[192:288])
+
+
+def test_g1_batch_scalar_mul(eng):
+    rng = O.SplitMix64(14)
+    n = 200
+    ks = rand_frs(rng, n)
+    bases = bytearray(points_from_scalars(ks))
+    bases[64 * 5:64 * 6] = bytes(64)                         # identity base (five_native_ecc.rs:118-150)
+    ss = rand_frs(rng, n)
+    ss[0], ss[1], ss[2], ss[3] = 0, 1, O.R - 1, 2
+    got = norm(eng, eng.g1_batch_scalar_mul(bytes(bases), fr_bytes(ss)))
+    want = norm(None, cref.g1_batch_scalar_mul(bytes(bases), fr_bytes(ss), n))
+    assert got == want
+    assert got[:64] == bytes(64) and got[64 * 5:64 * 6] == bytes(64)
+
+
+def test_g1_batch_to_affine(eng):
+    rng = O.SplitMix64(15)
+    n = 300
+    aff = bytearray(points_from_scalars(rand_frs(rng, n)))
+    aff[64 * 7:64 * 8] = bytes(64)
+    jac = to_jac_bytes(bytes(aff), [rng.fr() % O.P or 1 for _ in range(n)])
+    assert eng.g1_batch_to_affine(jac) == bytes(aff)
+
+
+@pytest.mark.parametrize("n", [0, 1, 2, 8, 300])
+def test_g1_sum(eng, n):
+    rng = O.SplitMix64(16 + n)
+    ks = rand_frs(rng, n)
+    jac = to_jac_bytes(points_from_scalars(ks), [rng.fr() % O.P or 1 for _ in range(n)])
+    want = O.aff_to_bytes(O.scalar_mul(sum(ks) % O.R, O.G1))
+    assert norm(eng, eng.g1_sum(jac)) == want
+
+
+# ------------------------------------------------------------------ multi_exp
+def _msm_case(rng, n, kind):
+    ks = rand_frs(rng, n)
+    ss = rand_frs(rng, n)
+    if kind == "edges" and n >= 8:
+        ss[0] = 0
+        ss[1] = O.R - 1
+        ss[2] = 1
+        ks[3] = ks[4]                 # duplicate base: P + P inside a bucket when scalars collide
+        ss[3] = ss[4]
+        ks[5] = (-ks[6]) % O.R        # a base and its negation with the same scalar: bucket sums to identity
+        ss[5] = ss[6]
+    if kind == "equal_scalars":
+        ss = [ss[0]] * n              # every point in the same bucket of every window (big-bucket path)
+    if kind == "small_scalars":
+        ss = [s % 1000 for s in ss]   # upper windows empty
+    bases = bytearray(points_from_scalars(ks))
+    if kind == "edges" and n >= 8:
+        bases[64 * 7:64 * 8] = bytes(64)   # identity base
+        ks[7] = 0
+    want_k = sum(k * s for k, s in zip(ks, ss)) % O.R
+    return bytes(bases), fr_bytes(ss), O.aff_to_bytes(O.scalar_mul(want_k, O.G1))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 64, 256, 1024])
+@pytest.mark.parametrize("kind", ["random", "edges"])
+def test_msm_vs_reference_algorithm(eng, n, kind):
+    rng = O.SplitMix64(1000 + n)
+    bases, sb, want = _msm_case(rng, n, kind)
+    got = norm(eng, eng.g1_msm(bases, sb))
+    assert got == cref.multi_exp_naive(bases, sb, n)      # mock/arith/ecc.rs:106-129 restated
+    assert got == want                                    # (sum k_i s_i) G
+
+
+@pytest.mark.parametrize("c", [2, 3, 5, 8, 11, 13, 16])
+def test_msm_every_window_size(eng, c):
+    rng = O.SplitMix64(2000 + c)
+    n = 600
+    bases, sb, want = _msm_case(rng, n, "edges")
+    eng.msm_configure(window_bits=c)
+    try:
+        assert norm(eng, eng.g1_msm(bases, sb)) == want
+    finally:
+        eng.msm_configure()
+
+
+@pytest.mark.parametrize("kind", ["equal_scalars", "small_scalars"])
+def test_msm_skewed_buckets(eng, kind):
+    rng = O.SplitMix64(3000)
+    n = 3000
+    bases, sb, want = _msm_case(rng, n, kind)
+    eng.msm_configure(window_bits=8, big_bucket_threshold=64)
+    try:
+        assert norm(eng, eng.g1_msm(bases, sb)) == want
+    finally:
+        eng.msm_configure()
+    assert norm(eng, eng.g1_msm(bases, sb)) == want
+
+
+def test_msm_all_zero_scalars_and_identity_bases(eng):
+    n = 100
+    rng = O.SplitMix64(3100)
+    bases = points_from_scalars(rand_frs(rng, n))
+    assert norm(eng, eng.g1_msm(bases, bytes(32 * n))) == bytes(64)
+    assert norm(eng, eng.g1_msm(bytes(64 * n), fr_bytes(rand_frs(rng, n)))) == bytes(64)
+
+
+def test_msm_empty_is_the_reference_panic(eng, pkg):
+    with pytest.raises(pkg.EmptyMultiExp):
+        eng.g1_msm(b"", b"")
+
+
+def test_msm_noncanonical_scalar_rejected(eng, pkg):
+    with pytest.raises(pkg.H2AggError) as ei:
+        eng.g1_msm(G_BYTES, (O.R + 5).to_bytes(32, "little"))
+    assert ei.value.code == pkg.ERR_NONCANONICAL
+
+
+def test_msm_preloaded_and_prefix(eng):
+    rng = O.SplitMix64(3200)
+    n = 500
+    ks, ss = rand_frs(rng, n), rand_frs(rng, n)
+    bases = points_from_scalars(ks)
+    h = eng.bases_upload(bases)
+    try:
+        assert eng.bases_download(h, 0, n) == bases
+        for m in (n, 123):
+            want = O.aff_to_bytes(O.scalar_mul(sum(k * s for k, s in zip(ks[:m], ss[:m])) % O.R, O.G1))
+            assert norm(eng, eng.g1_msm_preloaded(h, fr_bytes(ss[:m]))) == want
+    finally:
+        eng.bases_free(h)
+
+
+@pytest.mark.parametrize("n", [5, 300, 2000])
+def test_eval_flat(eng, n):
+    # evaluation.rs:189-200: multi_exp over scalar-carrying entries + add of scalar-less points
+    rng = O.SplitMix64(4000 + n)
+    pts = points_from_scalars(rand_frs(rng, n))
+    ss = fr_bytes(rand_frs(rng, n))
+    has = bytes([0 if i % 5 == 1 else 1 for i in range(n)])
+    assert norm(eng, eng.eval_flat(pts, ss, has)) == cref.eval_flat(pts, ss, has, n)
+
+
+def test_eval_flat_without_scalars_is_the_reference_panic(eng, pkg):
+    with pytest.raises(pkg.EmptyMultiExp):
+        eng.eval_flat(G_BYTES * 2, bytes(64), bytes(2))
