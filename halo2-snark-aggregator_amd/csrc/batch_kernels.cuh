@@ -22,22 +22,23 @@ FP_INLINE void lds_get(const uint32_t* lds, int tid, uint32_t* v) {
 #pragma unroll
     for (int k = 0; k < NLIMB; ++k) v[k] = lds[k * BLOCK + tid];
 }
+constexpr int XYZZ_WORDS = 4 * NL;  // 36
 FP_INLINE void lds_put_xyzz(uint32_t* lds, int tid, const G1XYZZ& p) {
-    lds_put<8>(lds, tid, p.x.l);
-    lds_put<8>(lds + 8 * BLOCK, tid, p.y.l);
-    lds_put<8>(lds + 16 * BLOCK, tid, p.zz.l);
-    lds_put<8>(lds + 24 * BLOCK, tid, p.zzz.l);
+    lds_put<NL>(lds, tid, p.x.l);
+    lds_put<NL>(lds + NL * BLOCK, tid, p.y.l);
+    lds_put<NL>(lds + 2 * NL * BLOCK, tid, p.zz.l);
+    lds_put<NL>(lds + 3 * NL * BLOCK, tid, p.zzz.l);
 }
 FP_INLINE G1XYZZ lds_get_xyzz(const uint32_t* lds, int tid) {
     G1XYZZ p;
-    lds_get<8>(lds, tid, p.x.l);
-    lds_get<8>(lds + 8 * BLOCK, tid, p.y.l);
-    lds_get<8>(lds + 16 * BLOCK, tid, p.zz.l);
-    lds_get<8>(lds + 24 * BLOCK, tid, p.zzz.l);
+    lds_get<NL>(lds, tid, p.x.l);
+    lds_get<NL>(lds + NL * BLOCK, tid, p.y.l);
+    lds_get<NL>(lds + 2 * NL * BLOCK, tid, p.zz.l);
+    lds_get<NL>(lds + 3 * NL * BLOCK, tid, p.zzz.l);
     return p;
 }
 // Sum of one XYZZ point per thread over a BLOCK-thread workgroup; result valid in thread 0.
-// lds must hold 32 * BLOCK words.
+// lds must hold XYZZ_WORDS * BLOCK words.
 __device__ __noinline__ G1XYZZ block_sum_xyzz(G1XYZZ v, uint32_t* lds) {
     const int tid = threadIdx.x;
     lds_put_xyzz(lds, tid, v);
@@ -53,17 +54,18 @@ __device__ __noinline__ G1XYZZ block_sum_xyzz(G1XYZZ v, uint32_t* lds) {
     }
     return v;
 }
+// canonical (< r) in, canonical out; lds must hold NL * BLOCK words
 __device__ __noinline__ Fr block_sum_fr(Fr v, uint32_t* lds) {
     const int tid = threadIdx.x;
-    lds_put<8>(lds, tid, v.l);
+    lds_put<NL>(lds, tid, v.l);
     __syncthreads();
 #pragma unroll 1
     for (int s = BLOCK / 2; s >= 1; s >>= 1) {
         if (tid < s) {
             Fr o;
-            lds_get<8>(lds, tid + s, o.l);
-            v = fp_add<FrParams>(v, o);
-            lds_put<8>(lds, tid, v.l);
+            lds_get<NL>(lds, tid + s, o.l);
+            v = fp_cond_sub<FrParams>(fp_add<FrParams>(v, o));
+            lds_put<NL>(lds, tid, v.l);
         }
         __syncthreads();
     }
@@ -84,14 +86,14 @@ __global__ void __launch_bounds__(BLOCK) k_fr_batch_op(int op, const uint8_t* __
             bad |= !fp_is_canonical<FrParams>(y);
         }
         if (bad) atomicOr(flags, FLAG_NONCANONICAL);
-        Fr z;
+        Fr z;  // canonical inputs (< r); every branch ends in the canonical representative
         switch (op) {
-        case 0: z = fp_add<FrParams>(x, y); break;  // add/sub are representation-agnostic
-        case 1: z = fp_sub<FrParams>(x, y); break;
-        case 2: z = fp_mul<FrParams>(fp_to_mont<FrParams>(x), y); break;  // (xR)*y/R = xy
-        case 3: z = fp_mul<FrParams>(fp_to_mont<FrParams>(x), x); break;
+        case 0: z = fp_cond_sub<FrParams>(fp_add<FrParams>(x, y)); break;
+        case 1: z = fp_cond_sub<FrParams>(fp_sub<1, FrParams>(x, y)); break;
+        case 2: z = fp_cond_sub<FrParams>(fp_mul<FrParams>(fp_to_mont<FrParams>(x), y)); break;  // (xR)*y/R = xy
+        case 3: z = fp_cond_sub<FrParams>(fp_mul<FrParams>(fp_to_mont<FrParams>(x), x)); break;
         default:
-            if (x.is_zero()) atomicOr(flags, FLAG_DIV_ZERO);
+            if (x.is_zero_int()) atomicOr(flags, FLAG_DIV_ZERO);
             z = fp_from_mont<FrParams>(fp_inv<FrParams>(fp_to_mont<FrParams>(x)));
             break;
         }
@@ -117,7 +119,7 @@ __device__ __noinline__ Fr fr_pow_u64(Fr x, uint64_t e) {
 __global__ void __launch_bounds__(BLOCK) k_fr_horner(const uint8_t* __restrict__ v, size_t n,
                                                      const uint8_t* __restrict__ b_in, uint8_t* __restrict__ out,
                                                      uint32_t* flags) {
-    __shared__ uint32_t lds[8 * BLOCK];
+    __shared__ uint32_t lds[NL * BLOCK];
     const int tid = threadIdx.x;
     const size_t L = (n + BLOCK - 1) / BLOCK;
     const size_t pad = L * BLOCK - n;
@@ -137,7 +139,7 @@ __global__ void __launch_bounds__(BLOCK) k_fr_horner(const uint8_t* __restrict__
         acc = fp_add<FrParams>(fp_mul<FrParams>(acc, b), x);
     }
     if (bad) atomicOr(flags, FLAG_NONCANONICAL);
-    lds_put<8>(lds, tid, acc.l);
+    lds_put<NL>(lds, tid, acc.l);
     __syncthreads();
     if (tid == 0) {
         Fr bl = fr_pow_u64(b, (uint64_t)L);
@@ -145,7 +147,7 @@ __global__ void __launch_bounds__(BLOCK) k_fr_horner(const uint8_t* __restrict__
 #pragma unroll 1
         for (int t = 0; t < BLOCK; ++t) {
             Fr h;
-            lds_get<8>(lds, t, h.l);
+            lds_get<NL>(lds, t, h.l);
             r = fp_add<FrParams>(fp_mul<FrParams>(r, bl), h);
         }
         fp_store<FrParams>(out, fp_from_mont<FrParams>(r));
@@ -156,20 +158,21 @@ __global__ void __launch_bounds__(BLOCK) k_fr_horner(const uint8_t* __restrict__
 __global__ void __launch_bounds__(BLOCK) k_fr_sum_coeff(const uint8_t* __restrict__ x, const uint8_t* __restrict__ cf,
                                                         size_t n, const uint8_t* __restrict__ b_in,
                                                         uint8_t* __restrict__ out, uint32_t* flags) {
-    __shared__ uint32_t lds[8 * BLOCK];
+    __shared__ uint32_t lds[NL * BLOCK];
     Fr acc = Fr::zero();  // canonical-domain accumulator: (xR)*c/R = x*c canonical
     uint32_t bad = 0;
     for (size_t i = threadIdx.x; i < n; i += BLOCK) {
         Fr a = fp_load<FrParams>(x + 32 * i);
         Fr c = fp_load<FrParams>(cf + 32 * i);
         bad |= !fp_is_canonical<FrParams>(a) | !fp_is_canonical<FrParams>(c);
-        acc = fp_add<FrParams>(acc, fp_mul<FrParams>(fp_to_mont<FrParams>(a), c));
+        Fr t = fp_cond_sub<FrParams>(fp_mul<FrParams>(fp_to_mont<FrParams>(a), c));
+        acc = fp_cond_sub<FrParams>(fp_add<FrParams>(acc, t));
     }
     Fr tot = block_sum_fr(acc, lds);
     if (threadIdx.x == 0) {
         Fr b = fp_load<FrParams>(b_in);
         bad |= !fp_is_canonical<FrParams>(b);
-        fp_store<FrParams>(out, fp_add<FrParams>(tot, b));
+        fp_store<FrParams>(out, fp_cond_sub<FrParams>(fp_add<FrParams>(tot, b)));
     }
     if (bad) atomicOr(flags, FLAG_NONCANONICAL);
 }
@@ -203,17 +206,31 @@ FP_INLINE G1Affine affine_load_canonical(const uint8_t* p, uint32_t& bad) {
     return r;
 }
 
+// a canonical 256-bit scalar as eight 32-bit words (what the C ABI carries; digits are taken from it directly)
+struct U256 {
+    uint32_t w[8];
+};
+FP_INLINE U256 u256_load(const void* p) {
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint4 a = q[0], b = q[1];
+    U256 r;
+    r.w[0] = a.x; r.w[1] = a.y; r.w[2] = a.z; r.w[3] = a.w;
+    r.w[4] = b.x; r.w[5] = b.y; r.w[6] = b.z; r.w[7] = b.w;
+    return r;
+}
+FP_INLINE bool u256_is_canonical_fr(const U256& s) { return fp_is_canonical<FrParams>(fp_unpack<FrParams>(s.w)); }
+
 // s * P, MSB-first double-and-add on the canonical 256-bit scalar (the reference's `G1 * Fr`)
-__device__ __noinline__ G1XYZZ g1_scalar_mul(const G1Affine& base, const Fr& s /* canonical */) {
+__device__ __noinline__ G1XYZZ g1_scalar_mul(const G1Affine& base, const U256& s) {
     G1XYZZ acc = G1XYZZ::identity();
-    Fr k = s;
+    U256 k = s;
 #pragma unroll 1
     for (int it = 0; it < 256; ++it) {
         acc = xyzz_double(acc);
-        const uint32_t top = k.l[7] >> 31;
+        const uint32_t top = k.w[7] >> 31;
 #pragma unroll
-        for (int i = 7; i > 0; --i) k.l[i] = (k.l[i] << 1) | (k.l[i - 1] >> 31);
-        k.l[0] <<= 1;
+        for (int i = 7; i > 0; --i) k.w[i] = (k.w[i] << 1) | (k.w[i - 1] >> 31);
+        k.w[0] <<= 1;
         if (top) xyzz_add_affine(acc, base);
     }
     return acc;
@@ -226,8 +243,8 @@ __global__ void __launch_bounds__(BLOCK) k_g1_batch_scalar_mul(const uint8_t* __
     for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
         uint32_t bad = 0;
         G1Affine p = affine_load_canonical(bases + 64 * i, bad);
-        Fr s = fp_load<FrParams>(scalars + 32 * i);
-        bad |= !fp_is_canonical<FrParams>(s);
+        U256 s = u256_load(scalars + 32 * i);
+        bad |= !u256_is_canonical_fr(s);
         if (bad) atomicOr(flags, FLAG_NONCANONICAL);
         jac_store_canonical(out + 96 * i, jac_from_xyzz(g1_scalar_mul(p, s)));
     }
@@ -262,7 +279,7 @@ __global__ void __launch_bounds__(BLOCK) k_g1_batch_to_affine(const uint8_t* __r
 // sum of n Jacobian points, one workgroup
 __global__ void __launch_bounds__(BLOCK) k_g1_sum(const uint8_t* __restrict__ in, size_t n, uint8_t* __restrict__ out,
                                                   uint32_t* flags) {
-    __shared__ uint32_t lds[32 * BLOCK];
+    __shared__ uint32_t lds[XYZZ_WORDS * BLOCK];
     G1XYZZ acc = G1XYZZ::identity();
     for (size_t i = threadIdx.x; i < n; i += BLOCK) {
         if (jac_noncanonical(in + 96 * i)) atomicOr(flags, FLAG_NONCANONICAL);
@@ -294,8 +311,8 @@ __global__ void __launch_bounds__(BLOCK) k_bases_from_mont(const uint8_t* __rest
 __global__ void __launch_bounds__(BLOCK) k_bases_generate(const uint8_t* __restrict__ k, size_t n,
                                                           uint8_t* __restrict__ out, uint32_t* flags) {
     for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
-        Fr s = fp_load<FrParams>(k + 32 * i);
-        if (!fp_is_canonical<FrParams>(s)) atomicOr(flags, FLAG_NONCANONICAL);
+        U256 s = u256_load(k + 32 * i);
+        if (!u256_is_canonical_fr(s)) atomicOr(flags, FLAG_NONCANONICAL);
         G1Affine g;
         g.x = Fq::one();
         g.y = FQ_DBL(Fq::one());

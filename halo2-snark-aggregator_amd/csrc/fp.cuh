@@ -4,11 +4,22 @@
 //   halo2-snark-aggregator-api/src/mock/arith/field.rs:45,54,104,113,121,132,144   (Fr: add/sub/mul/invert)
 //   halo2-snark-aggregator-api/src/mock/arith/ecc.rs:36,45,94,103                  (Fq inside every G1 op)
 //
-// Representation: 8 x 32-bit little-endian limbs in VGPRs, Montgomery form with R = 2^256, always
-// fully reduced to [0, m) so equality / zero tests (needed for the exceptional cases of the group law —
-// results must be bit-exact) are plain limb compares.  Multiplication is CIOS built on
-// v_mad_u64_u32 (32x32+64 -> 64); both moduli are < 2^254 so the running value never needs a ninth
-// limb.  No MFMA: this is carry-chained integer arithmetic, not a dense contraction.
+// Representation (round-1 measurement, profiles/r01_ubench_instruction_rates.txt: v_mad_u64_u32 issues
+// at HALF rate on gfx950 — 4 cycles per wave64, same as v_fma_f64 / v_lshl_add_u64 — while a saturated
+// 8x32-bit CIOS spends 2/3 of its cycles on carry bookkeeping): a field element is NINE 29-bit limbs in
+// VGPRs ("unsaturated" radix 2^29, 261 bits for 254-bit moduli).  A column of the schoolbook product
+// is a plain chain of v_mad_u64_u32 into one 64-bit accumulator — 18 products of < 2^58 never
+// overflow it — so a Montgomery multiplication (R = 2^261) is 162 mads + one carry sweep, with no carry
+// flags (VCC) anywhere and nine independent chains of ILP.
+//
+// Values are kept *lazily reduced*: limbs are tight (limbs 0..7 < 2^29), but the integer may be any
+// small multiple range [0, B*m).  With R/m ~ 2^7.4 = 169 a product of inputs < A*m and < B*m comes out
+// < (A*B/169 + 1)*m, so bounds do not grow through chains of multiplications; every function below
+// states the bound it needs / yields.  Subtraction adds K*m first (template parameter K >= bound of the
+// subtrahend) and carry-normalises with arithmetic shifts.  Exact zero / equality tests (needed for the
+// exceptional cases of the group law — results must be bit-exact) use a one-limb filter that cannot
+// miss a multiple of m, followed by a full reduction only when the filter fires.  No MFMA: this is
+// integer arithmetic on the VALU, not a dense contraction.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -17,243 +28,299 @@
 
 namespace h2agg {
 
+constexpr int NL = 9;                       // limbs
+constexpr uint32_t M29 = (1u << 29) - 1u;   // limb mask
+
 struct FqParams {
     // p = 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47
-    static constexpr uint32_t MOD[8] = {0xd87cfd47u, 0x3c208c16u, 0x6871ca8du, 0x97816a91u,
-                                        0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
-    static constexpr uint32_t INV = 0xe4866389u;  // -p^-1 mod 2^32
-    static constexpr uint32_t R1[8] = {0xc58f0d9du, 0xd35d438du, 0xf5c70b3du, 0x0a78eb28u,
-                                       0x7879462cu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
-    static constexpr uint32_t R2[8] = {0x538afa89u, 0xf32cfc5bu, 0xd44501fbu, 0xb5e71911u,
-                                       0x0a417ff6u, 0x47ab1effu, 0xcab8351fu, 0x06d89f71u};
+    static constexpr uint32_t MOD[9] = {0x187cfd47u, 0x010460b6u, 0x1c72a34fu, 0x02d522d0u, 0x1585d978u,
+                                        0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+    static constexpr uint32_t NINV = 0x04866389u;  // -p^-1 mod 2^29
+    static constexpr uint32_t R1[9] = {0x157ccc21u, 0x141c2758u, 0x185230d3u, 0x014c0419u, 0x0aa36fb9u,
+                                       0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};  // 2^261 mod p
+    static constexpr uint32_t R2[9] = {0x059bac10u, 0x0d1503a3u, 0x018016b8u, 0x10ab0ca8u, 0x02632639u,
+                                       0x02c0169fu, 0x169bfd53u, 0x11869d4cu, 0x002a11a6u};  // 2^522 mod p
 };
 struct FrParams {
     // r = 0x30644e72e131a029b85045b68181585d2833e84879b9709143e1f593f0000001
-    static constexpr uint32_t MOD[8] = {0xf0000001u, 0x43e1f593u, 0x79b97091u, 0x2833e848u,
-                                        0x8181585du, 0xb85045b6u, 0xe131a029u, 0x30644e72u};
-    static constexpr uint32_t INV = 0xefffffffu;  // -r^-1 mod 2^32
-    static constexpr uint32_t R1[8] = {0x4ffffffbu, 0xac96341cu, 0x9f60cd29u, 0x36fc7695u,
-                                       0x7879462eu, 0x666ea36fu, 0x9a07df2fu, 0x0e0a77c1u};
-    static constexpr uint32_t R2[8] = {0xae216da7u, 0x1bb8e645u, 0xe35c59e3u, 0x53fe3ab1u,
-                                       0x53bb8085u, 0x8c49833du, 0x7f4e44a5u, 0x0216d0b1u};
+    static constexpr uint32_t MOD[9] = {0x10000001u, 0x1f0fac9fu, 0x0e5c2450u, 0x07d090f3u, 0x1585d283u,
+                                        0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+    static constexpr uint32_t NINV = 0x0fffffffu;  // -r^-1 mod 2^29
+    static constexpr uint32_t R1[9] = {0x0fffff57u, 0x1ea70ab4u, 0x052c068bu, 0x17504f49u, 0x0aa8075bu,
+                                       0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};  // 2^261 mod r
+    static constexpr uint32_t R2[9] = {0x05b69bd4u, 0x06170a5au, 0x020cddceu, 0x1db6310bu, 0x0e54d0ffu,
+                                       0x1cf855e3u, 0x1c15e103u, 0x07d09161u, 0x000a054au};  // 2^522 mod r
 };
+
+// i-th tight limb of K * modulus (compile-time; K <= 64 keeps the value < 2^261)
+template <class P>
+constexpr uint32_t km_limb(int K, int i) {
+    uint64_t c = 0;
+    uint32_t out = 0;
+    for (int j = 0; j <= i; ++j) {
+        uint64_t t = (uint64_t)P::MOD[j] * (uint64_t)K + c;
+        out = (j < 8) ? (uint32_t)(t & M29) : (uint32_t)t;
+        c = t >> 29;
+    }
+    return out;
+}
 
 template <class P>
 struct Fp {
-    uint32_t l[8];
+    uint32_t l[NL];
 
     static FP_INLINE Fp zero() {
         Fp r;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) r.l[i] = 0;
+        for (int i = 0; i < NL; ++i) r.l[i] = 0;
         return r;
     }
-    static FP_INLINE Fp one() {  // Montgomery 1
+    static FP_INLINE Fp one() {  // Montgomery 1 (< m)
         Fp r;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) r.l[i] = P::R1[i];
+        for (int i = 0; i < NL; ++i) r.l[i] = P::R1[i];
         return r;
     }
     static FP_INLINE Fp r2() {
         Fp r;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) r.l[i] = P::R2[i];
+        for (int i = 0; i < NL; ++i) r.l[i] = P::R2[i];
         return r;
     }
-    FP_INLINE bool is_zero() const {
+    // all limbs zero (integer zero) — NOT "zero mod m"; see fp_is_zero_mod
+    FP_INLINE bool is_zero_int() const {
         uint32_t o = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o |= l[i];
+        for (int i = 0; i < NL; ++i) o |= l[i];
         return o == 0;
     }
-    FP_INLINE bool operator==(const Fp& b) const {
+    FP_INLINE bool same_int(const Fp& b) const {
         uint32_t o = 0;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) o |= (l[i] ^ b.l[i]);
+        for (int i = 0; i < NL; ++i) o |= (l[i] ^ b.l[i]);
         return o == 0;
     }
-    FP_INLINE bool operator!=(const Fp& b) const { return !(*this == b); }
 };
 
-// t = a - m ; returns borrow (1 if a < m)
+// carry-normalise signed limb values x[i] (|x[i]| < 2^31, total value in [0, 2^261)) to tight limbs
 template <class P>
-FP_INLINE uint32_t sub_mod_raw(uint32_t (&t)[8], const uint32_t (&a)[8]) {
-    uint64_t br = 0;
+FP_INLINE Fp<P> fp_normalize(const int32_t (&x)[NL]) {
+    Fp<P> r;
+    int32_t c = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        uint64_t d = (uint64_t)a[i] - P::MOD[i] - br;
-        t[i] = (uint32_t)d;
-        br = (d >> 32) & 1;
+        int32_t t = x[i] + c;
+        r.l[i] = (uint32_t)t & M29;
+        c = t >> 29;  // arithmetic
     }
-    return (uint32_t)br;
+    r.l[8] = (uint32_t)(x[8] + c);
+    return r;
 }
 
-// conditional final subtraction: a in [0, 2m) -> [0, m)
-template <class P>
-FP_INLINE void reduce_once(uint32_t (&a)[8]) {
-    uint32_t t[8];
-    uint32_t borrow = sub_mod_raw<P>(t, a);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) a[i] = borrow ? a[i] : t[i];
-}
-
+// a + b.  value bound: A + B.
 template <class P>
 FP_INLINE Fp<P> fp_add(const Fp<P>& a, const Fp<P>& b) {
-    Fp<P> r;
-    uint64_t c = 0;
+    int32_t x[NL];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        c += (uint64_t)a.l[i] + b.l[i];
-        r.l[i] = (uint32_t)c;
-        c >>= 32;
-    }
-    // a + b < 2m < 2^255: no carry out of limb 7
-    reduce_once<P>(r.l);
-    return r;
+    for (int i = 0; i < NL; ++i) x[i] = (int32_t)(a.l[i] + b.l[i]);
+    return fp_normalize<P>(x);
 }
-
-template <class P>
-FP_INLINE Fp<P> fp_sub(const Fp<P>& a, const Fp<P>& b) {
-    Fp<P> r;
-    uint64_t br = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        uint64_t d = (uint64_t)a.l[i] - b.l[i] - br;
-        r.l[i] = (uint32_t)d;
-        br = (d >> 32) & 1;
-    }
-    uint32_t mask = (uint32_t)0 - (uint32_t)br;
-    uint64_t c = 0;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        c += (uint64_t)r.l[i] + (P::MOD[i] & mask);
-        r.l[i] = (uint32_t)c;
-        c >>= 32;
-    }
-    return r;
-}
-
-template <class P>
-FP_INLINE Fp<P> fp_neg(const Fp<P>& a) {
-    Fp<P> r;
-    uint64_t br = 0;
-    bool z = a.is_zero();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        uint64_t d = (uint64_t)P::MOD[i] - a.l[i] - br;
-        r.l[i] = z ? 0u : (uint32_t)d;
-        br = (d >> 32) & 1;
-    }
-    return r;
-}
-
+// 2a.  bound: 2A.
 template <class P>
 FP_INLINE Fp<P> fp_dbl(const Fp<P>& a) {
+    int32_t x[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) x[i] = (int32_t)(a.l[i] << 1);
+    return fp_normalize<P>(x);
+}
+// a - b + K*m.  REQUIRES value(b) <= K*m.  bound: A + K.
+template <int K, class P>
+FP_INLINE Fp<P> fp_sub(const Fp<P>& a, const Fp<P>& b) {
+    int32_t x[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) x[i] = (int32_t)(a.l[i] + km_limb<P>(K, i)) - (int32_t)b.l[i];
+    return fp_normalize<P>(x);
+}
+// K*m - a.  REQUIRES value(a) <= K*m.  bound: K.
+template <int K, class P>
+FP_INLINE Fp<P> fp_neg(const Fp<P>& a) {
+    int32_t x[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) x[i] = (int32_t)km_limb<P>(K, i) - (int32_t)a.l[i];
+    return fp_normalize<P>(x);
+}
+
+// Montgomery reduction of an 18-column accumulator (columns < 2^63) -> tight limbs, value < (T/R + 1)*m
+template <class P>
+FP_INLINE Fp<P> fp_mont_reduce(uint64_t (&acc)[18]) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) {
+        const uint32_t m = ((uint32_t)acc[k] * P::NINV) & M29;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) acc[k + j] += (uint64_t)m * P::MOD[j];
+        acc[k + 1] += acc[k] >> 29;  // low 29 bits of acc[k] are now zero
+    }
     Fp<P> r;
-    uint32_t c = 0;
+    uint64_t c = 0;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        r.l[i] = (a.l[i] << 1) | c;
-        c = a.l[i] >> 31;
+        uint64_t t = acc[9 + i] + c;
+        r.l[i] = (uint32_t)t & M29;
+        c = t >> 29;
     }
-    reduce_once<P>(r.l);
+    r.l[8] = (uint32_t)(acc[17] + c);
     return r;
 }
 
-// Montgomery product a*b*2^-256 mod m.  CIOS, 8x8 limbs, 2 x 64 v_mad_u64_u32.
+// a*b / 2^261 mod m.  Inputs: tight limbs, bounds A, B with A*B <= ~1000.  Output bound: A*B/169 + 1.
 template <class P>
 FP_INLINE Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
-    uint32_t t[8];
+    uint64_t acc[18];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = 0;
+    for (int k = 0; k < 18; ++k) acc[k] = 0;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        uint64_t c = 0;
-        const uint32_t bi = b.l[i];
+    for (int i = 0; i < NL; ++i) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            c += (uint64_t)a.l[j] * bi + t[j];
-            t[j] = (uint32_t)c;
-            c >>= 32;
-        }
-        const uint32_t t8 = (uint32_t)c;
-        const uint32_t m = t[0] * P::INV;
-        c = (uint64_t)m * P::MOD[0] + t[0];
-        c >>= 32;
-#pragma unroll
-        for (int j = 1; j < 8; ++j) {
-            c += (uint64_t)m * P::MOD[j] + t[j];
-            t[j - 1] = (uint32_t)c;
-            c >>= 32;
-        }
-        c += t8;
-        t[7] = (uint32_t)c;  // value stays < 2m < 2^255: (c >> 32) == 0
+        for (int j = 0; j < NL; ++j) acc[i + j] += (uint64_t)a.l[i] * b.l[j];
     }
+    return fp_mont_reduce<P>(acc);
+}
+
+// a*a / 2^261 mod m: 45 products instead of 81.  Bound as fp_mul.
+template <class P>
+FP_INLINE Fp<P> fp_sqr(const Fp<P>& a) {
+    uint64_t acc[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) acc[k] = 0;
+    uint32_t d[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) d[i] = a.l[i] << 1;  // < 2^30
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        acc[2 * i] += (uint64_t)a.l[i] * a.l[i];
+#pragma unroll
+        for (int j = i + 1; j < NL; ++j) acc[i + j] += (uint64_t)d[i] * a.l[j];
+    }
+    return fp_mont_reduce<P>(acc);
+}
+
+// value < 2m  ->  [0, m)
+template <class P>
+FP_INLINE Fp<P> fp_cond_sub(const Fp<P>& a) {
+    int32_t x[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) x[i] = (int32_t)a.l[i] - (int32_t)km_limb<P>(1, i);
+    Fp<P> t = fp_normalize<P>(x);
+    const bool neg = (int32_t)t.l[8] < 0;
     Fp<P> r;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) r.l[i] = t[i];
-    reduce_once<P>(r.l);
+    for (int i = 0; i < NL; ++i) r.l[i] = neg ? a.l[i] : t.l[i];
     return r;
 }
 
+// any value < 2^261  ->  the canonical representative in [0, m)   (one multiplication by R mod m)
 template <class P>
-FP_INLINE Fp<P> fp_sqr(const Fp<P>& a) {
-    return fp_mul<P>(a, a);
+FP_INLINE Fp<P> fp_canonical(const Fp<P>& a) {
+    return fp_cond_sub<P>(fp_mul<P>(a, Fp<P>::one()));
 }
 
-// canonical integer (8 LE limbs, < m) -> Montgomery
+// Could a (value < K*m) be a multiple of m?  Exact "no", cheap "maybe": compares the low limb with the
+// low limbs of 0, m, ..., (K-1)*m.
+template <int K, class P>
+FP_INLINE bool fp_maybe_zero_mod(const Fp<P>& a) {
+    bool hit = false;
+#pragma unroll
+    for (int k = 0; k < K; ++k) hit |= (a.l[0] == km_limb<P>(k, 0));
+    return hit;
+}
+// exact test a == 0 (mod m), value(a) < K*m
+template <int K, class P>
+FP_INLINE bool fp_is_zero_mod(const Fp<P>& a) {
+    if (!fp_maybe_zero_mod<K, P>(a)) return false;
+    return fp_canonical<P>(a).is_zero_int();
+}
+
+// canonical integer (tight limbs, < m) -> Montgomery (< 2m)
 template <class P>
 FP_INLINE Fp<P> fp_to_mont(const Fp<P>& a) {
     return fp_mul<P>(a, Fp<P>::r2());
 }
-// Montgomery -> canonical integer
+// Montgomery (any bound) -> canonical integer in [0, m)
 template <class P>
 FP_INLINE Fp<P> fp_from_mont(const Fp<P>& a) {
     Fp<P> one;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) one.l[i] = (i == 0);
-    return fp_mul<P>(a, one);
+    for (int i = 0; i < NL; ++i) one.l[i] = (i == 0);
+    return fp_cond_sub<P>(fp_mul<P>(a, one));
 }
 
-// a^(m-2) (Fermat).  inv(0) = 0; callers that mirror `invert().unwrap()` test for zero first.
+// a^(m-2) (Fermat), Montgomery in / out (< 2m).  inv(0) = 0; callers mirroring `invert().unwrap()` test first.
 template <class P>
 __device__ __noinline__ Fp<P> fp_inv(const Fp<P>& a) {
+    // exponent m - 2 as 8 x 32-bit words, recomposed from the 29-bit limbs at compile time
     Fp<P> acc = Fp<P>::one();
-#pragma unroll
-    for (int i = 7; i >= 0; --i) {
-        // i is a compile-time constant after unrolling, so MOD[i] folds to a literal
-        const uint32_t e = P::MOD[i] - (i == 0 ? 2u : 0u);  // low limbs of both moduli are >= 2: no borrow
 #pragma unroll 1
-        for (int bit = 31; bit >= 0; --bit) {
-            acc = fp_sqr<P>(acc);
-            if ((e >> bit) & 1) acc = fp_mul<P>(acc, a);
-        }
+    for (int bit = 253; bit >= 0; --bit) {
+        acc = fp_sqr<P>(acc);
+        const int limb = bit / 29, off = bit % 29;
+        uint32_t w = 0;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) w = (limb == i) ? (P::MOD[i] - (i == 0 ? 2u : 0u)) : w;  // low limb >= 2
+        if ((w >> off) & 1u) acc = fp_mul<P>(acc, a);
     }
     return acc;
 }
 
-// 32-byte global <-> registers (two 16-byte accesses per element)
+// ---- 32-byte packed form (8 x 32-bit words, value < 2^256) <-> limbs -------------------------------
+template <class P>
+FP_INLINE Fp<P> fp_unpack(const uint32_t (&w)[8]) {
+    Fp<P> r;
+    r.l[0] = w[0] & M29;
+    r.l[1] = ((w[0] >> 29) | (w[1] << 3)) & M29;
+    r.l[2] = ((w[1] >> 26) | (w[2] << 6)) & M29;
+    r.l[3] = ((w[2] >> 23) | (w[3] << 9)) & M29;
+    r.l[4] = ((w[3] >> 20) | (w[4] << 12)) & M29;
+    r.l[5] = ((w[4] >> 17) | (w[5] << 15)) & M29;
+    r.l[6] = ((w[5] >> 14) | (w[6] << 18)) & M29;
+    r.l[7] = ((w[6] >> 11) | (w[7] << 21)) & M29;
+    r.l[8] = w[7] >> 8;
+    return r;
+}
+template <class P>
+FP_INLINE void fp_pack(uint32_t (&w)[8], const Fp<P>& a) {  // value(a) < 2^256, tight limbs
+    w[0] = a.l[0] | (a.l[1] << 29);
+    w[1] = (a.l[1] >> 3) | (a.l[2] << 26);
+    w[2] = (a.l[2] >> 6) | (a.l[3] << 23);
+    w[3] = (a.l[3] >> 9) | (a.l[4] << 20);
+    w[4] = (a.l[4] >> 12) | (a.l[5] << 17);
+    w[5] = (a.l[5] >> 15) | (a.l[6] << 14);
+    w[6] = (a.l[6] >> 18) | (a.l[7] << 11);
+    w[7] = (a.l[7] >> 21) | (a.l[8] << 8);
+}
+// 32 bytes in global memory (two 16-byte accesses) <-> limbs
 template <class P>
 FP_INLINE Fp<P> fp_load(const void* p) {
     const uint4* q = reinterpret_cast<const uint4*>(p);
     uint4 a = q[0], b = q[1];
-    Fp<P> r;
-    r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
-    r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-    return r;
+    uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    return fp_unpack<P>(w);
 }
 template <class P>
 FP_INLINE void fp_store(void* p, const Fp<P>& v) {
+    uint32_t w[8];
+    fp_pack<P>(w, v);
     uint4* q = reinterpret_cast<uint4*>(p);
-    q[0] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
-    q[1] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    q[0] = make_uint4(w[0], w[1], w[2], w[3]);
+    q[1] = make_uint4(w[4], w[5], w[6], w[7]);
 }
-
-// is the canonical integer < m ?
+// is the 256-bit integer at p (as loaded by fp_load) < m ?  (top limb of a 256-bit load is < 2^24)
 template <class P>
 FP_INLINE bool fp_is_canonical(const Fp<P>& a) {
-    uint32_t t[8];
-    return sub_mod_raw<P>(t, a.l) != 0;
+    int32_t x[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) x[i] = (int32_t)a.l[i] - (int32_t)km_limb<P>(1, i);
+    Fp<P> t = fp_normalize<P>(x);
+    return (int32_t)t.l[8] < 0;
 }
 
 using Fq = Fp<FqParams>;

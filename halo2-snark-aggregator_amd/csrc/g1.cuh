@@ -17,16 +17,27 @@
 
 namespace h2agg {
 
-struct G1Affine {  // identity encoded as (0, 0), as halo2curves' G1Affine::identity()
+#define FQ_MUL(a, b) fp_mul<FqParams>(a, b)
+#define FQ_SQR(a) fp_sqr<FqParams>(a)
+#define FQ_ADD(a, b) fp_add<FqParams>(a, b)
+#define FQ_SUB(K, a, b) fp_sub<K, FqParams>(a, b) /* a - b + K*p, needs value(b) <= K*p */
+#define FQ_DBL(a) fp_dbl<FqParams>(a)
+
+// Lazy-reduction invariant of every point held in registers or memory (bounds in multiples of p):
+//     XYZZ:   X < 8,  Y < 4,  ZZ < 2,  ZZZ < 2          affine (Montgomery):  x, y <= 2
+// Each formula is annotated [bound] so that every fp_mul / fp_sqr has (bound a)*(bound b) <= 169 (its
+// result is then < 2) and every subtraction offset K >= the bound of its subtrahend.
+
+struct G1Affine {  // identity encoded as the integers (0, 0), as halo2curves' G1Affine::identity()
     Fq x, y;
-    FP_INLINE bool is_identity() const { return x.is_zero() && y.is_zero(); }
+    FP_INLINE bool is_identity() const { return x.is_zero_int() && y.is_zero_int(); }
 };
 struct G1Jac {  // identity: z = 0
     Fq x, y, z;
 };
-struct G1XYZZ {  // identity: zz = 0
+struct G1XYZZ {  // identity: zz is the integer 0 (a computed ZZ of a finite point is never 0 mod p)
     Fq x, y, zz, zzz;
-    FP_INLINE bool is_identity() const { return zz.is_zero(); }
+    FP_INLINE bool is_identity() const { return zz.is_zero_int(); }
     static FP_INLINE G1XYZZ identity() {
         G1XYZZ r;
         r.x = Fq::zero();
@@ -46,25 +57,30 @@ struct G1XYZZ {  // identity: zz = 0
     }
 };
 
-#define FQ_MUL(a, b) fp_mul<FqParams>(a, b)
-#define FQ_SQR(a) fp_sqr<FqParams>(a)
-#define FQ_ADD(a, b) fp_add<FqParams>(a, b)
-#define FQ_SUB(a, b) fp_sub<FqParams>(a, b)
-#define FQ_DBL(a) fp_dbl<FqParams>(a)
+// -q for an affine point (identity stays the identity)
+FP_INLINE G1Affine affine_neg(const G1Affine& q) {
+    G1Affine r = q;
+    if (!q.is_identity()) r.y = fp_neg<2, FqParams>(q.y);  // [<= 2]
+    return r;
+}
+
+// shared tail of the doubling formulas: given U = 2Y [u<=8], X [<8], Y [<4] returns X3, Y3 and V, W
+FP_INLINE void xyzz_double_core(const Fq& x, const Fq& y, Fq& x3, Fq& y3, Fq& v, Fq& w) {
+    Fq u = FQ_DBL(y);                                   // [8]
+    v = FQ_SQR(u);                                      // 64  -> [2]
+    w = FQ_MUL(u, v);                                   // 16  -> [2]
+    Fq s = FQ_MUL(x, v);                                // 16  -> [2]
+    Fq xx = FQ_SQR(x);                                  // 64  -> [2]
+    Fq m = FQ_ADD(FQ_DBL(xx), xx);                      // [6]
+    x3 = FQ_SUB(4, FQ_SQR(m), FQ_DBL(s));               // 36 -> [2]; 2S [4]  -> [6]
+    y3 = FQ_SUB(2, FQ_MUL(m, FQ_SUB(6, s, x3)),         // S - X3 + 6p [8]; 6*8 = 48 -> [2]
+                FQ_MUL(w, y));                          // 2*4 -> [2]        -> [4]
+}
 
 // 2 * (affine point), mdbl-2008-s-1.  p must not be the identity; y = 0 cannot occur on a prime-order curve.
 FP_INLINE G1XYZZ xyzz_double_affine(const G1Affine& p) {
     G1XYZZ r;
-    Fq u = FQ_DBL(p.y);
-    Fq v = FQ_SQR(u);
-    Fq w = FQ_MUL(u, v);
-    Fq s = FQ_MUL(p.x, v);
-    Fq xx = FQ_SQR(p.x);
-    Fq m = FQ_ADD(FQ_DBL(xx), xx);
-    r.x = FQ_SUB(FQ_SQR(m), FQ_DBL(s));
-    r.y = FQ_SUB(FQ_MUL(m, FQ_SUB(s, r.x)), FQ_MUL(w, p.y));
-    r.zz = v;
-    r.zzz = w;
+    xyzz_double_core(p.x, p.y, r.x, r.y, r.zz, r.zzz);
     return r;
 }
 
@@ -72,14 +88,8 @@ FP_INLINE G1XYZZ xyzz_double_affine(const G1Affine& p) {
 FP_INLINE G1XYZZ xyzz_double(const G1XYZZ& p) {
     if (p.is_identity()) return p;
     G1XYZZ r;
-    Fq u = FQ_DBL(p.y);
-    Fq v = FQ_SQR(u);
-    Fq w = FQ_MUL(u, v);
-    Fq s = FQ_MUL(p.x, v);
-    Fq xx = FQ_SQR(p.x);
-    Fq m = FQ_ADD(FQ_DBL(xx), xx);
-    r.x = FQ_SUB(FQ_SQR(m), FQ_DBL(s));
-    r.y = FQ_SUB(FQ_MUL(m, FQ_SUB(s, r.x)), FQ_MUL(w, p.y));
+    Fq v, w;
+    xyzz_double_core(p.x, p.y, r.x, r.y, v, w);
     r.zz = FQ_MUL(v, p.zz);
     r.zzz = FQ_MUL(w, p.zzz);
     return r;
@@ -95,64 +105,68 @@ FP_INLINE void xyzz_add_affine(G1XYZZ& acc, const G1Affine& q) {
         acc.zzz = Fq::one();
         return;
     }
-    Fq u2 = FQ_MUL(q.x, acc.zz);
-    Fq s2 = FQ_MUL(q.y, acc.zzz);
-    Fq p = FQ_SUB(u2, acc.x);
-    Fq r = FQ_SUB(s2, acc.y);
-    if (p.is_zero()) {
-        if (r.is_zero()) {
-            acc = xyzz_double_affine(q);
-        } else {
-            acc = G1XYZZ::identity();
+    Fq u2 = FQ_MUL(q.x, acc.zz);                        // 2*2 -> [2]
+    Fq s2 = FQ_MUL(q.y, acc.zzz);                       // [2]
+    Fq p = FQ_SUB(8, u2, acc.x);                        // [10]
+    Fq r = FQ_SUB(4, s2, acc.y);                        // [6]
+    if (fp_maybe_zero_mod<10, FqParams>(p)) {           // exact "no"; the rare "maybe" is decided exactly
+        if (fp_is_zero_mod<10, FqParams>(p)) {
+            if (fp_is_zero_mod<6, FqParams>(r)) {
+                acc = xyzz_double_affine(q);
+            } else {
+                acc = G1XYZZ::identity();
+            }
+            return;
         }
-        return;
     }
-    Fq pp = FQ_SQR(p);
-    Fq ppp = FQ_MUL(p, pp);
-    Fq qq = FQ_MUL(acc.x, pp);
-    Fq x3 = FQ_SUB(FQ_SUB(FQ_SQR(r), ppp), FQ_DBL(qq));
-    Fq y3 = FQ_SUB(FQ_MUL(r, FQ_SUB(qq, x3)), FQ_MUL(acc.y, ppp));
+    Fq pp = FQ_SQR(p);                                  // 100 -> [2]
+    Fq ppp = FQ_MUL(p, pp);                             // 20  -> [2]
+    Fq qq = FQ_MUL(acc.x, pp);                          // 16  -> [2]
+    Fq x3 = FQ_SUB(6, FQ_SQR(r), FQ_ADD(ppp, FQ_DBL(qq)));           // 36 -> [2]; PPP + 2Q [6] -> [8]
+    Fq y3 = FQ_SUB(2, FQ_MUL(r, FQ_SUB(8, qq, x3)), FQ_MUL(acc.y, ppp));  // [10]: 60 -> [2]; 8 -> [2] -> [4]
     acc.x = x3;
     acc.y = y3;
-    acc.zz = FQ_MUL(acc.zz, pp);
-    acc.zzz = FQ_MUL(acc.zzz, ppp);
+    acc.zz = FQ_MUL(acc.zz, pp);                        // [2]
+    acc.zzz = FQ_MUL(acc.zzz, ppp);                     // [2]
 }
 
 // a + b, add-2008-s, complete.
 FP_INLINE G1XYZZ xyzz_add(const G1XYZZ& a, const G1XYZZ& b) {
     if (a.is_identity()) return b;
     if (b.is_identity()) return a;
-    Fq u1 = FQ_MUL(a.x, b.zz);
-    Fq u2 = FQ_MUL(b.x, a.zz);
-    Fq s1 = FQ_MUL(a.y, b.zzz);
-    Fq s2 = FQ_MUL(b.y, a.zzz);
-    Fq p = FQ_SUB(u2, u1);
-    Fq r = FQ_SUB(s2, s1);
-    if (p.is_zero()) {
-        if (r.is_zero()) return xyzz_double(a);
-        return G1XYZZ::identity();
+    Fq u1 = FQ_MUL(a.x, b.zz);                          // 16 -> [2]
+    Fq u2 = FQ_MUL(b.x, a.zz);                          // [2]
+    Fq s1 = FQ_MUL(a.y, b.zzz);                         // 8 -> [2]
+    Fq s2 = FQ_MUL(b.y, a.zzz);                         // [2]
+    Fq p = FQ_SUB(2, u2, u1);                           // [4]
+    Fq r = FQ_SUB(2, s2, s1);                           // [4]
+    if (fp_maybe_zero_mod<4, FqParams>(p)) {
+        if (fp_is_zero_mod<4, FqParams>(p)) {
+            if (fp_is_zero_mod<4, FqParams>(r)) return xyzz_double(a);
+            return G1XYZZ::identity();
+        }
     }
     G1XYZZ o;
-    Fq pp = FQ_SQR(p);
-    Fq ppp = FQ_MUL(p, pp);
-    Fq q = FQ_MUL(u1, pp);
-    o.x = FQ_SUB(FQ_SUB(FQ_SQR(r), ppp), FQ_DBL(q));
-    o.y = FQ_SUB(FQ_MUL(r, FQ_SUB(q, o.x)), FQ_MUL(s1, ppp));
-    o.zz = FQ_MUL(FQ_MUL(a.zz, b.zz), pp);
-    o.zzz = FQ_MUL(FQ_MUL(a.zzz, b.zzz), ppp);
+    Fq pp = FQ_SQR(p);                                  // 16 -> [2]
+    Fq ppp = FQ_MUL(p, pp);                             // [2]
+    Fq q = FQ_MUL(u1, pp);                              // [2]
+    o.x = FQ_SUB(6, FQ_SQR(r), FQ_ADD(ppp, FQ_DBL(q)));                  // [8]
+    o.y = FQ_SUB(2, FQ_MUL(r, FQ_SUB(8, q, o.x)), FQ_MUL(s1, ppp));      // 4*10 -> [2] -> [4]
+    o.zz = FQ_MUL(FQ_MUL(a.zz, b.zz), pp);              // [2]
+    o.zzz = FQ_MUL(FQ_MUL(a.zzz, b.zzz), ppp);          // [2]
     return o;
 }
 
 FP_INLINE G1XYZZ xyzz_neg(const G1XYZZ& a) {
     G1XYZZ r = a;
-    r.y = fp_neg<FqParams>(a.y);
+    if (!a.is_identity()) r.y = fp_neg<4, FqParams>(a.y);  // [4]
     return r;
 }
 
-// Jacobian (X, Y, Z) -> XYZZ: ZZ = Z^2, ZZZ = Z^3
+// Jacobian (X, Y, Z) [each <= 2] -> XYZZ: ZZ = Z^2, ZZZ = Z^3.  Identity <=> Z = 0 mod p.
 FP_INLINE G1XYZZ xyzz_from_jac(const G1Jac& p) {
     G1XYZZ r;
-    if (p.z.is_zero()) return G1XYZZ::identity();
+    if (fp_is_zero_mod<2, FqParams>(p.z)) return G1XYZZ::identity();
     r.x = p.x;
     r.y = p.y;
     r.zz = FQ_SQR(p.z);
@@ -168,40 +182,62 @@ FP_INLINE G1Jac jac_from_xyzz(const G1XYZZ& p) {
         r.z = Fq::zero();
         return r;
     }
-    r.x = FQ_MUL(p.x, FQ_SQR(p.zz));
-    r.y = FQ_MUL(p.y, FQ_SQR(p.zzz));
+    r.x = FQ_MUL(p.x, FQ_SQR(p.zz));                    // 8*2 -> [2]
+    r.y = FQ_MUL(p.y, FQ_SQR(p.zzz));                   // [2]
     r.z = p.zzz;
     return r;
 }
 
-// load / store helpers.  Device-resident points are Montgomery-form limbs; `canonical` variants convert
-// from / to the C ABI's canonical little-endian integers.
+// ---- memory formats ---------------------------------------------------------------------------------
+// base tables:   64 B / point, x || y, each a packed 256-bit Montgomery value (< 2p)
+// XYZZ records: 144 B / point (internal: buckets, partial sums), 4 x 9 limbs as 9 x uint4
+constexpr int XYZZ_BYTES = 144;
+
 FP_INLINE G1Affine affine_load(const void* p) {
     G1Affine r;
     r.x = fp_load<FqParams>(p);
     r.y = fp_load<FqParams>(reinterpret_cast<const uint8_t*>(p) + 32);
     return r;
 }
-FP_INLINE void affine_store(void* p, const G1Affine& a) {
+FP_INLINE void affine_store(void* p, const G1Affine& a) {  // coordinates must be < 2^256 (Montgomery outputs are)
     fp_store<FqParams>(p, a.x);
     fp_store<FqParams>(reinterpret_cast<uint8_t*>(p) + 32, a.y);
 }
 FP_INLINE G1XYZZ xyzz_load(const void* p) {
-    const uint8_t* b = reinterpret_cast<const uint8_t*>(p);
+    const uint4* q = reinterpret_cast<const uint4*>(p);
+    uint32_t w[36];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        uint4 v = q[i];
+        w[4 * i] = v.x;
+        w[4 * i + 1] = v.y;
+        w[4 * i + 2] = v.z;
+        w[4 * i + 3] = v.w;
+    }
     G1XYZZ r;
-    r.x = fp_load<FqParams>(b);
-    r.y = fp_load<FqParams>(b + 32);
-    r.zz = fp_load<FqParams>(b + 64);
-    r.zzz = fp_load<FqParams>(b + 96);
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        r.x.l[i] = w[i];
+        r.y.l[i] = w[9 + i];
+        r.zz.l[i] = w[18 + i];
+        r.zzz.l[i] = w[27 + i];
+    }
     return r;
 }
 FP_INLINE void xyzz_store(void* p, const G1XYZZ& a) {
-    uint8_t* b = reinterpret_cast<uint8_t*>(p);
-    fp_store<FqParams>(b, a.x);
-    fp_store<FqParams>(b + 32, a.y);
-    fp_store<FqParams>(b + 64, a.zz);
-    fp_store<FqParams>(b + 96, a.zzz);
+    uint32_t w[36];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        w[i] = a.x.l[i];
+        w[9 + i] = a.y.l[i];
+        w[18 + i] = a.zz.l[i];
+        w[27 + i] = a.zzz.l[i];
+    }
+    uint4* q = reinterpret_cast<uint4*>(p);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) q[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
 }
+// C-ABI Jacobian: three canonical little-endian integers
 FP_INLINE G1Jac jac_load_canonical(const void* p) {
     const uint8_t* b = reinterpret_cast<const uint8_t*>(p);
     G1Jac r;

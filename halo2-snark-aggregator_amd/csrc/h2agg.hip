@@ -184,9 +184,9 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     TRY(ensure(c, c->cursor, (size_t)p.NBT * 4));
     TRY(ensure(c, c->blocksum, (size_t)nscanblocks * 4));
     TRY(ensure(c, c->entries, nent * 4));
-    TRY(ensure(c, c->buckets, (size_t)p.NBT * 128));
-    TRY(ensure(c, c->segsum, (size_t)nseg_total * 128));
-    TRY(ensure(c, c->wsum, (size_t)p.W * 128));
+    TRY(ensure(c, c->buckets, (size_t)p.NBT * XYZZ_BYTES));
+    TRY(ensure(c, c->segsum, (size_t)nseg_total * XYZZ_BYTES));
+    TRY(ensure(c, c->wsum, (size_t)p.W * XYZZ_BYTES));
     TRY(ensure(c, c->big_list, (size_t)p.NBT * 4));
     uint32_t* hist = (uint32_t*)c->hist.p;
     uint32_t* offs = (uint32_t*)c->offs.p;
@@ -298,8 +298,8 @@ int h2agg_create(int device_ordinal, h2agg_ctx** out) {
     }
     c->stream = c->own_stream;
     c->d_flags = (uint32_t*)c->small.p;
-    c->d_res_xyzz = (uint8_t*)c->small.p + 64;
-    c->d_res_jac = (uint8_t*)c->small.p + 256;
+    c->d_res_xyzz = (uint8_t*)c->small.p + 64;   // 144 B
+    c->d_res_jac = (uint8_t*)c->small.p + 256;   // 96 B
     for (int s = 0; s < ST_N; ++s)
         for (int k = 0; k < 2; ++k) hipEventCreate(&c->ev[s][k]);
     hipMemset(c->small.p, 0, 1024);

@@ -36,16 +36,16 @@ struct MsmPlan {
 // Signed-digit recode of a canonical scalar; calls f(window, bucket_index(0-based), negative) for every
 // non-zero digit.  Digits lie in [-2^(c-1), 2^(c-1)]; W*c >= 255 guarantees no carry out of the top window.
 template <class F>
-FP_INLINE void msm_for_each_digit(Fr s, int c, int W, F&& f) {
+FP_INLINE void msm_for_each_digit(U256 s, int c, int W, F&& f) {
     const uint32_t mask = (1u << c) - 1u;
     const uint32_t half = 1u << (c - 1);
     uint32_t carry = 0;
 #pragma unroll 1
     for (int w = 0; w < W; ++w) {
-        uint32_t raw = (s.l[0] & mask) + carry;
+        uint32_t raw = (s.w[0] & mask) + carry;
 #pragma unroll
-        for (int i = 0; i < 7; ++i) s.l[i] = (s.l[i] >> c) | (s.l[i + 1] << (32 - c));
-        s.l[7] >>= c;
+        for (int i = 0; i < 7; ++i) s.w[i] = (s.w[i] >> c) | (s.w[i + 1] << (32 - c));
+        s.w[7] >>= c;
         const bool neg = raw > half;
         carry = neg ? 1u : 0u;
         const uint32_t mag = neg ? ((1u << c) - raw) : raw;
@@ -56,8 +56,8 @@ FP_INLINE void msm_for_each_digit(Fr s, int c, int W, F&& f) {
 __global__ void __launch_bounds__(BLOCK) k_msm_count(const uint8_t* __restrict__ scalars, size_t n, int c, int W,
                                                      uint32_t NB, uint32_t* __restrict__ hist, uint32_t* flags) {
     for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
-        Fr s = fp_load<FrParams>(scalars + 32 * i);
-        if (!fp_is_canonical<FrParams>(s)) atomicOr(flags, FLAG_NONCANONICAL);
+        U256 s = u256_load(scalars + 32 * i);
+        if (!u256_is_canonical_fr(s)) atomicOr(flags, FLAG_NONCANONICAL);
         msm_for_each_digit(s, c, W, [&](int w, uint32_t b, bool) { atomicAdd(&hist[(uint32_t)w * NB + b], 1u); });
     }
 }
@@ -66,7 +66,7 @@ __global__ void __launch_bounds__(BLOCK) k_msm_scatter(const uint8_t* __restrict
                                                        uint32_t NB, uint32_t* __restrict__ cursor,
                                                        uint32_t* __restrict__ entries) {
     for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
-        Fr s = fp_load<FrParams>(scalars + 32 * i);
+        U256 s = u256_load(scalars + 32 * i);
         msm_for_each_digit(s, c, W, [&](int w, uint32_t b, bool neg) {
             uint32_t pos = atomicAdd(&cursor[(uint32_t)w * NB + b], 1u);
             entries[pos] = (uint32_t)i | (neg ? 0x80000000u : 0u);
@@ -145,8 +145,7 @@ __global__ void __launch_bounds__(BLOCK) k_scan_add(uint32_t* __restrict__ offs,
 // ------------------------------------------------------------------ bucket accumulation
 FP_INLINE G1Affine msm_gather(const uint8_t* __restrict__ bases, uint32_t e) {
     G1Affine p = affine_load(bases + 64 * (size_t)(e & 0x7fffffffu));
-    if (e >> 31) p.y = fp_neg<FqParams>(p.y);
-    return p;
+    return (e >> 31) ? affine_neg(p) : p;
 }
 
 __global__ void __launch_bounds__(BLOCK) k_msm_accumulate(const uint8_t* __restrict__ bases,
@@ -173,7 +172,7 @@ __global__ void __launch_bounds__(BLOCK) k_msm_accumulate(const uint8_t* __restr
             xyzz_add_affine(acc, cur);
         }
     }
-    xyzz_store(buckets + 128 * (size_t)key, acc);
+    xyzz_store(buckets + XYZZ_BYTES * (size_t)key, acc);
 }
 
 // one workgroup per over-long bucket
@@ -184,7 +183,7 @@ __global__ void __launch_bounds__(BLOCK) k_msm_accumulate_big(const uint8_t* __r
                                                               uint8_t* __restrict__ buckets,
                                                               const uint32_t* __restrict__ big_list,
                                                               const uint32_t* __restrict__ big_count) {
-    __shared__ uint32_t lds[32 * BLOCK];
+    __shared__ uint32_t lds[XYZZ_WORDS * BLOCK];
     const uint32_t nbig = *big_count;
     for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {
         const uint32_t key = big_list[b];
@@ -194,7 +193,7 @@ __global__ void __launch_bounds__(BLOCK) k_msm_accumulate_big(const uint8_t* __r
 #pragma unroll 1
         for (uint32_t k = threadIdx.x; k < len; k += BLOCK) xyzz_add_affine(acc, msm_gather(bases, run[k]));
         G1XYZZ tot = block_sum_xyzz(acc, lds);
-        if (threadIdx.x == 0) xyzz_store(buckets + 128 * (size_t)key, tot);
+        if (threadIdx.x == 0) xyzz_store(buckets + XYZZ_BYTES * (size_t)key, tot);
         __syncthreads();
     }
 }
@@ -219,29 +218,29 @@ __global__ void __launch_bounds__(BLOCK) k_msm_reduce_segments(const uint8_t* __
     if (t >= total) return;
     const uint32_t w = t / spw, sidx = t - w * spw;
     const uint32_t a = sidx * seg;
-    const uint8_t* B = buckets + 128 * ((size_t)w * NB + a);
+    const uint8_t* B = buckets + XYZZ_BYTES * ((size_t)w * NB + a);
     G1XYZZ running = G1XYZZ::identity(), acc = G1XYZZ::identity();
 #pragma unroll 1
     for (int j = (int)seg - 1; j >= 0; --j) {
-        running = xyzz_add(running, xyzz_load(B + 128 * (size_t)j));
+        running = xyzz_add(running, xyzz_load(B + XYZZ_BYTES * (size_t)j));
         acc = xyzz_add(acc, running);
     }
     // sum (a + jj + 1) B = acc + a * running
     if (a != 0 && !running.is_identity()) acc = xyzz_add(acc, xyzz_mul_small(running, a));
-    xyzz_store(segsum + 128 * (size_t)t, acc);
+    xyzz_store(segsum + XYZZ_BYTES * (size_t)t, acc);
 }
 
 // wsum[w] = sum_s segsum[w][s]; one workgroup per window
 __global__ void __launch_bounds__(BLOCK) k_msm_window_sum(const uint8_t* __restrict__ segsum, uint32_t spw,
                                                           uint8_t* __restrict__ wsum) {
-    __shared__ uint32_t lds[32 * BLOCK];
+    __shared__ uint32_t lds[XYZZ_WORDS * BLOCK];
     const uint32_t w = blockIdx.x;
     G1XYZZ acc = G1XYZZ::identity();
 #pragma unroll 1
     for (uint32_t s = threadIdx.x; s < spw; s += BLOCK)
-        acc = xyzz_add(acc, xyzz_load(segsum + 128 * ((size_t)w * spw + s)));
+        acc = xyzz_add(acc, xyzz_load(segsum + XYZZ_BYTES * ((size_t)w * spw + s)));
     G1XYZZ tot = block_sum_xyzz(acc, lds);
-    if (threadIdx.x == 0) xyzz_store(wsum + 128 * (size_t)w, tot);
+    if (threadIdx.x == 0) xyzz_store(wsum + XYZZ_BYTES * (size_t)w, tot);
 }
 
 // result = sum_w 2^(c*w) * wsum[w]  (Horner, top window first).  Writes the XYZZ value (Montgomery, for
@@ -249,12 +248,12 @@ __global__ void __launch_bounds__(BLOCK) k_msm_window_sum(const uint8_t* __restr
 __global__ void k_msm_final(const uint8_t* __restrict__ wsum, int c, int W, uint8_t* __restrict__ out_xyzz,
                             uint8_t* __restrict__ out_jac) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    G1XYZZ acc = xyzz_load(wsum + 128 * (size_t)(W - 1));
+    G1XYZZ acc = xyzz_load(wsum + XYZZ_BYTES * (size_t)(W - 1));
 #pragma unroll 1
     for (int w = W - 2; w >= 0; --w) {
 #pragma unroll 1
         for (int k = 0; k < c; ++k) acc = xyzz_double(acc);
-        acc = xyzz_add(acc, xyzz_load(wsum + 128 * (size_t)w));
+        acc = xyzz_add(acc, xyzz_load(wsum + XYZZ_BYTES * (size_t)w));
     }
     if (out_xyzz) xyzz_store(out_xyzz, acc);
     if (out_jac) jac_store_canonical(out_jac, jac_from_xyzz(acc));
@@ -264,7 +263,7 @@ __global__ void k_msm_final(const uint8_t* __restrict__ wsum, int c, int W, uint
 __global__ void __launch_bounds__(BLOCK) k_eval_tail(const uint8_t* __restrict__ msm_xyzz,
                                                      const uint8_t* __restrict__ pts_aff, size_t n,
                                                      uint8_t* __restrict__ out_jac, uint32_t* flags) {
-    __shared__ uint32_t lds[32 * BLOCK];
+    __shared__ uint32_t lds[XYZZ_WORDS * BLOCK];
     G1XYZZ acc = G1XYZZ::identity();
     if (threadIdx.x == 0 && msm_xyzz) acc = xyzz_load(msm_xyzz);
     uint32_t bad = 0;

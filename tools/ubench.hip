@@ -70,12 +70,16 @@ __global__ void __launch_bounds__(256) k_fma_f32(uint32_t* out, uint32_t seed) {
 
 // whole-op throughput
 __global__ void __launch_bounds__(256) k_fqmul(uint32_t* out, uint32_t seed) {
-  Fq a = Fq::one(), b = Fq::r2(); a.l[0] ^= seed + threadIdx.x; a.l[7] &= 0x0fffffff;
+  Fq a = Fq::one(), b = Fq::r2(); a.l[0] ^= (seed + threadIdx.x) & 0xffff;
   for (int it = 0; it < 256; ++it) { a = fp_mul<FqParams>(a, b); b = fp_mul<FqParams>(b, a); }
   out[blockIdx.x*256+threadIdx.x] = a.l[0] ^ b.l[3]; }
+__global__ void __launch_bounds__(256) k_fqsqr(uint32_t* out, uint32_t seed) {
+  Fq a = Fq::one(), b = Fq::r2(); a.l[0] ^= (seed + threadIdx.x) & 0xffff;
+  for (int it = 0; it < 256; ++it) { a = fp_sqr<FqParams>(a); b = fp_sqr<FqParams>(b); }
+  out[blockIdx.x*256+threadIdx.x] = a.l[0] ^ b.l[3]; }
 __global__ void __launch_bounds__(256) k_fqadd(uint32_t* out, uint32_t seed) {
-  Fq a = Fq::one(), b = Fq::r2(); a.l[0] ^= seed + threadIdx.x; a.l[7] &= 0x0fffffff;
-  for (int it = 0; it < 2048; ++it) { a = fp_add<FqParams>(a, b); b = fp_sub<FqParams>(b, a); }
+  Fq a = Fq::one(), b = Fq::r2(); a.l[0] ^= (seed + threadIdx.x) & 0xffff;
+  for (int it = 0; it < 2048; ++it) { a = fp_add<FqParams>(a, b); b = fp_sub<8, FqParams>(b, a); a.l[8] &= 0xffff; b.l[8] &= 0xffff; }
   out[blockIdx.x*256+threadIdx.x] = a.l[0] ^ b.l[3]; }
 __global__ void __launch_bounds__(256) k_madd(uint32_t* out, uint32_t seed) {
   G1Affine g; g.x = Fq::one(); g.y = fp_dbl<FqParams>(Fq::one());
@@ -110,6 +114,7 @@ int main() {
   run(k_fma_f64, "v_fma_f64", per, blocks, d);
   run(k_fma_f32, "v_fma_f32", per, blocks, d);
   run(k_fqmul, "fq_mul", 512.0, blocks, d);
+  run(k_fqsqr, "fq_sqr", 512.0, blocks, d);
   run(k_fqadd, "fq_add/sub", 4096.0, blocks, d);
   run(k_madd, "xyzz_madd", 64.0, blocks, d);
   return 0; }
