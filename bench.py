@@ -66,6 +66,7 @@ def main():
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=1 << 16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="run the Horner tail in-stream (latency mode)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -90,6 +91,8 @@ def main():
     eng.set_stream(stream.cuda_stream)
     if args.window:
         eng.msm_configure(window_bits=args.window)
+    if not args.no_overlap:
+        eng.msm_set_tail_overlap(True)   # serial Horner tail of MSM k runs under the bulk of MSM k+1
 
     n = 1 << args.log2n
     seed = 0x48324147
@@ -116,12 +119,14 @@ def main():
         return torch.stack(gathered)
 
     def barrier():
+        eng.synchronize()                # joins the context's tail stream into the timed stream
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
     for i in range(args.warmup):
         step(i)
+    eng.synchronize()
     exchange()
     barrier()
 
@@ -139,6 +144,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
+    eng.synchronize()
     gathered = exchange()
     barrier()
     dt = time.perf_counter() - t0
@@ -178,6 +184,7 @@ def main():
                             "(BASELINE.json configs[1]); one MSM (= one proof's multi_exp) per rank per step" % args.log2n,
                 "points_per_msm": n,
                 "window_bits": args.window or "auto",
+                "tail_overlap": not args.no_overlap,
                 "proofs_per_sec": world * args.steps / dt_max,
                 "exchange": "none (1 GPU)" if world == 1 else "1 all-gather of %d x 96 B + local fold" % world,
                 "bases_generate_s": t_gen,

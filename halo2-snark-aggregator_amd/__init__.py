@@ -76,6 +76,7 @@ def load_library():
         "h2agg_g1_msm_device": (i32, [ctxp, u64, vp, sz, vp]),
         "h2agg_g1_msm_device_async": (i32, [ctxp, u64, vp, sz, vp]),
         "h2agg_msm_configure": (i32, [ctxp, i32, i32, i32]),
+        "h2agg_msm_set_tail_overlap": (i32, [ctxp, i32]),
         "h2agg_profile_enable": (i32, [ctxp, i32]),
         "h2agg_profile_reset": (i32, [ctxp]),
         "h2agg_profile_stage_count": (i32, [ctxp]),
@@ -225,6 +226,9 @@ class H2Agg:
     # ------------------------------------------------------------------ tuning / measurement
     def msm_configure(self, window_bits: int = 0, reduce_segment: int = 0, big_bucket_threshold: int = 0):
         self._check(self._lib.h2agg_msm_configure(self._ctx, window_bits, reduce_segment, big_bucket_threshold))
+
+    def msm_set_tail_overlap(self, on: bool = True):
+        self._check(self._lib.h2agg_msm_set_tail_overlap(self._ctx, int(on)))
 
     def profile_enable(self, on: bool = True):
         self._check(self._lib.h2agg_profile_enable(self._ctx, int(on)))

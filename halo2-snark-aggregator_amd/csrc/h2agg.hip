@@ -22,9 +22,13 @@ struct DevBuf {
     size_t cap = 0;
 };
 
-enum Stage { ST_COUNT = 0, ST_SCAN, ST_SCATTER, ST_ACCUM, ST_ACCUM_BIG, ST_REDUCE, ST_WINDOW_SUM, ST_FINAL, ST_N };
-const char* const STAGE_NAMES[ST_N] = {"msm_count",          "msm_scan",   "msm_scatter",    "msm_accumulate",
-                                       "msm_accumulate_big", "msm_reduce", "msm_window_sum", "msm_final"};
+enum Stage {
+    ST_PART_COUNT = 0, ST_PART_SCATTER, ST_BUCKET_SORT, ST_ORDER, ST_ACCUM, ST_ACCUM_BIG, ST_REDUCE, ST_WINDOW_SUM,
+    ST_FINAL, ST_N
+};
+const char* const STAGE_NAMES[ST_N] = {"msm_part_count", "msm_part_scatter",   "msm_bucket_sort",
+                                       "msm_order",      "msm_accumulate",     "msm_accumulate_big",
+                                       "msm_reduce",     "msm_window_sum",     "msm_final"};
 
 struct Table {
     uint8_t* d = nullptr;  // Montgomery affine, 64 B / point
@@ -43,7 +47,7 @@ struct h2agg_ctx {
 
     // grow-only device workspace
     DevBuf in_a, in_b, in_c, out, tmp_bases;                      // host-buffer entry points
-    DevBuf hist, offs, cursor, blocksum, entries, buckets, segsum, wsum, big_list, small;  // MSM
+    DevBuf hist, offs, pmeta, item_idx, item_sub, order, entries, buckets, segsum, wsum, big_list, small;  // MSM
     uint32_t* d_flags = nullptr;      // in `small`: [0] status flags, [1] big_count
     uint8_t* d_res_xyzz = nullptr;    // in `small` + 64
     uint8_t* d_res_jac = nullptr;     // in `small` + 256
@@ -55,10 +59,25 @@ struct h2agg_ctx {
     // tuning
     int cfg_c = 0, cfg_seg = 0, cfg_big = 0;
 
-    // profiling
+    // optional overlap of the serial tail (k_msm_final) of MSM k with the bulk of MSM k+1
+    bool tail_overlap = false;
+    hipStream_t tail_stream = nullptr;
+    hipEvent_t ev_bulk[2] = {}, ev_tail[2] = {};
+    bool tail_pending[2] = {false, false};
+    int parity = 0;
+
+    // profiling: a ring of per-call event sets, harvested lazily so that measuring does not serialise
+    // back-to-back asynchronous MSMs
+    static constexpr int PROF_RING = 32;
+    struct ProfSlot {
+        hipEvent_t ev[ST_N][2] = {};
+        bool used[ST_N] = {};
+        bool pending = false;
+    };
     bool profiling = false;
-    hipEvent_t ev[ST_N][2] = {};
-    bool ev_used[ST_N] = {};
+    bool prof_events_created = false;
+    ProfSlot prof[PROF_RING];
+    int prof_cur = 0;
     double stage_ms[ST_N] = {};
     uint64_t stage_launches[ST_N] = {};
 };
@@ -142,31 +161,58 @@ MsmPlan make_plan(const h2agg_ctx* c, size_t n) {
 struct StageTimer {
     h2agg_ctx* c;
     int st;
-    StageTimer(h2agg_ctx* c_, int st_) : c(c_), st(st_) {
+    hipStream_t s;
+    StageTimer(h2agg_ctx* c_, int st_, hipStream_t s_ = nullptr) : c(c_), st(st_), s(s_ ? s_ : c_->stream) {
         if (c->profiling) {
-            hipEventRecord(c->ev[st][0], c->stream);
+            hipEventRecord(c->prof[c->prof_cur].ev[st][0], s);
         }
     }
     ~StageTimer() {
         if (c->profiling) {
-            hipEventRecord(c->ev[st][1], c->stream);
-            c->ev_used[st] = true;
+            hipEventRecord(c->prof[c->prof_cur].ev[st][1], s);
+            c->prof[c->prof_cur].used[st] = true;
         }
     }
 };
 
-void profile_collect(h2agg_ctx* c) {
-    if (!c->profiling) return;
-    hipStreamSynchronize(c->stream);
+// harvest one ring slot (blocks until that call's events have completed)
+void profile_harvest(h2agg_ctx* c, int slot) {
+    h2agg_ctx::ProfSlot& ps = c->prof[slot];
+    if (!ps.pending) return;
     for (int s = 0; s < ST_N; ++s) {
-        if (!c->ev_used[s]) continue;
+        if (!ps.used[s]) continue;
         float ms = 0.f;
-        if (hipEventElapsedTime(&ms, c->ev[s][0], c->ev[s][1]) == hipSuccess) {
+        hipEventSynchronize(ps.ev[s][1]);
+        if (hipEventElapsedTime(&ms, ps.ev[s][0], ps.ev[s][1]) == hipSuccess) {
             c->stage_ms[s] += ms;
             c->stage_launches[s] += 1;
         }
-        c->ev_used[s] = false;
+        ps.used[s] = false;
     }
+    ps.pending = false;
+}
+void profile_begin_call(h2agg_ctx* c) {
+    if (!c->profiling) return;
+    profile_harvest(c, c->prof_cur);  // slot about to be reused
+}
+void profile_end_call(h2agg_ctx* c) {
+    if (!c->profiling) return;
+    c->prof[c->prof_cur].pending = true;
+    c->prof_cur = (c->prof_cur + 1) % h2agg_ctx::PROF_RING;
+}
+void profile_harvest_all(h2agg_ctx* c) {
+    for (int k = 0; k < h2agg_ctx::PROF_RING; ++k) profile_harvest(c, k);
+}
+
+// make everything queued on the tail stream visible to the main stream
+int join_tails(h2agg_ctx* c) {
+    for (int k = 0; k < 2; ++k) {
+        if (c->tail_pending[k]) {
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_tail[k], 0));
+            c->tail_pending[k] = false;
+        }
+    }
+    return H2AGG_OK;
 }
 
 // The MSM proper.  d_bases: Montgomery affine table; d_scalars: canonical 32-B scalars (device).
@@ -176,52 +222,77 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     const MsmPlan p = make_plan(c, n);
     const size_t nent = n * (size_t)p.W;
     if (nent >= ((size_t)1 << 32)) return fail(c, H2AGG_ERR_INVALID, "n * windows must be < 2^32");
-    const uint32_t nscanblocks = (p.NBT + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;
-    if (nscanblocks > (uint32_t)SCAN_PER_BLOCK) return fail(c, H2AGG_ERR_INVALID, "too many buckets");
+    SortPlan sp;
+    sp.sub_bits = (p.c - 1 < SORT_SUB_BITS) ? p.c - 1 : SORT_SUB_BITS;
+    sp.SB = 1u << sp.sub_bits;
+    sp.ppw = p.NB >> sp.sub_bits;
+    sp.PW = (uint32_t)p.W * sp.ppw;
+    sp.tile = 2048;
+    if (sp.PW > (uint32_t)SORT_MAX_PW) return fail(c, H2AGG_ERR_INVALID, "too many sort partitions");
     const uint32_t nseg_total = (uint32_t)p.W * p.spw;
+    // pmeta words: [0,PW] pcount | [2048, +PW+1] pstart | [4096, +PW] pcursor | [6144,+1024] bin_count |
+    //              [8192,+1025] bin_start | [10240,+1024] bin_cursor
+    TRY(ensure(c, c->pmeta, 12288 * 4));
     TRY(ensure(c, c->hist, (size_t)p.NBT * 4));
     TRY(ensure(c, c->offs, (size_t)p.NBT * 4));
-    TRY(ensure(c, c->cursor, (size_t)p.NBT * 4));
-    TRY(ensure(c, c->blocksum, (size_t)nscanblocks * 4));
+    TRY(ensure(c, c->order, (size_t)p.NBT * 4));
+    TRY(ensure(c, c->item_idx, nent * 4));
+    TRY(ensure(c, c->item_sub, nent * 2));
     TRY(ensure(c, c->entries, nent * 4));
     TRY(ensure(c, c->buckets, (size_t)p.NBT * XYZZ_BYTES));
     TRY(ensure(c, c->segsum, (size_t)nseg_total * XYZZ_BYTES));
-    TRY(ensure(c, c->wsum, (size_t)p.W * XYZZ_BYTES));
+    TRY(ensure(c, c->wsum, 2 * (size_t)p.W * XYZZ_BYTES));
     TRY(ensure(c, c->big_list, (size_t)p.NBT * 4));
+    uint32_t* meta = (uint32_t*)c->pmeta.p;
+    uint32_t *pcount = meta, *pstart = meta + 2048, *pcursor = meta + 4096;
+    uint32_t *bin_count = meta + 6144, *bin_start = meta + 8192, *bin_cursor = meta + 10240;
     uint32_t* hist = (uint32_t*)c->hist.p;
     uint32_t* offs = (uint32_t*)c->offs.p;
-    uint32_t* cursor = (uint32_t*)c->cursor.p;
-    uint32_t* blocksum = (uint32_t*)c->blocksum.p;
+    uint32_t* order = (uint32_t*)c->order.p;
+    uint32_t* item_idx = (uint32_t*)c->item_idx.p;
+    uint16_t* item_sub = (uint16_t*)c->item_sub.p;
     uint32_t* entries = (uint32_t*)c->entries.p;
     uint8_t* buckets = (uint8_t*)c->buckets.p;
     uint8_t* segsum = (uint8_t*)c->segsum.p;
-    uint8_t* wsum = (uint8_t*)c->wsum.p;
+    const int par = c->parity;
+    uint8_t* wsum = (uint8_t*)c->wsum.p + (size_t)par * p.W * XYZZ_BYTES;
     uint32_t* big_list = (uint32_t*)c->big_list.p;
     uint32_t* big_count = c->d_flags + 1;
     hipStream_t st = c->stream;
-    const int g = grid_for(c, n);
+    const unsigned ntiles = (unsigned)((n + sp.tile - 1) / sp.tile);
+    profile_begin_call(c);
 
     {
-        StageTimer t(c, ST_COUNT);
-        HIP_TRY(c, hipMemsetAsync(hist, 0, (size_t)p.NBT * 4, st));
+        StageTimer t(c, ST_PART_COUNT);
+        HIP_TRY(c, hipMemsetAsync(meta, 0, 12288 * 4, st));
         HIP_TRY(c, hipMemsetAsync(big_count, 0, 4, st));
-        hipLaunchKernelGGL(k_msm_count, dim3(g), dim3(BLOCK), 0, st, d_scalars, n, p.c, p.W, p.NB, hist, c->d_flags);
+        hipLaunchKernelGGL(k_part_count, dim3(ntiles), dim3(BLOCK), 0, st, d_scalars, n, p.c, p.W, sp, pcount,
+                           c->d_flags);
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(BLOCK), 0, st, pcount, sp.PW, pstart, pcursor);
     }
     {
-        StageTimer t(c, ST_SCAN);
-        hipLaunchKernelGGL(k_scan_local, dim3(nscanblocks), dim3(BLOCK), 0, st, hist, p.NBT, offs, blocksum);
-        hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(BLOCK), 0, st, blocksum, nscanblocks);
-        hipLaunchKernelGGL(k_scan_add, dim3((p.NBT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, offs, cursor, p.NBT,
-                           blocksum);
+        StageTimer t(c, ST_PART_SCATTER);
+        hipLaunchKernelGGL(k_part_scatter, dim3(ntiles), dim3(BLOCK), 0, st, d_scalars, n, p.c, p.W, sp, pcursor,
+                           item_idx, item_sub);
     }
     {
-        StageTimer t(c, ST_SCATTER);
-        hipLaunchKernelGGL(k_msm_scatter, dim3(g), dim3(BLOCK), 0, st, d_scalars, n, p.c, p.W, p.NB, cursor, entries);
+        StageTimer t(c, ST_BUCKET_SORT);
+        hipLaunchKernelGGL(k_bucket_sort, dim3(sp.PW), dim3(BLOCK), 0, st, pstart, item_idx, item_sub, sp, p.NB, hist,
+                           offs, entries);
+    }
+    {
+        StageTimer t(c, ST_ORDER);
+        unsigned g = (p.NBT + BLOCK * 8 - 1) / (BLOCK * 8);
+        if (g > (unsigned)c->cu_count * 4) g = (unsigned)c->cu_count * 4;
+        hipLaunchKernelGGL(k_size_count, dim3(g), dim3(BLOCK), 0, st, hist, p.NBT, bin_count);
+        hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(BLOCK), 0, st, bin_count, (uint32_t)SIZE_BINS, bin_start,
+                           bin_cursor);
+        hipLaunchKernelGGL(k_size_scatter, dim3(g), dim3(BLOCK), 0, st, hist, p.NBT, bin_cursor, order);
     }
     {
         StageTimer t(c, ST_ACCUM);
         hipLaunchKernelGGL(k_msm_accumulate, dim3((p.NBT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d_bases, entries,
-                           offs, hist, p.NBT, p.big, buckets, big_list, big_count);
+                           offs, hist, order, p.NBT, p.big, buckets, big_list, big_count);
     }
     {
         StageTimer t(c, ST_ACCUM_BIG);
@@ -240,12 +311,29 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         StageTimer t(c, ST_WINDOW_SUM);
         hipLaunchKernelGGL(k_msm_window_sum, dim3(p.W), dim3(BLOCK), 0, st, segsum, p.spw, wsum);
     }
-    {
+    if (c->tail_overlap) {
+        // serial Horner tail on its own stream: it overlaps the bulk of the next MSM.  The main stream
+        // picks the result up (join_tails) before anything that consumes it or reuses wsum[par].
+        HIP_TRY(c, hipEventRecord(c->ev_bulk[par], st));
+        HIP_TRY(c, hipStreamWaitEvent(c->tail_stream, c->ev_bulk[par], 0));
+        {
+            StageTimer t(c, ST_FINAL, c->tail_stream);
+            hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, c->tail_stream, wsum, p.c, p.W, c->d_res_xyzz,
+                               d_out_jac);
+        }
+        HIP_TRY(c, hipEventRecord(c->ev_tail[par], c->tail_stream));
+        c->tail_pending[par] = true;
+        if (c->tail_pending[par ^ 1]) {  // previous MSM's tail: its wsum slot is reused by the next call
+            HIP_TRY(c, hipStreamWaitEvent(st, c->ev_tail[par ^ 1], 0));
+            c->tail_pending[par ^ 1] = false;
+        }
+        c->parity ^= 1;
+    } else {
         StageTimer t(c, ST_FINAL);
         hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, st, wsum, p.c, p.W, c->d_res_xyzz, d_out_jac);
     }
     HIP_TRY(c, hipGetLastError());
-    profile_collect(c);
+    profile_end_call(c);
     return H2AGG_OK;
 }
 
@@ -256,6 +344,7 @@ int set_identity_jac(uint8_t out[96]) {
 }
 
 int fetch_result_jac(h2agg_ctx* c, uint8_t out[96]) {
+    TRY(join_tails(c));
     HIP_TRY(c, hipMemcpyAsync(c->h_pinned, c->d_res_jac, 96, hipMemcpyDeviceToHost, c->stream));
     TRY(finish(c));
     memcpy(out, c->h_pinned, 96);
@@ -297,11 +386,17 @@ int h2agg_create(int device_ordinal, h2agg_ctx** out) {
         return H2AGG_ERR_HIP;
     }
     c->stream = c->own_stream;
+    if (hipStreamCreateWithFlags(&c->tail_stream, hipStreamNonBlocking) != hipSuccess) {
+        h2agg_destroy(c);
+        return H2AGG_ERR_HIP;
+    }
+    for (int k = 0; k < 2; ++k) {
+        hipEventCreateWithFlags(&c->ev_bulk[k], hipEventDisableTiming);
+        hipEventCreateWithFlags(&c->ev_tail[k], hipEventDisableTiming);
+    }
     c->d_flags = (uint32_t*)c->small.p;
     c->d_res_xyzz = (uint8_t*)c->small.p + 64;   // 144 B
     c->d_res_jac = (uint8_t*)c->small.p + 256;   // 96 B
-    for (int s = 0; s < ST_N; ++s)
-        for (int k = 0; k < 2; ++k) hipEventCreate(&c->ev[s][k]);
     hipMemset(c->small.p, 0, 1024);
     *out = c;
     return H2AGG_OK;
@@ -311,16 +406,24 @@ void h2agg_destroy(h2agg_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->in_a, &c->in_b,   &c->in_c,    &c->out,    &c->tmp_bases, &c->hist,     &c->offs, &c->cursor,
-                      &c->blocksum, &c->entries, &c->buckets, &c->segsum, &c->wsum,      &c->big_list, &c->small};
+    if (c->tail_stream) hipStreamSynchronize(c->tail_stream);
+    DevBuf* bufs[] = {&c->in_a,  &c->in_b,     &c->in_c,     &c->out,   &c->tmp_bases, &c->hist,
+                      &c->offs,  &c->pmeta,    &c->item_idx, &c->item_sub, &c->order,  &c->entries,
+                      &c->buckets, &c->segsum, &c->wsum,     &c->big_list, &c->small};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     for (auto& kv : c->tables)
         if (kv.second.d) hipFree(kv.second.d);
     if (c->h_pinned) hipHostFree(c->h_pinned);
-    for (int s = 0; s < ST_N; ++s)
-        for (int k = 0; k < 2; ++k)
-            if (c->ev[s][k]) hipEventDestroy(c->ev[s][k]);
+    for (int r = 0; r < h2agg_ctx::PROF_RING; ++r)
+        for (int s = 0; s < ST_N; ++s)
+            for (int k = 0; k < 2; ++k)
+                if (c->prof[r].ev[s][k]) hipEventDestroy(c->prof[r].ev[s][k]);
+    for (int k = 0; k < 2; ++k) {
+        if (c->ev_bulk[k]) hipEventDestroy(c->ev_bulk[k]);
+        if (c->ev_tail[k]) hipEventDestroy(c->ev_tail[k]);
+    }
+    if (c->tail_stream) hipStreamDestroy(c->tail_stream);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -330,6 +433,7 @@ const char* h2agg_describe(h2agg_ctx* c) { return c ? c->desc.c_str() : ""; }
 
 int h2agg_set_stream(h2agg_ctx* c, void* hip_stream) {
     TRY(bind(c));
+    TRY(join_tails(c));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return H2AGG_OK;
@@ -337,6 +441,7 @@ int h2agg_set_stream(h2agg_ctx* c, void* hip_stream) {
 
 int h2agg_synchronize(h2agg_ctx* c) {
     TRY(bind(c));
+    TRY(join_tails(c));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return H2AGG_OK;
 }
@@ -610,6 +715,7 @@ int h2agg_eval_flat(h2agg_ctx* c, const uint8_t* pts, const uint8_t* scalars, co
     hipLaunchKernelGGL(k_bases_to_mont, dim3(grid_for(c, m)), dim3(BLOCK), 0, c->stream, (const uint8_t*)c->in_a.p, m,
                        (uint8_t*)c->tmp_bases.p, c->d_flags);
     TRY(msm_run(c, (const uint8_t*)c->tmp_bases.p, (const uint8_t*)c->in_b.p, m, nullptr));
+    TRY(join_tails(c));
     hipLaunchKernelGGL(k_eval_tail, dim3(1), dim3(BLOCK), 0, c->stream, (const uint8_t*)c->d_res_xyzz,
                        (const uint8_t*)c->in_c.p, k, c->d_res_jac, c->d_flags);
     return fetch_result_jac(c, out);
@@ -629,13 +735,29 @@ int h2agg_msm_configure(h2agg_ctx* c, int window_bits, int reduce_segment, int b
     return H2AGG_OK;
 }
 
+int h2agg_msm_set_tail_overlap(h2agg_ctx* c, int enable) {
+    TRY(bind(c));
+    TRY(join_tails(c));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->tail_overlap = enable != 0;
+    return H2AGG_OK;
+}
+
 int h2agg_profile_enable(h2agg_ctx* c, int enable) {
-    if (!c) return H2AGG_ERR_INVALID;
+    TRY(bind(c));
+    if (enable && !c->prof_events_created) {
+        for (int r = 0; r < h2agg_ctx::PROF_RING; ++r)
+            for (int s = 0; s < ST_N; ++s)
+                for (int k = 0; k < 2; ++k) HIP_TRY(c, hipEventCreate(&c->prof[r].ev[s][k]));
+        c->prof_events_created = true;
+    }
+    if (!enable) profile_harvest_all(c);
     c->profiling = enable != 0;
     return H2AGG_OK;
 }
 int h2agg_profile_reset(h2agg_ctx* c) {
     if (!c) return H2AGG_ERR_INVALID;
+    profile_harvest_all(c);
     for (int s = 0; s < ST_N; ++s) {
         c->stage_ms[s] = 0;
         c->stage_launches[s] = 0;
@@ -646,6 +768,7 @@ int h2agg_profile_stage_count(h2agg_ctx*) { return ST_N; }
 const char* h2agg_profile_stage_name(h2agg_ctx*, int i) { return (i >= 0 && i < ST_N) ? STAGE_NAMES[i] : ""; }
 int h2agg_profile_stage_get(h2agg_ctx* c, int i, double* total_ms, uint64_t* launches) {
     if (!c || i < 0 || i >= ST_N) return H2AGG_ERR_INVALID;
+    profile_harvest_all(c);
     if (total_ms) *total_ms = c->stage_ms[i];
     if (launches) *launches = c->stage_launches[i];
     return H2AGG_OK;

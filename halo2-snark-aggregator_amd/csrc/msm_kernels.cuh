@@ -7,11 +7,10 @@
 //
 //   digits      each lane recodes one canonical scalar into W signed c-bit digits (carry chain in
 //               registers, the 256-bit value is shifted down c bits per window), coalesced 32-B reads
-//   count       histogram of (window, |digit|) keys              -> hist[W * 2^(c-1)]
-//   scan        exclusive prefix sum of hist                     -> offs[], cursor[]
-//   scatter     point index (| sign << 31) into its key's run    -> entries[n * W]
-//   accumulate  one lane per bucket walks its run: 64-B gathers of Montgomery affine bases, XYZZ mixed
-//               adds; buckets longer than `big` are handed to a workgroup each (LDS tree sum)
+//   sort        two-level LDS partition of the (window, |digit|) keys (sort_kernels.cuh)
+//               -> hist[W * 2^(c-1)], offs[], entries[n * W] (point index | sign << 31), order[]
+//   accumulate  one lane per bucket (longest first) walks its run: 64-B gathers of Montgomery affine
+//               bases, XYZZ mixed adds; buckets longer than `big` are handed to a workgroup each
 //   reduce      per window sum_j (j+1) * B_j by running sums over segments of `seg` buckets, segment
 //               offsets folded in with a <= 15-bit double-and-add, then one workgroup per window
 //   final       Horner over the W window sums (c doublings each), canonical Jacobian out
@@ -19,7 +18,7 @@
 // Point order inside a bucket is whatever the scatter's atomics produced; the result does not depend on
 // it because the arithmetic is exact.
 #pragma once
-#include "batch_kernels.cuh"
+#include "sort_kernels.cuh"
 
 namespace h2agg {
 
@@ -33,115 +32,6 @@ struct MsmPlan {
     uint32_t big;   // bucket length above which a workgroup takes the bucket
 };
 
-// Signed-digit recode of a canonical scalar; calls f(window, bucket_index(0-based), negative) for every
-// non-zero digit.  Digits lie in [-2^(c-1), 2^(c-1)]; W*c >= 255 guarantees no carry out of the top window.
-template <class F>
-FP_INLINE void msm_for_each_digit(U256 s, int c, int W, F&& f) {
-    const uint32_t mask = (1u << c) - 1u;
-    const uint32_t half = 1u << (c - 1);
-    uint32_t carry = 0;
-#pragma unroll 1
-    for (int w = 0; w < W; ++w) {
-        uint32_t raw = (s.w[0] & mask) + carry;
-#pragma unroll
-        for (int i = 0; i < 7; ++i) s.w[i] = (s.w[i] >> c) | (s.w[i + 1] << (32 - c));
-        s.w[7] >>= c;
-        const bool neg = raw > half;
-        carry = neg ? 1u : 0u;
-        const uint32_t mag = neg ? ((1u << c) - raw) : raw;
-        if (mag != 0) f(w, mag - 1u, neg);
-    }
-}
-
-__global__ void __launch_bounds__(BLOCK) k_msm_count(const uint8_t* __restrict__ scalars, size_t n, int c, int W,
-                                                     uint32_t NB, uint32_t* __restrict__ hist, uint32_t* flags) {
-    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
-        U256 s = u256_load(scalars + 32 * i);
-        if (!u256_is_canonical_fr(s)) atomicOr(flags, FLAG_NONCANONICAL);
-        msm_for_each_digit(s, c, W, [&](int w, uint32_t b, bool) { atomicAdd(&hist[(uint32_t)w * NB + b], 1u); });
-    }
-}
-
-__global__ void __launch_bounds__(BLOCK) k_msm_scatter(const uint8_t* __restrict__ scalars, size_t n, int c, int W,
-                                                       uint32_t NB, uint32_t* __restrict__ cursor,
-                                                       uint32_t* __restrict__ entries) {
-    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
-        U256 s = u256_load(scalars + 32 * i);
-        msm_for_each_digit(s, c, W, [&](int w, uint32_t b, bool neg) {
-            uint32_t pos = atomicAdd(&cursor[(uint32_t)w * NB + b], 1u);
-            entries[pos] = (uint32_t)i | (neg ? 0x80000000u : 0u);
-        });
-    }
-}
-
-// ------------------------------------------------------------------ exclusive scan (3 small kernels)
-constexpr int SCAN_PER_THREAD = 8;
-constexpr int SCAN_PER_BLOCK = BLOCK * SCAN_PER_THREAD;
-
-FP_INLINE uint32_t block_exclusive_scan_u32(uint32_t v, uint32_t* lds /* BLOCK words */, uint32_t& total) {
-    const int tid = threadIdx.x;
-    lds[tid] = v;
-    __syncthreads();
-#pragma unroll 1
-    for (int d = 1; d < BLOCK; d <<= 1) {
-        uint32_t t = (tid >= d) ? lds[tid - d] : 0u;
-        __syncthreads();
-        lds[tid] += t;
-        __syncthreads();
-    }
-    total = lds[BLOCK - 1];
-    return lds[tid] - v;
-}
-
-__global__ void __launch_bounds__(BLOCK) k_scan_local(const uint32_t* __restrict__ in, uint32_t n,
-                                                      uint32_t* __restrict__ out, uint32_t* __restrict__ blocksum) {
-    __shared__ uint32_t lds[BLOCK];
-    const uint32_t base = blockIdx.x * SCAN_PER_BLOCK + threadIdx.x * SCAN_PER_THREAD;
-    uint32_t v[SCAN_PER_THREAD];
-    uint32_t sum = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
-        v[k] = (base + k < n) ? in[base + k] : 0u;
-        sum += v[k];
-    }
-    uint32_t total;
-    uint32_t off = block_exclusive_scan_u32(sum, lds, total);
-#pragma unroll
-    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
-        if (base + k < n) out[base + k] = off;
-        off += v[k];
-    }
-    if (threadIdx.x == 0) blocksum[blockIdx.x] = total;
-}
-// scans up to SCAN_PER_BLOCK block sums in place (exclusive)
-__global__ void __launch_bounds__(BLOCK) k_scan_blocks(uint32_t* __restrict__ blocksum, uint32_t nblocks) {
-    __shared__ uint32_t lds[BLOCK];
-    const uint32_t base = threadIdx.x * SCAN_PER_THREAD;
-    uint32_t v[SCAN_PER_THREAD];
-    uint32_t sum = 0;
-#pragma unroll
-    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
-        v[k] = (base + k < nblocks) ? blocksum[base + k] : 0u;
-        sum += v[k];
-    }
-    uint32_t total;
-    uint32_t off = block_exclusive_scan_u32(sum, lds, total);
-#pragma unroll
-    for (int k = 0; k < SCAN_PER_THREAD; ++k) {
-        if (base + k < nblocks) blocksum[base + k] = off;
-        off += v[k];
-    }
-}
-__global__ void __launch_bounds__(BLOCK) k_scan_add(uint32_t* __restrict__ offs, uint32_t* __restrict__ cursor,
-                                                    uint32_t n, const uint32_t* __restrict__ blockoff) {
-    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
-    if (i < n) {
-        uint32_t v = offs[i] + blockoff[i / SCAN_PER_BLOCK];
-        offs[i] = v;
-        cursor[i] = v;
-    }
-}
-
 // ------------------------------------------------------------------ bucket accumulation
 FP_INLINE G1Affine msm_gather(const uint8_t* __restrict__ bases, uint32_t e) {
     G1Affine p = affine_load(bases + 64 * (size_t)(e & 0x7fffffffu));
@@ -151,11 +41,13 @@ FP_INLINE G1Affine msm_gather(const uint8_t* __restrict__ bases, uint32_t e) {
 __global__ void __launch_bounds__(BLOCK) k_msm_accumulate(const uint8_t* __restrict__ bases,
                                                           const uint32_t* __restrict__ entries,
                                                           const uint32_t* __restrict__ offs,
-                                                          const uint32_t* __restrict__ hist, uint32_t nbt, uint32_t big,
+                                                          const uint32_t* __restrict__ hist,
+                                                          const uint32_t* __restrict__ order, uint32_t nbt, uint32_t big,
                                                           uint8_t* __restrict__ buckets, uint32_t* __restrict__ big_list,
                                                           uint32_t* __restrict__ big_count) {
-    const uint32_t key = blockIdx.x * BLOCK + threadIdx.x;
-    if (key >= nbt) return;
+    const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    if (t >= nbt) return;
+    const uint32_t key = order[t];  // buckets sorted by length, longest first: a wave's lanes finish together
     const uint32_t len = hist[key];
     if (len > big) {
         big_list[atomicAdd(big_count, 1u)] = key;
@@ -249,6 +141,16 @@ __global__ void k_msm_final(const uint8_t* __restrict__ wsum, int c, int W, uint
                             uint8_t* __restrict__ out_jac) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     G1XYZZ acc = xyzz_load(wsum + XYZZ_BYTES * (size_t)(W - 1));
+    // Everything here is wave-uniform, and hipcc would otherwise move the whole chain onto the scalar
+    // ALU (s_mul_hi_u32 sequences: 3.4 ms for 240 doublings, profiles/r01_kernel_stats_baseline_u32x8.txt).
+    // Pin the accumulator in VGPRs so the 64-bit multiply-adds run on the vector ALU.
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        asm volatile("" : "+v"(acc.x.l[i]));
+        asm volatile("" : "+v"(acc.y.l[i]));
+        asm volatile("" : "+v"(acc.zz.l[i]));
+        asm volatile("" : "+v"(acc.zzz.l[i]));
+    }
 #pragma unroll 1
     for (int w = W - 2; w >= 0; --w) {
 #pragma unroll 1

@@ -137,6 +137,11 @@ int h2agg_g1_msm_device_async(h2agg_ctx* ctx, uint64_t bases_handle, const void*
 /* ---- tuning / measurement -------------------------------------------------------------------------
  * window_bits: Pippenger window c in [2, 16], 0 = choose from n.  Other knobs: 0 = default. */
 int h2agg_msm_configure(h2agg_ctx* ctx, int window_bits, int reduce_segment, int big_bucket_threshold);
+/* Overlap the serial Horner tail of one MSM (k_msm_final, one wave) with the bulk kernels of the next:
+ * the tail runs on a second stream of the context.  With overlap on, a result written by
+ * h2agg_g1_msm_device_async is complete after h2agg_synchronize() (or after the next synchronous call on
+ * the context), not merely after the caller's stream has drained.  Default: off. */
+int h2agg_msm_set_tail_overlap(h2agg_ctx* ctx, int enable);
 /* When enabled, every MSM stage is bracketed by HIP events on the context's stream and per-stage times
  * are accumulated (this makes the async entry point synchronise at the end of each call). */
 int h2agg_profile_enable(h2agg_ctx* ctx, int enable);
