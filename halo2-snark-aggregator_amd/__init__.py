@@ -75,6 +75,19 @@ def load_library():
         "h2agg_g1_msm_preloaded": (i32, [ctxp, u64, u8p, sz, vp]),
         "h2agg_g1_msm_device": (i32, [ctxp, u64, vp, sz, vp]),
         "h2agg_g1_msm_device_async": (i32, [ctxp, u64, vp, sz, vp]),
+        "h2agg_schema_create": (i32, [ctxp, C.POINTER(C.c_void_p)]),
+        "h2agg_schema_destroy": (None, [C.c_void_p]),
+        "h2agg_schema_node_commitment": (i32, [C.c_void_p, C.c_char_p, u8p, C.POINTER(C.c_uint32)]),
+        "h2agg_schema_node_eval": (i32, [C.c_void_p, u8p, C.POINTER(C.c_uint32)]),
+        "h2agg_schema_node_scalar": (i32, [C.c_void_p, u8p, C.POINTER(C.c_uint32)]),
+        "h2agg_schema_node_add": (i32, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
+        "h2agg_schema_node_mul": (i32, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
+        "h2agg_schema_estimate": (i32, [C.c_void_p, C.c_uint32, C.POINTER(C.c_size_t)]),
+        "h2agg_schema_eval": (i32, [C.c_void_p, C.c_uint32, vp, C.POINTER(i32), vp]),
+        "h2agg_evaluate_multiopen_proof": (i32, [C.c_void_p, C.c_uint32, C.c_uint32, vp, vp]),
+        "h2agg_schema_name_count": (C.c_size_t, [C.c_void_p]),
+        "h2agg_schema_name": (C.c_char_p, [C.c_void_p, C.c_size_t]),
+        "h2agg_schema_point_list_len": (C.c_size_t, [C.c_void_p]),
         "h2agg_msm_configure": (i32, [ctxp, i32, i32, i32]),
         "h2agg_msm_set_tail_overlap": (i32, [ctxp, i32]),
         "h2agg_profile_enable": (i32, [ctxp, i32]),
@@ -244,3 +257,82 @@ class H2Agg:
             self._check(self._lib.h2agg_profile_stage_get(self._ctx, i, C.byref(ms), C.byref(cnt)))
             out[self._lib.h2agg_profile_stage_name(self._ctx, i).decode()] = (ms.value, cnt.value)
         return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# EvaluationQuerySchema mirror (halo2-snark-aggregator-api/src/systems/halo2/evaluation.rs).  The AST lives
+# in the C++ host layer of libh2agg.so; these classes only hold node ids, so tests read like the
+# reference's: `commit(cq) + evalq(cq)`, `scalar(v) * acc + q`, `proof.w_x.eval(...)`.
+class CommitQuery:                       # evaluation.rs:7-12
+    def __init__(self, key: str, commitment: Optional[bytes] = None, eval: Optional[bytes] = None):
+        self.key, self.commitment, self.eval = key, commitment, eval
+
+
+class SchemaBuilder:
+    """Arena of schema nodes bound to one H2Agg context."""
+
+    def __init__(self, eng: H2Agg):
+        self.eng = eng
+        self._lib = eng._lib
+        self._s = C.c_void_p()
+        eng._check(self._lib.h2agg_schema_create(eng._ctx, C.byref(self._s)))
+
+    def close(self):
+        if getattr(self, "_s", None):
+            self._lib.h2agg_schema_destroy(self._s)
+            self._s = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _node(self, fn, *args) -> "EvaluationQuerySchema":
+        out = C.c_uint32()
+        self.eng._check(fn(self._s, *args, C.byref(out)))
+        return EvaluationQuerySchema(self, out.value)
+
+    def commit(self, cq: CommitQuery) -> "EvaluationQuerySchema":        # commit!  evaluation.rs:41-46
+        return self._node(self._lib.h2agg_schema_node_commitment, cq.key.encode(), cq.commitment)
+
+    def evalq(self, cq: CommitQuery) -> "EvaluationQuerySchema":         # eval!    evaluation.rs:48-53
+        return self._node(self._lib.h2agg_schema_node_eval, cq.eval)
+
+    def scalar(self, s: bytes) -> "EvaluationQuerySchema":               # scalar!  evaluation.rs:55-60
+        return self._node(self._lib.h2agg_schema_node_scalar, s)
+
+    def evaluate_multiopen_proof(self, w_x: "EvaluationQuerySchema", w_g: "EvaluationQuerySchema"):
+        """verify.rs:705-731 -> (left_aff, right_aff, names)"""
+        left, right = C.create_string_buffer(64), C.create_string_buffer(64)
+        self.eng._check(self._lib.h2agg_evaluate_multiopen_proof(self._s, w_x.node, w_g.node, left, right))
+        return left.raw, right.raw, self.names()
+
+    def names(self):
+        n = self._lib.h2agg_schema_name_count(self._s)
+        return [self._lib.h2agg_schema_name(self._s, i).decode() for i in range(n)]
+
+    def point_list_len(self) -> int:
+        return self._lib.h2agg_schema_point_list_len(self._s)
+
+
+class EvaluationQuerySchema:
+    def __init__(self, builder: SchemaBuilder, node: int):
+        self.b, self.node = builder, node
+
+    def __add__(self, other):                                            # impl Add  evaluation.rs:62-72
+        return self.b._node(self.b._lib.h2agg_schema_node_add, self.node, other.node)
+
+    def __mul__(self, other):                                            # impl Mul  evaluation.rs:74-84
+        return self.b._node(self.b._lib.h2agg_schema_node_mul, self.node, other.node)
+
+    def estimate(self) -> int:                                           # evaluation.rs:295-330
+        out = C.c_size_t()
+        self.b.eng._check(self.b._lib.h2agg_schema_estimate(self.b._s, self.node, C.byref(out)))
+        return out.value
+
+    def eval(self):
+        """evaluation.rs:172-203 -> (point_jac, scalar or None, names)"""
+        jac, sc, has = C.create_string_buffer(96), C.create_string_buffer(32), C.c_int()
+        self.b.eng._check(self.b._lib.h2agg_schema_eval(self.b._s, self.node, jac, C.byref(has), sc))
+        return jac.raw, (sc.raw if has.value else None), self.b.names()

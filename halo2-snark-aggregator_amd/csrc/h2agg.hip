@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "msm_kernels.cuh"
+#include "schema.cuh"
 
 using namespace h2agg;
 
@@ -775,3 +776,5 @@ int h2agg_profile_stage_get(h2agg_ctx* c, int i, double* total_ms, uint64_t* lau
 }
 
 }  // extern "C"
+
+#include "schema_api.inc"

@@ -1,0 +1,290 @@
+// EvaluationQuerySchema on the GPU backend: host-side AST + symbolic eval_prepare, device-side Fr tape.
+//
+// Mirrors halo2-snark-aggregator-api/src/systems/halo2/evaluation.rs:
+//   enum EvaluationQuerySchema { Commitment, Eval, Scalar, Add, Mul }   :15-27   (+ has_commitment :30-38)
+//   impl Add / impl Mul (cache the children's has-commitment flags)      :62-84
+//   eval                                                                 :172-203
+//   eval_prepare                                                         :205-293
+//   estimate                                                             :295-330
+// and the tail of evaluate_multiopen_proof (verify.rs:705-731).
+//
+// The reference walks the tree calling schip.mul / schip.add (MockFieldChip = halo2curves Fr on one CPU
+// thread).  Here the host walks the same tree with the same control flow, but every schip call only
+// RECORDS an operation on a tape of Fr registers; the tape then runs on the device level by level (all
+// operations whose inputs are ready run in parallel), the resulting scalars are gathered straight into
+// the MSM's scalar buffer, and no field arithmetic happens on the host.  Key merging uses a hash index
+// instead of the reference's linear `find` (evaluation.rs:251) — same first-match semantics, since keys
+// are unique inside one result list.
+#pragma once
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "msm_kernels.cuh"
+
+namespace h2agg {
+
+// ------------------------------------------------------------------ device side: Fr tape
+enum : uint32_t { TAPE_MUL = 0, TAPE_ADD = 1, TAPE_SUB = 2 };
+struct TapeOp {
+    uint32_t dst, a, b, op;
+};
+constexpr int REG_WORDS = NL;  // a register = 9 limbs, Montgomery, value < 2r
+
+FP_INLINE Fr reg_load(const uint32_t* regs, uint32_t i) {
+    Fr r;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) r.l[k] = regs[(size_t)i * REG_WORDS + k];
+    return r;
+}
+FP_INLINE void reg_store(uint32_t* regs, uint32_t i, const Fr& v) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) regs[(size_t)i * REG_WORDS + k] = v.l[k];
+}
+// value < 4r -> < 2r
+FP_INLINE Fr fr_fold_2r(const Fr& a) {
+    int32_t x[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) x[i] = (int32_t)a.l[i] - (int32_t)km_limb<FrParams>(2, i);
+    Fr t = fp_normalize<FrParams>(x);
+    const bool neg = (int32_t)t.l[8] < 0;
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = neg ? a.l[i] : t.l[i];
+    return r;
+}
+
+// constants: canonical 32-byte integers -> Montgomery registers [0, n)
+__global__ void __launch_bounds__(BLOCK) k_tape_load_consts(const uint8_t* __restrict__ consts, uint32_t n,
+                                                            uint32_t* __restrict__ regs, uint32_t* flags) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    Fr x = fp_load<FrParams>(consts + 32 * (size_t)i);
+    if (!fp_is_canonical<FrParams>(x)) atomicOr(flags, FLAG_NONCANONICAL);
+    reg_store(regs, i, fp_to_mont<FrParams>(x));
+}
+// one dependency level of the tape: every op's inputs were produced by earlier levels
+// MockFieldChip::mul / add / sub  (mock/arith/field.rs:98-105, 39-55)
+__global__ void __launch_bounds__(BLOCK) k_tape_level(const TapeOp* __restrict__ ops, uint32_t n,
+                                                      uint32_t* __restrict__ regs) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    const TapeOp op = ops[i];
+    const Fr a = reg_load(regs, op.a), b = reg_load(regs, op.b);
+    Fr r;
+    if (op.op == TAPE_MUL) r = fp_mul<FrParams>(a, b);                       // 4/169 + 1 -> < 2r
+    else if (op.op == TAPE_ADD) r = fr_fold_2r(fp_add<FrParams>(a, b));     // < 4r -> < 2r
+    else r = fr_fold_2r(fp_sub<2, FrParams>(a, b));                         // a - b + 2r < 4r -> < 2r
+    reg_store(regs, op.dst, r);
+}
+// registers -> canonical 32-byte scalars (MSM scalar buffer / results)
+__global__ void __launch_bounds__(BLOCK) k_tape_gather(const uint32_t* __restrict__ regs,
+                                                       const uint32_t* __restrict__ idx, uint32_t n,
+                                                       uint8_t* __restrict__ out) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    fp_store<FrParams>(out + 32 * (size_t)i, fp_from_mont<FrParams>(reg_load(regs, idx[i])));
+}
+
+// ------------------------------------------------------------------ host side: AST + symbolic evaluation
+struct Tape {
+    std::vector<uint8_t> consts;   // 32 B each; register i < nconsts is constant i
+    std::vector<TapeOp> ops;       // op k writes register nconsts_final + k (fixed up at finalisation)
+    std::vector<uint32_t> level;   // per register
+    uint32_t nconst = 0;
+    // registers are numbered: constants first (ids 0..nconst-1 while recording are provisional: we
+    // record with a tag bit and resolve when the constant count is known)
+    static constexpr uint32_t OPBIT = 0x80000000u;
+    uint32_t add_const(const uint8_t v[32]) {
+        consts.insert(consts.end(), v, v + 32);
+        return nconst++;
+    }
+    uint32_t record(uint32_t opcode, uint32_t a, uint32_t b) {
+        TapeOp o{(uint32_t)ops.size() | OPBIT, a, b, opcode};
+        ops.push_back(o);
+        return o.dst;
+    }
+    uint32_t resolve(uint32_t r) const { return (r & OPBIT) ? nconst + (r & ~OPBIT) : r; }
+};
+
+struct SchemaNode {
+    enum Kind : uint8_t { COMMITMENT, EVAL, SCALAR, ADD, MUL } kind;
+    bool has_commitment;   // own flag (Add/Mul: l.1 || r.1), i.e. what a parent caches in its Box<(_, bool)>
+    uint32_t l = 0, r = 0; // children (ADD / MUL)
+    int32_t point = -1;    // COMMITMENT: index into Schema::points
+    uint32_t reg = 0;      // EVAL / SCALAR: tape constant
+    std::string key;       // COMMITMENT
+};
+
+struct PreparedEntry {
+    std::string key;
+    int32_t point;   // -1 = None
+    int64_t scalar;  // -1 = None, otherwise a tape register (possibly OPBIT-tagged)
+};
+struct Prepared {
+    std::vector<PreparedEntry> v;
+    std::unordered_map<std::string, uint32_t> index;  // key -> position of its first entry
+    bool indexed = false;
+    void build_index() {
+        if (indexed) return;
+        index.reserve(v.size() * 2 + 8);
+        for (uint32_t i = 0; i < v.size(); ++i) index.emplace(v[i].key, i);  // emplace keeps the FIRST match
+        indexed = true;
+    }
+};
+
+struct Schema {
+    std::vector<SchemaNode> nodes;
+    std::vector<uint8_t> points;  // 64 B canonical affine each
+    Tape tape;
+    uint32_t one_reg = 0;
+    bool has_one = false;
+    std::string err;
+
+    // results of the last eval (names: evaluation.rs:183)
+    std::vector<std::string> names;
+    size_t point_list_len = 0;     // what MockChipCtx::point_list.len() would be after multi_exp
+
+    uint32_t one() {
+        if (!has_one) {
+            uint8_t v[32] = {1};
+            one_reg = tape.add_const(v);
+            has_one = true;
+        }
+        return one_reg;
+    }
+    uint32_t add_commitment(const char* key, const uint8_t p[64]) {
+        SchemaNode n;
+        n.kind = SchemaNode::COMMITMENT;
+        n.has_commitment = true;
+        n.key = key;
+        n.point = (int32_t)(points.size() / 64);
+        points.insert(points.end(), p, p + 64);
+        nodes.push_back(std::move(n));
+        return (uint32_t)nodes.size() - 1;
+    }
+    uint32_t add_leaf_scalar(SchemaNode::Kind k, const uint8_t s[32]) {
+        SchemaNode n;
+        n.kind = k;
+        n.has_commitment = false;
+        n.reg = tape.add_const(s);
+        nodes.push_back(std::move(n));
+        return (uint32_t)nodes.size() - 1;
+    }
+    bool valid(uint32_t id) const { return id < nodes.size(); }
+    uint32_t add_binary(SchemaNode::Kind k, uint32_t l, uint32_t r) {
+        SchemaNode n;
+        n.kind = k;
+        n.l = l;
+        n.r = r;
+        n.has_commitment = nodes[l].has_commitment || nodes[r].has_commitment;  // evaluation.rs:35-36
+        nodes.push_back(std::move(n));
+        return (uint32_t)nodes.size() - 1;
+    }
+
+    // estimate (evaluation.rs:295-330)
+    size_t estimate(uint32_t id, bool scalar) const {
+        const SchemaNode& n = nodes[id];
+        switch (n.kind) {
+        case SchemaNode::COMMITMENT: return 1;
+        case SchemaNode::EVAL:
+        case SchemaNode::SCALAR: return scalar ? 1 : 0;
+        case SchemaNode::ADD:
+            if (!nodes[n.l].has_commitment && !nodes[n.r].has_commitment) {
+                size_t e = estimate(n.l, false) + estimate(n.r, false);
+                return scalar ? e + 1 : e;
+            }
+            return estimate(n.l, scalar) + estimate(n.r, scalar);
+        case SchemaNode::MUL:
+            return !nodes[n.l].has_commitment ? estimate(n.r, true) : estimate(n.l, true);
+        }
+        return 0;
+    }
+
+    // eval_prepare (evaluation.rs:205-293); `scalar` = -1 for None.  Returns false on the reference's
+    // assertion failures (err is set).
+    bool eval_prepare(uint32_t id, int64_t scalar, Prepared& out) {
+        const SchemaNode& n = nodes[id];
+        switch (n.kind) {
+        case SchemaNode::COMMITMENT:                                         // :216-218
+            out.v.push_back({n.key, n.point, scalar});
+            return true;
+        case SchemaNode::EVAL: {                                             // :219-225
+            int64_t e = scalar >= 0 ? (int64_t)tape.record(TAPE_MUL, (uint32_t)scalar, n.reg) : (int64_t)n.reg;
+            out.v.push_back({std::string(), -1, e});
+            return true;
+        }
+        case SchemaNode::SCALAR: {                                           // :226-232
+            int64_t s = scalar >= 0 ? (int64_t)tape.record(TAPE_MUL, n.reg, (uint32_t)scalar) : (int64_t)n.reg;
+            out.v.push_back({std::string(), -1, s});
+            return true;
+        }
+        case SchemaNode::ADD: {
+            const uint32_t l = n.l, r = n.r;  // copy: `nodes` is not modified below, but keep it simple
+            if (!nodes[l].has_commitment && !nodes[r].has_commitment) {      // :234-244
+                Prepared pl, pr;
+                if (!eval_prepare(l, -1, pl) || !eval_prepare(r, -1, pr)) return false;
+                if (pl.v.size() != 1 || pr.v.size() != 1) {
+                    err = "assert!(l.len() == 1 && r.len() == 1) failed (evaluation.rs:237-238)";
+                    return false;
+                }
+                int64_t sum = tape.record(TAPE_ADD, (uint32_t)pl.v[0].scalar, (uint32_t)pr.v[0].scalar);
+                if (scalar >= 0) sum = tape.record(TAPE_MUL, (uint32_t)scalar, (uint32_t)sum);
+                out.v.push_back({std::string(), -1, sum});
+                return true;
+            }
+            // :245-268  merge entries with equal key by adding their scalars (None == one)
+            Prepared res;
+            if (!eval_prepare(l, scalar, res)) return false;
+            Prepared rhs;
+            if (!eval_prepare(r, scalar, rhs)) return false;
+            // the left list itself may hold duplicate keys only if a child produced them; the reference
+            // pushes left entries through the same find-or-push loop, so do that too
+            Prepared merged;
+            merged.v.reserve(res.v.size() + rhs.v.size());
+            merged.index.reserve((res.v.size() + rhs.v.size()) * 2 + 8);
+            merged.indexed = true;
+            for (Prepared* side : {&res, &rhs}) {
+                for (PreparedEntry& ev : side->v) {
+                    auto it = merged.index.find(ev.key);
+                    if (it != merged.index.end()) {
+                        PreparedEntry& p = merged.v[it->second];
+                        const uint32_t a = p.scalar >= 0 ? (uint32_t)p.scalar : one();
+                        const uint32_t b = ev.scalar >= 0 ? (uint32_t)ev.scalar : one();
+                        p.scalar = tape.record(TAPE_ADD, a, b);
+                    } else {
+                        merged.index.emplace(ev.key, (uint32_t)merged.v.size());
+                        merged.v.push_back(std::move(ev));
+                    }
+                }
+            }
+            out = std::move(merged);
+            return true;
+        }
+        case SchemaNode::MUL: {                                              // :271-291
+            const uint32_t l = n.l, r = n.r;
+            Prepared s;
+            uint32_t rem;
+            if (!nodes[l].has_commitment) {
+                if (!eval_prepare(l, -1, s)) return false;
+                rem = r;
+            } else {
+                if (!eval_prepare(r, -1, s)) return false;
+                rem = l;
+            }
+            if (s.v.size() != 1) {
+                err = "assert_eq!(s.len(), 1) failed (evaluation.rs:282)";
+                return false;
+            }
+            int64_t sv = s.v[0].scalar;
+            if (scalar >= 0) sv = tape.record(TAPE_MUL, (uint32_t)scalar, (uint32_t)sv);
+            return eval_prepare(rem, sv, out);
+        }
+        }
+        return false;
+    }
+};
+
+}  // namespace h2agg

@@ -134,6 +134,39 @@ int h2agg_g1_msm_device(h2agg_ctx* ctx, uint64_t bases_handle, const void* d_sca
 int h2agg_g1_msm_device_async(h2agg_ctx* ctx, uint64_t bases_handle, const void* d_scalars, size_t n,
                               void* d_out_jac);
 
+/* ---- EvaluationQuerySchema (the entry point of the hot path) ---------------------------------------
+ * replaces: the AST of halo2-snark-aggregator-api/src/systems/halo2/evaluation.rs:15-27 and its
+ * constructors `commit!` / `eval!` / `scalar!` (:41-60), `impl Add` / `impl Mul` (:62-84), `estimate`
+ * (:295-330) and `eval` (:172-203, with eval_prepare :205-293).  A schema object is an arena of nodes
+ * bound to one context; node ids are indices into it.  The host walks the tree exactly as eval_prepare
+ * does but only records the schip.mul / schip.add calls on a tape; the tape runs on the GPU, its
+ * results feed the multi_exp directly.  Keys are NUL-terminated strings (the reference's `String` keys). */
+typedef struct h2agg_schema h2agg_schema;
+int h2agg_schema_create(h2agg_ctx* ctx, h2agg_schema** out);
+void h2agg_schema_destroy(h2agg_schema* s);
+int h2agg_schema_node_commitment(h2agg_schema* s, const char* key, const uint8_t point_aff[64], uint32_t* node_out);
+int h2agg_schema_node_eval(h2agg_schema* s, const uint8_t eval[32], uint32_t* node_out);     /* eval!(cq)   */
+int h2agg_schema_node_scalar(h2agg_schema* s, const uint8_t scalar[32], uint32_t* node_out); /* scalar!(s)  */
+int h2agg_schema_node_add(h2agg_schema* s, uint32_t l, uint32_t r, uint32_t* node_out);      /* l + r       */
+int h2agg_schema_node_mul(h2agg_schema* s, uint32_t l, uint32_t r, uint32_t* node_out);      /* l * r       */
+int h2agg_schema_estimate(h2agg_schema* s, uint32_t node, size_t* out);                      /* estimate(None) */
+/* eval(): out_jac = multi_exp(points with scalars) + sum(points without); *has_scalar / out_scalar = the
+ * accumulated pure-scalar term (key ""), None -> *has_scalar = 0.  A Mul whose both sides hold
+ * commitments, or an Add of non-singleton scalar sides, fails with H2AGG_ERR_INVALID (the reference's
+ * assert!, evaluation.rs:237-238,282); no scalar-carrying commitment -> H2AGG_ERR_EMPTY (its panic). */
+int h2agg_schema_eval(h2agg_schema* s, uint32_t node, uint8_t out_jac[96], int* has_scalar, uint8_t out_scalar[32]);
+/* replaces: evaluate_multiopen_proof without the print-only pairing
+ * (halo2-snark-aggregator-api/src/systems/halo2/verify.rs:705-731): left = eval(w_x) + e_x*G,
+ * right = eval(w_g) - e_g*G, both `to_value`d; output order = verify_circuit_final_pair.data
+ * (halo2-snark-aggregator-circuit/src/fs.rs:187-190). */
+int h2agg_evaluate_multiopen_proof(h2agg_schema* s, uint32_t w_x, uint32_t w_g, uint8_t left_aff[64],
+                                   uint8_t right_aff[64]);
+/* names returned by the last eval (evaluation.rs:183) / points_wx ++ points_wg (verify.rs:711-712), and the
+ * length MockChipCtx::point_list would have after the last multi_exp (mock/arith/ecc.rs:112-116). */
+size_t h2agg_schema_name_count(h2agg_schema* s);
+const char* h2agg_schema_name(h2agg_schema* s, size_t i);
+size_t h2agg_schema_point_list_len(h2agg_schema* s);
+
 /* ---- tuning / measurement -------------------------------------------------------------------------
  * window_bits: Pippenger window c in [2, 16], 0 = choose from n.  Other knobs: 0 = default. */
 int h2agg_msm_configure(h2agg_ctx* ctx, int window_bits, int reduce_segment, int big_bucket_threshold);
