@@ -1,0 +1,111 @@
+"""Sharded aggregation of N proofs across ranks (one process per GPU).
+
+The reference folds all proofs into one schema and evaluates it on one CPU thread
+(verify_aggregation_proofs_in_chip, halo2-snark-aggregator-api/src/systems/halo2/verify.rs:835-942).  The
+fold is linear: (W_x, W_g) = sum_i lambda^(N-1-i) * (W_x_i, W_g_i), so the proofs shard across ranks:
+
+    rank r takes proofs r, r+G, r+2G, ...            (round-robin, no data-path collective)
+    builds its local schema  sum_j lambda^(N-1-i_j) * proof_{i_j}   (powers of lambda are schema nodes:
+        they are evaluated on the device tape, the host does no field arithmetic)
+    evaluates it on its GPU -> partial (left, right) affine points (e*G terms included: linear too)
+    ONE all-gather of 2 x 64 bytes per rank, then every rank sums the G partials locally.
+
+RCCL has no reduction over group elements (ncclRedOp_t is sum/prod/min/max on numeric dtypes), so
+BASELINE.json's "all-reduce of (W_x, W_e)" is an all-gather + local EC adds.
+
+`backend` is duck-typed so the distributed logic can be tested on CPU with gloo (tests inject an
+oracle-backed backend); the product backend is `GpuBackend` below and has no fallback.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+from .multiopen import MultiOpenProof
+
+IDENTITY_AFF = bytes(64)
+
+
+def shard_indices(n: int, world: int, rank: int) -> List[int]:
+    return list(range(rank, n, world))
+
+
+def lambda_power(b, lam: bytes, e: int):
+    """lambda^e as a schema node (e >= 1), square-and-multiply over Scalar nodes (Mul of two
+    commitment-free sides is a scalar product in eval_prepare, evaluation.rs:271-291)."""
+    assert e >= 1
+    result = None
+    base = b.scalar(lam)
+    while e:
+        if e & 1:
+            result = base if result is None else result * base
+        e >>= 1
+        if e:
+            base = base * base
+    return result
+
+
+def local_weighted_proof(b, proofs: Sequence[MultiOpenProof], indices: Sequence[int], n_total: int,
+                         lam: bytes) -> Optional[MultiOpenProof]:
+    """sum_j lambda^(N-1-i_j) * proofs[j] for this rank's (ascending) global indices."""
+    acc = None
+    for j, (p, i) in enumerate(zip(proofs, indices)):
+        if acc is None:
+            acc = p
+        else:
+            gap = i - indices[j - 1]
+            lg = lambda_power(b, lam, gap)
+            acc = MultiOpenProof(acc.w_x * lg + p.w_x, acc.w_g * lg + p.w_g)
+    if acc is None:
+        return None
+    tail = n_total - 1 - indices[-1]
+    if tail > 0:
+        lt = lambda_power(b, lam, tail)
+        acc = MultiOpenProof(acc.w_x * lt, acc.w_g * lt)
+    return acc
+
+
+class GpuBackend:
+    """Product backend: everything runs through libh2agg.so."""
+
+    def __init__(self, pkg, eng):
+        self.pkg, self.eng = pkg, eng
+        self.CommitQuery = pkg.CommitQuery
+
+    def new_builder(self):
+        return self.pkg.SchemaBuilder(self.eng)
+
+    def evaluate(self, b, proof: MultiOpenProof):
+        left, right, _names = b.evaluate_multiopen_proof(proof.w_x, proof.w_g)
+        return left, right
+
+    def sum_affine(self, pts: Sequence[bytes]) -> bytes:
+        one = (1).to_bytes(32, "little")
+        jac = b"".join((p + one) if p != IDENTITY_AFF else (bytes(32) + one + bytes(32)) for p in pts)
+        return self.eng.g1_batch_to_affine(self.eng.g1_sum(jac))
+
+
+def aggregate_sharded(backend, build_local_proofs, n_total: int, lam: bytes, dist=None, device=None):
+    """Returns the final pair (left_aff, right_aff), identical on every rank.
+
+    build_local_proofs(builder, indices) -> list of MultiOpenProof for those global proof indices.
+    dist: torch.distributed (initialised) or None for a single process."""
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    idx = shard_indices(n_total, world, rank)
+    b = backend.new_builder()
+    proofs = build_local_proofs(b, idx)
+    local = local_weighted_proof(b, proofs, idx, n_total, lam)
+    if local is None:
+        left, right = IDENTITY_AFF, IDENTITY_AFF
+    else:
+        left, right = backend.evaluate(b, local)
+    if dist is None:
+        return left, right
+    import torch
+    mine = torch.frombuffer(bytearray(left + right), dtype=torch.uint8)
+    if device is not None:
+        mine = mine.to(device)
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)                                   # the only collective: 128 B per rank
+    parts = [bytes(g.cpu().numpy().tobytes()) for g in gathered]
+    return (backend.sum_affine([p[:64] for p in parts]), backend.sum_affine([p[64:] for p in parts]))

@@ -1,0 +1,148 @@
+"""CPU, world_size 2, gloo: the N>1 host path (proof sharding, lambda weighting, all-gather, local fold).
+
+The compute backend injected here is oracle-backed (tests may use the oracle as the checker); the
+product backend (aggregate.GpuBackend) is exercised on the GPU box in tests/test_gpu_aggregate.py."""
+import os
+import sys
+
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class OracleBackend:
+    def __init__(self):
+        from oracle import bn254 as O, schema as S
+        self.O, self.S = O, S
+        outer = self
+
+        class CQ:
+            def __init__(self, key, commitment=None, eval=None):
+                self.key, self.commitment, self.eval = key, commitment, eval
+        self.CommitQuery = CQ
+
+        class Builder:
+            def commit(self, cq):
+                return S.commit(S.CommitQuery(cq.key, O.aff_from_bytes(cq.commitment), None))
+
+            def evalq(self, cq):
+                return S.evalq(S.CommitQuery("", None, O.fe_from_bytes(cq.eval)))
+
+            def scalar(self, s):
+                return S.scalar(O.fe_from_bytes(s))
+        self._Builder = Builder
+
+    def new_builder(self):
+        return self._Builder()
+
+    def evaluate(self, b, proof):
+        S, O = self.S, self.O
+        l, r, _ = S.evaluate_multiopen_proof(S.OracleCtx(), S.OracleFieldChip(), S.OracleEccChip(),
+                                             S.MultiOpenProof(proof.w_x, proof.w_g))
+        return O.aff_to_bytes(l), O.aff_to_bytes(r)
+
+    def sum_affine(self, pts):
+        O = self.O
+        acc = O.INF
+        for p in pts:
+            acc = O.add(acc, O.aff_from_bytes(p))
+        return O.aff_to_bytes(acc)
+
+
+def make_proofs(pkg_multiopen, backend, b, indices, n_total, seed=0xD157):
+    """deterministic synthetic proofs; proof i depends only on (seed, i) so every rank builds the same ones"""
+    from oracle import bn254 as O
+    from tests.golden.make_golden import synthetic_proof
+    out = []
+    for i in indices:
+        rng = O.SplitMix64(seed + 1000 * i)
+        sp = synthetic_proof(rng, "c_p%d" % i, 2, 2, 3, 2)
+        qs = []
+        for (rot, pt, s) in sp["queries"]:
+            qs.append(pkg_multiopen.EvaluationQuery(rot, O.fe_to_bytes(pt), _mirror(backend, b, s)))
+        out.append(pkg_multiopen.batch_multi_open_proofs(b, backend.CommitQuery, sp["key"], qs,
+                                                         [O.aff_to_bytes(w) for w in sp["w"]],
+                                                         O.fe_to_bytes(sp["v"]), O.fe_to_bytes(sp["u"])))
+    return out
+
+
+def _mirror(backend, b, s):
+    from oracle import bn254 as O
+    if s.kind == "commitment":
+        return b.commit(backend.CommitQuery(s.cq.key, O.aff_to_bytes(s.cq.commitment), None))
+    if s.kind == "eval":
+        return b.evalq(backend.CommitQuery("", None, O.fe_to_bytes(s.cq.eval)))
+    if s.kind == "scalar":
+        return b.scalar(O.fe_to_bytes(s.s))
+    l, r = _mirror(backend, b, s.l), _mirror(backend, b, s.r)
+    return l + r if s.kind == "add" else l * r
+
+
+def reference_final_pair(n_total, lam_int):
+    """single-process reference semantics: fold all proofs (verify.rs:926-938), evaluate once"""
+    from oracle import bn254 as O, schema as S
+    from tests.golden.make_golden import synthetic_proof
+    proofs = []
+    for i in range(n_total):
+        rng = O.SplitMix64(0xD157 + 1000 * i)
+        sp = synthetic_proof(rng, "c_p%d" % i, 2, 2, 3, 2)
+        proofs.append(S.batch_multi_open_proofs(sp["key"], sp["queries"], sp["w"], sp["v"], sp["u"]))
+    agg = S.aggregate_fold(proofs, lam_int)
+    l, r, _ = S.evaluate_multiopen_proof(S.OracleCtx(), S.OracleFieldChip(), S.OracleEccChip(), agg)
+    return S.final_pair_bytes(l, r)
+
+
+def _worker(rank, world, port, n_total, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+    entry.load_package()
+    import importlib
+    agg = importlib.import_module(entry.PKG_NAME + ".aggregate")
+    mo = importlib.import_module(entry.PKG_NAME + ".multiopen")
+    from oracle import bn254 as O
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        backend = OracleBackend()
+        lam = 0x1234567890ABCDEF1234567890ABCDEF % O.R
+        left, right = agg.aggregate_sharded(
+            backend, lambda b, idx: make_proofs(mo, backend, b, idx, n_total), n_total, O.fe_to_bytes(lam), dist=dist)
+        q.put((rank, (left + right).hex()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_total", [5, 1])
+def test_sharded_aggregation_world2_gloo(n_total):
+    from oracle import bn254 as O
+    world, port = 2, 29500 + (os.getpid() % 2000)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port + n_total, n_total, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    lam = 0x1234567890ABCDEF1234567890ABCDEF % O.R
+    want = reference_final_pair(n_total, lam).hex()
+    assert res[0] == want and res[1] == want          # identical on every rank, equal to the unsharded fold
+
+
+def test_shard_and_lambda_helpers():
+    import importlib
+    import __graft_entry__ as entry
+    entry.load_package()
+    agg = importlib.import_module(entry.PKG_NAME + ".aggregate")
+    assert agg.shard_indices(10, 4, 1) == [1, 5, 9] and agg.shard_indices(2, 4, 3) == []
+    from oracle import bn254 as O, schema as S
+    backend = OracleBackend()
+    b = backend.new_builder()
+    lam = 987654321987654321
+    for e in (1, 2, 3, 7, 8, 13):
+        node = agg.lambda_power(b, O.fe_to_bytes(lam), e)
+        out = node.eval_prepare(S.OracleCtx(), S.OracleFieldChip(), 1, None)
+        assert len(out) == 1 and out[0][2] == pow(lam, e, O.R)
