@@ -131,6 +131,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--log2n", type=int, default=20)
     ap.add_argument("--window", type=int, default=0)
+    ap.add_argument("--seg", type=int, default=0)
+    ap.add_argument("--sub-bits", type=int, default=0)
+    ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--cpu-sample", type=int, default=1 << 16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the Horner tail in-stream (latency mode)")
@@ -158,8 +161,10 @@ def main():
     eng = pkg.H2Agg(local_rank)
     stream = torch.cuda.current_stream(dev)
     eng.set_stream(stream.cuda_stream)
-    if args.window:
-        eng.msm_configure(window_bits=args.window)
+    if args.window or args.seg:
+        eng.msm_configure(window_bits=args.window, reduce_segment=args.seg)
+    if args.sub_bits or args.tile:
+        eng.msm_configure_sort(args.sub_bits, args.tile)
     if not args.no_overlap:
         eng.msm_set_tail_overlap(True)   # serial Horner tail of MSM k runs under the bulk of MSM k+1
 

@@ -58,7 +58,7 @@ struct h2agg_ctx {
     uint64_t next_handle = 1;
 
     // tuning
-    int cfg_c = 0, cfg_seg = 0, cfg_big = 0;
+    int cfg_c = 0, cfg_seg = 0, cfg_big = 0, cfg_sub_bits = 0, cfg_tile = 0;
 
     // optional overlap of the serial tail (k_msm_final) of MSM k with the bulk of MSM k+1
     bool tail_overlap = false;
@@ -151,7 +151,7 @@ MsmPlan make_plan(const h2agg_ctx* c, size_t n) {
     p.W = (255 + p.c - 1) / p.c;
     p.NB = 1u << (p.c - 1);
     p.NBT = (uint32_t)p.W * p.NB;
-    uint32_t seg = c->cfg_seg ? (uint32_t)c->cfg_seg : 16u;
+    uint32_t seg = c->cfg_seg ? (uint32_t)c->cfg_seg : 8u;
     if (seg > p.NB) seg = p.NB;
     p.seg = seg;
     p.spw = p.NB / seg;
@@ -224,11 +224,12 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     const size_t nent = n * (size_t)p.W;
     if (nent >= ((size_t)1 << 32)) return fail(c, H2AGG_ERR_INVALID, "n * windows must be < 2^32");
     SortPlan sp;
-    sp.sub_bits = (p.c - 1 < SORT_SUB_BITS) ? p.c - 1 : SORT_SUB_BITS;
+    const int want_sub = c->cfg_sub_bits ? c->cfg_sub_bits : SORT_SUB_BITS;
+    sp.sub_bits = (p.c - 1 < want_sub) ? p.c - 1 : want_sub;
     sp.SB = 1u << sp.sub_bits;
     sp.ppw = p.NB >> sp.sub_bits;
     sp.PW = (uint32_t)p.W * sp.ppw;
-    sp.tile = 2048;
+    sp.tile = c->cfg_tile ? (uint32_t)c->cfg_tile : 2048u;
     if (sp.PW > (uint32_t)SORT_MAX_PW) return fail(c, H2AGG_ERR_INVALID, "too many sort partitions");
     const uint32_t nseg_total = (uint32_t)p.W * p.spw;
     // pmeta words: [0,PW] pcount | [2048, +PW+1] pstart | [4096, +PW] pcursor | [6144,+1024] bin_count |
@@ -733,6 +734,16 @@ int h2agg_msm_configure(h2agg_ctx* c, int window_bits, int reduce_segment, int b
     c->cfg_c = window_bits;
     c->cfg_seg = reduce_segment;
     c->cfg_big = big_bucket_threshold;
+    return H2AGG_OK;
+}
+
+int h2agg_msm_configure_sort(h2agg_ctx* c, int sub_bits, int tile) {
+    if (!c) return H2AGG_ERR_INVALID;
+    if (sub_bits != 0 && (sub_bits < 4 || sub_bits > SORT_MAX_SUB_BITS))
+        return fail(c, H2AGG_ERR_INVALID, "sub_bits must be 0 or in [4, 12]");
+    if (tile != 0 && (tile < BLOCK || tile > (1 << 16))) return fail(c, H2AGG_ERR_INVALID, "tile must be 0 or in [256, 65536]");
+    c->cfg_sub_bits = sub_bits;
+    c->cfg_tile = tile;
     return H2AGG_OK;
 }
 

@@ -21,8 +21,9 @@
 namespace h2agg {
 
 constexpr int SORT_MAX_PW = 1024;   // partitions (LDS counters in level 1)
-constexpr int SORT_SUB_BITS = 9;    // low bucket bits resolved in level 2
-constexpr int SORT_MAX_SB = 1 << SORT_SUB_BITS;
+constexpr int SORT_SUB_BITS = 9;    // default low bucket bits resolved in level 2 (tunable, <= 12; sweep: profiles/r01_sweeps.txt)
+constexpr int SORT_MAX_SUB_BITS = 12;
+constexpr int SORT_MAX_SB = 1 << SORT_MAX_SUB_BITS;
 constexpr int SIZE_BINS = 1024;     // bucket-length bins of the ordering pass
 
 struct SortPlan {
@@ -166,10 +167,13 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_sort(const uint32_t* __restric
     __syncthreads();
     for (uint32_t k = start + tid; k < end; k += BLOCK) atomicAdd(&h[item_sub[k]], 1u);
     __syncthreads();
-    // exclusive scan of h[0..SB) with 2 entries per thread (SB <= 512)
-    const uint32_t a0 = (2u * tid < sp.SB) ? h[2 * tid] : 0u;
-    const uint32_t a1 = (2u * tid + 1u < sp.SB) ? h[2 * tid + 1] : 0u;
-    scan[tid] = a0 + a1;
+    // exclusive scan of h[0..SB): each thread owns `per` consecutive counters
+    const uint32_t per = (sp.SB + BLOCK - 1) / BLOCK;
+    const uint32_t lo = tid * per;
+    uint32_t mine = 0;
+    for (uint32_t j = 0; j < per; ++j)
+        if (lo + j < sp.SB) mine += h[lo + j];
+    scan[tid] = mine;
     __syncthreads();
 #pragma unroll 1
     for (int d = 1; d < BLOCK; d <<= 1) {
@@ -178,18 +182,18 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_sort(const uint32_t* __restric
         scan[tid] += t;
         __syncthreads();
     }
-    const uint32_t e0 = scan[tid] - (a0 + a1), e1 = e0 + a0;
+    uint32_t run = scan[tid] - mine;
     const uint32_t w = p / sp.ppw, phi = p - w * sp.ppw;
     const uint32_t key0 = w * NB + (phi << sp.sub_bits);
-    if (2u * tid < sp.SB) {
-        hist[key0 + 2 * tid] = a0;
-        offs[key0 + 2 * tid] = start + e0;
-        h[2 * tid] = e0;
-    }
-    if (2u * tid + 1u < sp.SB) {
-        hist[key0 + 2 * tid + 1] = a1;
-        offs[key0 + 2 * tid + 1] = start + e1;
-        h[2 * tid + 1] = e1;
+    for (uint32_t j = 0; j < per; ++j) {
+        const uint32_t sidx = lo + j;
+        if (sidx < sp.SB) {
+            const uint32_t cnt = h[sidx];
+            hist[key0 + sidx] = cnt;
+            offs[key0 + sidx] = start + run;
+            h[sidx] = run;  // becomes the cursor
+            run += cnt;
+        }
     }
     __syncthreads();
     for (uint32_t k = start + tid; k < end; k += BLOCK) {

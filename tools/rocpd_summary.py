@@ -23,15 +23,21 @@ def main(path):
         print("%-58s %7d %12.1f %12.2f %10.2f %10.2f %6.2f" % (short, calls, tot / 1e3, avg / 1e3, mn / 1e3, mx / 1e3,
                                                                100.0 * tot / total))
     try:
+        # several rows per (dispatch, counter): one per hardware instance (XCD / SE) -> sum them per dispatch
         pmc = cur.execute(
-            "select k.%s, p.counter_name, count(*), avg(p.value), sum(p.value) from pmc_events p "
-            "join kernels k on k.dispatch_id = p.dispatch_id group by 1, 2 order by 1, 2" % name_col).fetchall()
+            "select name, counter_name, count(*), avg(v), avg(d) from ("
+            " select name, counter_name, dispatch_id, sum(counter_value) as v, max(duration) as d"
+            " from pmc_events group by name, counter_name, dispatch_id) group by name, counter_name"
+            " order by name, counter_name").fetchall()
     except sqlite3.Error:
         pmc = []
     if pmc:
-        print("\n# PMC counters (per-dispatch average, sum over dispatches)")
-        for name, ctr, cnt, avg, tot in pmc:
-            print("%-58s %-24s n=%-5d avg=%-16.1f sum=%.1f" % (name.split("(")[0][-58:], ctr, cnt, avg, tot))
+        print("\n# PMC counters: per-dispatch value (summed over hardware instances), averaged over dispatches")
+        print("%-40s %-22s %6s %18s %12s" % ("kernel", "counter", "n", "avg_value", "avg_dur_us"))
+        for name, ctr, cnt, avg, dur in pmc:
+            if name.startswith("__amd") or "at::native" in name:
+                continue
+            print("%-40s %-22s %6d %18.1f %12.2f" % (name.split("(")[0][-40:], ctr, cnt, avg, (dur or 0) / 1e3))
 
 
 if __name__ == "__main__":
