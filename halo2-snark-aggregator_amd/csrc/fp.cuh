@@ -186,6 +186,52 @@ FP_INLINE Fp<P> fp_mul(const Fp<P>& a, const Fp<P>& b) {
     return fp_mont_reduce<P>(acc);
 }
 
+// (a*b + c*d) / 2^261 mod m with ONE Montgomery reduction (27 products of < 2^58 per column still fit
+// 64 bits).  Output bound: (A*B + C*D)/169 + 1.
+template <class P>
+FP_INLINE Fp<P> fp_mul2(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>& d) {
+    uint64_t acc[18];
+#pragma unroll
+    for (int k = 0; k < 18; ++k) acc[k] = 0;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) acc[i + j] += (uint64_t)a.l[i] * b.l[j];
+    }
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+#pragma unroll
+        for (int j = 0; j < NL; ++j) acc[i + j] += (uint64_t)c.l[i] * d.l[j];
+    }
+    return fp_mont_reduce<P>(acc);
+}
+
+// a - b - 2c + K*m in one carry sweep.  REQUIRES value(b) + 2*value(c) <= K*m.  bound: A + K.
+template <int K, class P>
+FP_INLINE Fp<P> fp_sub_sub2(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c) {
+    int32_t x[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i)
+        x[i] = (int32_t)(a.l[i] + km_limb<P>(K, i)) - (int32_t)b.l[i] - (int32_t)(c.l[i] << 1);
+    return fp_normalize<P>(x);
+}
+// a - 2b + K*m.  REQUIRES 2*value(b) <= K*m.  bound: A + K.
+template <int K, class P>
+FP_INLINE Fp<P> fp_sub2(const Fp<P>& a, const Fp<P>& b) {
+    int32_t x[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) x[i] = (int32_t)(a.l[i] + km_limb<P>(K, i)) - (int32_t)(b.l[i] << 1);
+    return fp_normalize<P>(x);
+}
+// 3a.  bound: 3A.
+template <class P>
+FP_INLINE Fp<P> fp_triple(const Fp<P>& a) {
+    int32_t x[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) x[i] = (int32_t)(a.l[i] * 3u);
+    return fp_normalize<P>(x);
+}
+
 // a*a / 2^261 mod m: 45 products instead of 81.  Bound as fp_mul.
 template <class P>
 FP_INLINE Fp<P> fp_sqr(const Fp<P>& a) {
@@ -228,10 +274,10 @@ FP_INLINE Fp<P> fp_canonical(const Fp<P>& a) {
 // low limbs of 0, m, ..., (K-1)*m.
 template <int K, class P>
 FP_INLINE bool fp_maybe_zero_mod(const Fp<P>& a) {
-    bool hit = false;
-#pragma unroll
-    for (int k = 0; k < K; ++k) hit |= (a.l[0] == km_limb<P>(k, 0));
-    return hit;
+    // a = k*m with 0 <= k < K  =>  a.l[0] = k*m_0 mod 2^29  =>  k = a.l[0] * m_0^-1 mod 2^29, and
+    // m_0^-1 = 2^29 - NINV.  One multiply instead of K compares; never misses a multiple.
+    const uint32_t k = (a.l[0] * ((1u << 29) - P::NINV)) & M29;
+    return k < (uint32_t)K;
 }
 // exact test a == 0 (mod m), value(a) < K*m
 template <int K, class P>

@@ -71,10 +71,10 @@ FP_INLINE void xyzz_double_core(const Fq& x, const Fq& y, Fq& x3, Fq& y3, Fq& v,
     w = FQ_MUL(u, v);                                   // 16  -> [2]
     Fq s = FQ_MUL(x, v);                                // 16  -> [2]
     Fq xx = FQ_SQR(x);                                  // 64  -> [2]
-    Fq m = FQ_ADD(FQ_DBL(xx), xx);                      // [6]
-    x3 = FQ_SUB(4, FQ_SQR(m), FQ_DBL(s));               // 36 -> [2]; 2S [4]  -> [6]
-    y3 = FQ_SUB(2, FQ_MUL(m, FQ_SUB(6, s, x3)),         // S - X3 + 6p [8]; 6*8 = 48 -> [2]
-                FQ_MUL(w, y));                          // 2*4 -> [2]        -> [4]
+    Fq m = fp_triple<FqParams>(xx);                     // [6]
+    x3 = fp_sub2<4, FqParams>(FQ_SQR(m), s);            // 36 -> [2]; 2S [4]  -> [6]
+    // M*(S - X3) - W*Y as ONE reduction: M*(S - X3 + 6p) + W*(4p - Y):  (6*8 + 2*4)/169 + 1 -> [2]
+    y3 = fp_mul2<FqParams>(m, FQ_SUB(6, s, x3), w, fp_neg<4, FqParams>(y));
 }
 
 // 2 * (affine point), mdbl-2008-s-1.  p must not be the identity; y = 0 cannot occur on a prime-order curve.
@@ -122,8 +122,9 @@ FP_INLINE void xyzz_add_affine(G1XYZZ& acc, const G1Affine& q) {
     Fq pp = FQ_SQR(p);                                  // 100 -> [2]
     Fq ppp = FQ_MUL(p, pp);                             // 20  -> [2]
     Fq qq = FQ_MUL(acc.x, pp);                          // 16  -> [2]
-    Fq x3 = FQ_SUB(6, FQ_SQR(r), FQ_ADD(ppp, FQ_DBL(qq)));           // 36 -> [2]; PPP + 2Q [6] -> [8]
-    Fq y3 = FQ_SUB(2, FQ_MUL(r, FQ_SUB(8, qq, x3)), FQ_MUL(acc.y, ppp));  // [10]: 60 -> [2]; 8 -> [2] -> [4]
+    Fq x3 = fp_sub_sub2<6, FqParams>(FQ_SQR(r), ppp, qq);           // 36 -> [2]; PPP + 2Q [6] -> [8]
+    // R*(Q - X3) - Y1*PPP as ONE reduction: R*(Q - X3 + 8p) + (4p - Y1)*PPP: (6*10 + 4*2)/169 + 1 -> [2]
+    Fq y3 = fp_mul2<FqParams>(r, FQ_SUB(8, qq, x3), fp_neg<4, FqParams>(acc.y), ppp);
     acc.x = x3;
     acc.y = y3;
     acc.zz = FQ_MUL(acc.zz, pp);                        // [2]
@@ -150,8 +151,9 @@ FP_INLINE G1XYZZ xyzz_add(const G1XYZZ& a, const G1XYZZ& b) {
     Fq pp = FQ_SQR(p);                                  // 16 -> [2]
     Fq ppp = FQ_MUL(p, pp);                             // [2]
     Fq q = FQ_MUL(u1, pp);                              // [2]
-    o.x = FQ_SUB(6, FQ_SQR(r), FQ_ADD(ppp, FQ_DBL(q)));                  // [8]
-    o.y = FQ_SUB(2, FQ_MUL(r, FQ_SUB(8, q, o.x)), FQ_MUL(s1, ppp));      // 4*10 -> [2] -> [4]
+    o.x = fp_sub_sub2<6, FqParams>(FQ_SQR(r), ppp, q);                   // [8]
+    // R*(Q - X3 + 8p) + (2p - S1)*PPP: (4*10 + 2*2)/169 + 1 -> [2]
+    o.y = fp_mul2<FqParams>(r, FQ_SUB(8, q, o.x), fp_neg<2, FqParams>(s1), ppp);
     o.zz = FQ_MUL(FQ_MUL(a.zz, b.zz), pp);              // [2]
     o.zzz = FQ_MUL(FQ_MUL(a.zzz, b.zzz), ppp);          // [2]
     return o;
