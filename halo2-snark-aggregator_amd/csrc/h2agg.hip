@@ -59,6 +59,7 @@ struct h2agg_ctx {
 
     // tuning
     int cfg_c = 0, cfg_seg = 0, cfg_big = 0, cfg_sub_bits = 0, cfg_tile = 0;
+    bool cfg_no_stage = false, cfg_stage_l1 = false, staged_attr_set = false;
 
     // optional overlap of the serial tail (k_msm_final) of MSM k with the bulk of MSM k+1
     bool tail_overlap = false;
@@ -226,10 +227,19 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     SortPlan sp;
     const int want_sub = c->cfg_sub_bits ? c->cfg_sub_bits : SORT_SUB_BITS;
     sp.sub_bits = (p.c - 1 < want_sub) ? p.c - 1 : want_sub;
+    while (((uint32_t)p.W * (p.NB >> sp.sub_bits)) > (uint32_t)SORT_MAX_PW && sp.sub_bits < p.c - 1 &&
+           sp.sub_bits < SORT_MAX_SUB_BITS)
+        ++sp.sub_bits;  // keep the level-1 partition count within its LDS counters
     sp.SB = 1u << sp.sub_bits;
     sp.ppw = p.NB >> sp.sub_bits;
     sp.PW = (uint32_t)p.W * sp.ppw;
     sp.tile = c->cfg_tile ? (uint32_t)c->cfg_tile : 2048u;
+    // packed-item staged path: index field of 31 - sub_bits bits, a tile's keys must fit the LDS stage
+    const int idx_bits = 31 - sp.sub_bits;
+    bool staged = !c->cfg_no_stage && n <= ((size_t)1 << idx_bits);
+    if (staged && c->cfg_stage_l1 && (size_t)sp.tile * p.W > (size_t)STAGE_ITEMS)
+        sp.tile = (uint32_t)(STAGE_ITEMS / p.W);
+    if (staged && sp.tile < (uint32_t)BLOCK) staged = false;
     if (sp.PW > (uint32_t)SORT_MAX_PW) return fail(c, H2AGG_ERR_INVALID, "too many sort partitions");
     const uint32_t nseg_total = (uint32_t)p.W * p.spw;
     // pmeta words: [0,PW] pcount | [2048, +PW+1] pstart | [4096, +PW] pcursor | [6144,+1024] bin_count |
@@ -272,15 +282,42 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
                            c->d_flags);
         hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(BLOCK), 0, st, pcount, sp.PW, pstart, pcursor);
     }
-    {
-        StageTimer t(c, ST_PART_SCATTER);
-        hipLaunchKernelGGL(k_part_scatter, dim3(ntiles), dim3(BLOCK), 0, st, d_scalars, n, p.c, p.W, sp, pcursor,
-                           item_idx, item_sub);
-    }
-    {
-        StageTimer t(c, ST_BUCKET_SORT);
-        hipLaunchKernelGGL(k_bucket_sort, dim3(sp.PW), dim3(BLOCK), 0, st, pstart, item_idx, item_sub, sp, p.NB, hist,
-                           offs, entries);
+    if (staged) {
+        // LDS-staged sort: keys leave the CU as contiguous runs (n fits the packed item's index field)
+        const size_t lds1 = (size_t)(4 * SORT_MAX_PW + STAGE_ITEMS) * 4;
+        const size_t lds2 = (size_t)(SORT_MAX_SB + BLOCK + STAGE_ITEMS) * 4;
+        if (!c->staged_attr_set) {
+            HIP_TRY(c, hipFuncSetAttribute((const void*)k_part_scatter_staged,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
+            HIP_TRY(c, hipFuncSetAttribute((const void*)k_bucket_sort_staged,
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
+            c->staged_attr_set = true;
+        }
+        {
+            StageTimer t(c, ST_PART_SCATTER);
+            if (c->cfg_stage_l1)
+                hipLaunchKernelGGL(k_part_scatter_staged, dim3(ntiles), dim3(BLOCK), lds1, st, d_scalars, n, p.c, p.W,
+                                   sp, idx_bits, pcursor, item_idx);
+            else
+                hipLaunchKernelGGL(k_part_scatter_packed, dim3(ntiles), dim3(BLOCK), 0, st, d_scalars, n, p.c, p.W, sp,
+                                   idx_bits, pcursor, item_idx);
+        }
+        {
+            StageTimer t(c, ST_BUCKET_SORT);
+            hipLaunchKernelGGL(k_bucket_sort_staged, dim3(sp.PW), dim3(BLOCK), lds2, st, pstart, item_idx, sp, idx_bits,
+                               p.NB, hist, offs, entries);
+        }
+    } else {
+        {
+            StageTimer t(c, ST_PART_SCATTER);
+            hipLaunchKernelGGL(k_part_scatter, dim3(ntiles), dim3(BLOCK), 0, st, d_scalars, n, p.c, p.W, sp, pcursor,
+                               item_idx, item_sub);
+        }
+        {
+            StageTimer t(c, ST_BUCKET_SORT);
+            hipLaunchKernelGGL(k_bucket_sort, dim3(sp.PW), dim3(BLOCK), 0, st, pstart, item_idx, item_sub, sp, p.NB,
+                               hist, offs, entries);
+        }
     }
     {
         StageTimer t(c, ST_ORDER);
@@ -741,9 +778,12 @@ int h2agg_msm_configure_sort(h2agg_ctx* c, int sub_bits, int tile) {
     if (!c) return H2AGG_ERR_INVALID;
     if (sub_bits != 0 && (sub_bits < 4 || sub_bits > SORT_MAX_SUB_BITS))
         return fail(c, H2AGG_ERR_INVALID, "sub_bits must be 0 or in [4, 12]");
-    if (tile != 0 && (tile < BLOCK || tile > (1 << 16))) return fail(c, H2AGG_ERR_INVALID, "tile must be 0 or in [256, 65536]");
+    if (tile != 0 && tile != -1 && tile != -2 && (tile < BLOCK || tile > (1 << 16)))
+        return fail(c, H2AGG_ERR_INVALID, "tile must be 0, -1, -2 or in [256, 65536]");
     c->cfg_sub_bits = sub_bits;
-    c->cfg_tile = tile;
+    c->cfg_no_stage = tile == -1;   // -1: force the direct two-array sort kernels
+    c->cfg_stage_l1 = tile == -2;   // -2: also stage level 1 through LDS (experiment: slower, kept for tests)
+    c->cfg_tile = tile > 0 ? tile : 0;
     return H2AGG_OK;
 }
 

@@ -54,6 +54,28 @@ FP_INLINE void msm_for_each_digit(U256 s, int c, int W, F&& f) {
     }
 }
 
+// Walk this thread's scalars of the tile (index i, value s) with the NEXT scalar's two 16-byte loads already
+// in flight while the current one is recoded: the loop is otherwise one exposed memory latency per scalar.
+#define TILE_SCALARS_BEGIN(TID)                                                        \
+    {                                                                                  \
+        uint32_t k_ = (TID);                                                           \
+        size_t i = base + k_;                                                          \
+        bool live_ = k_ < sp.tile && i < n;                                            \
+        U256 nxt_;                                                                     \
+        if (live_) nxt_ = u256_load(scalars + 32 * i);                                 \
+        while (live_) {                                                                \
+            U256 s = nxt_;                                                             \
+            const uint32_t kn_ = k_ + BLOCK;                                           \
+            const size_t in_ = base + kn_;                                             \
+            const bool more_ = kn_ < sp.tile && in_ < n;                               \
+            if (more_) nxt_ = u256_load(scalars + 32 * in_);
+#define TILE_SCALARS_END                                                               \
+            k_ = kn_;                                                                  \
+            i = in_;                                                                   \
+            live_ = more_;                                                             \
+        }                                                                              \
+    }
+
 // ------------------------------------------------------------------ level 1
 __global__ void __launch_bounds__(BLOCK) k_part_count(const uint8_t* __restrict__ scalars, size_t n, int c, int W,
                                                       SortPlan sp, uint32_t* __restrict__ pcount, uint32_t* flags) {
@@ -62,15 +84,12 @@ __global__ void __launch_bounds__(BLOCK) k_part_count(const uint8_t* __restrict_
     __syncthreads();
     const size_t base = (size_t)blockIdx.x * sp.tile;
     uint32_t bad = 0;
-    for (uint32_t k = threadIdx.x; k < sp.tile; k += BLOCK) {
-        const size_t i = base + k;
-        if (i >= n) break;
-        U256 s = u256_load(scalars + 32 * i);
+    TILE_SCALARS_BEGIN(threadIdx.x)
         bad |= !u256_is_canonical_fr(s);
         msm_for_each_digit(s, c, W, [&](int w, uint32_t b, bool) {
             atomicAdd(&cnt[(uint32_t)w * sp.ppw + (b >> sp.sub_bits)], 1u);
         });
-    }
+    TILE_SCALARS_END
     if (bad) atomicOr(flags, FLAG_NONCANONICAL);
     __syncthreads();
     for (uint32_t p = threadIdx.x; p < sp.PW; p += BLOCK) {
@@ -123,14 +142,11 @@ __global__ void __launch_bounds__(BLOCK) k_part_scatter(const uint8_t* __restric
     for (uint32_t p = threadIdx.x; p < sp.PW; p += BLOCK) cnt[p] = 0;
     __syncthreads();
     const size_t base = (size_t)blockIdx.x * sp.tile;
-    for (uint32_t k = threadIdx.x; k < sp.tile; k += BLOCK) {
-        const size_t i = base + k;
-        if (i >= n) break;
-        U256 s = u256_load(scalars + 32 * i);
+    TILE_SCALARS_BEGIN(threadIdx.x)
         msm_for_each_digit(s, c, W, [&](int w, uint32_t b, bool) {
             atomicAdd(&cnt[(uint32_t)w * sp.ppw + (b >> sp.sub_bits)], 1u);
         });
-    }
+    TILE_SCALARS_END
     __syncthreads();
     for (uint32_t p = threadIdx.x; p < sp.PW; p += BLOCK) {
         const uint32_t v = cnt[p];
@@ -139,17 +155,14 @@ __global__ void __launch_bounds__(BLOCK) k_part_scatter(const uint8_t* __restric
     }
     __syncthreads();
     const uint32_t submask = sp.SB - 1u;
-    for (uint32_t k = threadIdx.x; k < sp.tile; k += BLOCK) {
-        const size_t i = base + k;
-        if (i >= n) break;
-        U256 s = u256_load(scalars + 32 * i);
+    TILE_SCALARS_BEGIN(threadIdx.x)
         msm_for_each_digit(s, c, W, [&](int w, uint32_t b, bool neg) {
             const uint32_t p = (uint32_t)w * sp.ppw + (b >> sp.sub_bits);
             const uint32_t pos = basep[p] + atomicAdd(&cnt[p], 1u);
             item_idx[pos] = (uint32_t)i | (neg ? 0x80000000u : 0u);
             item_sub[pos] = (uint16_t)(b & submask);
         });
-    }
+    TILE_SCALARS_END
 }
 
 // ------------------------------------------------------------------ level 2: one workgroup per partition
@@ -165,7 +178,14 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_sort(const uint32_t* __restric
     const int tid = threadIdx.x;
     for (uint32_t s = tid; s < sp.SB; s += BLOCK) h[s] = 0;
     __syncthreads();
-    for (uint32_t k = start + tid; k < end; k += BLOCK) atomicAdd(&h[item_sub[k]], 1u);
+    for (uint32_t k0 = start + tid; k0 < end; k0 += 8 * BLOCK) {  // 8 independent loads in flight
+        uint16_t sb[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sb[j] = (k0 + j * BLOCK < end) ? item_sub[k0 + j * BLOCK] : (uint16_t)0xffff;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (sb[j] != 0xffff) atomicAdd(&h[sb[j]], 1u);
+    }
     __syncthreads();
     // exclusive scan of h[0..SB): each thread owns `per` consecutive counters
     const uint32_t per = (sp.SB + BLOCK - 1) / BLOCK;
@@ -196,9 +216,204 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_sort(const uint32_t* __restric
         }
     }
     __syncthreads();
-    for (uint32_t k = start + tid; k < end; k += BLOCK) {
-        const uint32_t r = atomicAdd(&h[item_sub[k]], 1u);
-        entries[start + r] = item_idx[k];
+    for (uint32_t k0 = start + tid; k0 < end; k0 += 8 * BLOCK) {
+        uint16_t sb[8];
+        uint32_t ix[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool ok = k0 + j * BLOCK < end;
+            sb[j] = ok ? item_sub[k0 + j * BLOCK] : (uint16_t)0xffff;
+            ix[j] = ok ? item_idx[k0 + j * BLOCK] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (sb[j] != 0xffff) entries[start + atomicAdd(&h[sb[j]], 1u)] = ix[j];
+    }
+}
+
+// ------------------------------------------------------------------ LDS-staged variants (n < 2^idx_bits)
+// Round-1 PMC (profiles/r01_pmc_write.txt): the direct versions above write 563 MB (level 1) and 426 MB
+// (level 2) for 96 MB + 64 MB of payload — single 4- and 2-byte stores to ~1000 open runs per workgroup are
+// evicted from L2 as partial lines.  Here the keys of a tile (level 1) / of a partition (level 2) are
+// first ordered in LDS and then leave the CU as contiguous runs written by consecutive lanes.
+// Item = sub-bucket << (idx_bits + 1) | negative << idx_bits | point index.
+constexpr int STAGE_ITEMS = 32768;  // 128 KiB of LDS
+
+__global__ void __launch_bounds__(BLOCK) k_part_scatter_staged(const uint8_t* __restrict__ scalars, size_t n, int c,
+                                                               int W, SortPlan sp, int idx_bits,
+                                                               uint32_t* __restrict__ pcursor,
+                                                               uint32_t* __restrict__ items) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* len = smem;                       // [SORT_MAX_PW]
+    uint32_t* lbase = smem + SORT_MAX_PW;       // [SORT_MAX_PW]
+    uint32_t* gbase = smem + 2 * SORT_MAX_PW;   // [SORT_MAX_PW]
+    uint32_t* cur = smem + 3 * SORT_MAX_PW;     // [SORT_MAX_PW]
+    uint32_t* stage = smem + 4 * SORT_MAX_PW;   // [STAGE_ITEMS]
+    const int tid = threadIdx.x;
+    for (uint32_t p = tid; p < SORT_MAX_PW; p += BLOCK) {
+        len[p] = 0;
+        cur[p] = 0;
+    }
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * sp.tile;
+    TILE_SCALARS_BEGIN(tid)
+        msm_for_each_digit(s, c, W, [&](int w, uint32_t b, bool) {
+            atomicAdd(&len[(uint32_t)w * sp.ppw + (b >> sp.sub_bits)], 1u);
+        });
+    TILE_SCALARS_END
+    __syncthreads();
+    // exclusive scan over the partitions (4 per thread), and one global reservation per non-empty partition
+    constexpr int PER = SORT_MAX_PW / BLOCK;
+    uint32_t v[PER], sum = 0;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        v[j] = len[tid * PER + j];
+        sum += v[j];
+    }
+    gbase[tid] = sum;  // scratch for the scan
+    __syncthreads();
+#pragma unroll 1
+    for (int d = 1; d < BLOCK; d <<= 1) {
+        uint32_t t = (tid >= d) ? gbase[tid - d] : 0u;
+        __syncthreads();
+        gbase[tid] += t;
+        __syncthreads();
+    }
+    uint32_t off = gbase[tid] - sum;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const uint32_t p = tid * PER + j;
+        lbase[p] = off;
+        off += v[j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const uint32_t p = tid * PER + j;
+        gbase[p] = v[j] ? atomicAdd(&pcursor[p], v[j]) : 0u;
+    }
+    __syncthreads();
+    const uint32_t submask = sp.SB - 1u;
+    TILE_SCALARS_BEGIN(tid)
+        msm_for_each_digit(s, c, W, [&](int w, uint32_t b, bool neg) {
+            const uint32_t p = (uint32_t)w * sp.ppw + (b >> sp.sub_bits);
+            const uint32_t r = atomicAdd(&cur[p], 1u);
+            stage[lbase[p] + r] = ((b & submask) << (idx_bits + 1)) | ((neg ? 1u : 0u) << idx_bits) | (uint32_t)i;
+        });
+    TILE_SCALARS_END
+    __syncthreads();
+    // copy-out: a wave per partition run, consecutive lanes -> consecutive addresses
+    const uint32_t wave = tid >> 6, lane = tid & 63;
+    for (uint32_t p = wave; p < sp.PW; p += BLOCK / 64) {
+        const uint32_t L = len[p], lb = lbase[p], gb = gbase[p];
+        for (uint32_t k = lane; k < L; k += 64) items[gb + k] = stage[lb + k];
+    }
+}
+
+// direct level 1 writing PACKED items (small LDS footprint -> several workgroups per CU hide the latency
+// that the 144-KiB staged variant exposes; profiles/r01_sweeps.txt)
+__global__ void __launch_bounds__(BLOCK) k_part_scatter_packed(const uint8_t* __restrict__ scalars, size_t n, int c,
+                                                               int W, SortPlan sp, int idx_bits,
+                                                               uint32_t* __restrict__ pcursor,
+                                                               uint32_t* __restrict__ items) {
+    __shared__ uint32_t cnt[SORT_MAX_PW];
+    __shared__ uint32_t basep[SORT_MAX_PW];
+    for (uint32_t p = threadIdx.x; p < sp.PW; p += BLOCK) cnt[p] = 0;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * sp.tile;
+    TILE_SCALARS_BEGIN(threadIdx.x)
+        msm_for_each_digit(s, c, W, [&](int w, uint32_t b, bool) {
+            atomicAdd(&cnt[(uint32_t)w * sp.ppw + (b >> sp.sub_bits)], 1u);
+        });
+    TILE_SCALARS_END
+    __syncthreads();
+    for (uint32_t p = threadIdx.x; p < sp.PW; p += BLOCK) {
+        const uint32_t v = cnt[p];
+        basep[p] = v ? atomicAdd(&pcursor[p], v) : 0u;
+        cnt[p] = 0;
+    }
+    __syncthreads();
+    const uint32_t submask = sp.SB - 1u;
+    TILE_SCALARS_BEGIN(threadIdx.x)
+        msm_for_each_digit(s, c, W, [&](int w, uint32_t b, bool neg) {
+            const uint32_t p = (uint32_t)w * sp.ppw + (b >> sp.sub_bits);
+            const uint32_t pos = basep[p] + atomicAdd(&cnt[p], 1u);
+            items[pos] = ((b & submask) << (idx_bits + 1)) | ((neg ? 1u : 0u) << idx_bits) | (uint32_t)i;
+        });
+    TILE_SCALARS_END
+}
+
+__global__ void __launch_bounds__(BLOCK) k_bucket_sort_staged(const uint32_t* __restrict__ pstart,
+                                                              const uint32_t* __restrict__ items, SortPlan sp,
+                                                              int idx_bits, uint32_t NB, uint32_t* __restrict__ hist,
+                                                              uint32_t* __restrict__ offs,
+                                                              uint32_t* __restrict__ entries) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    uint32_t* h = smem;                         // [SORT_MAX_SB]
+    uint32_t* scan = smem + SORT_MAX_SB;        // [BLOCK]
+    uint32_t* sorted = smem + SORT_MAX_SB + BLOCK;  // [STAGE_ITEMS]
+    const uint32_t p = blockIdx.x;
+    const uint32_t start = pstart[p], end = pstart[p + 1], total = end - start;
+    const int tid = threadIdx.x;
+    const uint32_t idxmask = (1u << idx_bits) - 1u;
+    for (uint32_t s = tid; s < sp.SB; s += BLOCK) h[s] = 0;
+    __syncthreads();
+    for (uint32_t k0 = start + tid; k0 < end; k0 += 8 * BLOCK) {  // 8 independent loads in flight
+        uint32_t it[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) it[j] = (k0 + j * BLOCK < end) ? items[k0 + j * BLOCK] : 0xffffffffu;
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (it[j] != 0xffffffffu) atomicAdd(&h[it[j] >> (idx_bits + 1)], 1u);
+    }
+    __syncthreads();
+    const uint32_t per = (sp.SB + BLOCK - 1) / BLOCK;
+    const uint32_t lo = tid * per;
+    uint32_t mine = 0;
+    for (uint32_t j = 0; j < per; ++j)
+        if (lo + j < sp.SB) mine += h[lo + j];
+    scan[tid] = mine;
+    __syncthreads();
+#pragma unroll 1
+    for (int d = 1; d < BLOCK; d <<= 1) {
+        uint32_t t = (tid >= d) ? scan[tid - d] : 0u;
+        __syncthreads();
+        scan[tid] += t;
+        __syncthreads();
+    }
+    uint32_t run = scan[tid] - mine;
+    const uint32_t w = p / sp.ppw, phi = p - w * sp.ppw;
+    const uint32_t key0 = w * NB + (phi << sp.sub_bits);
+    for (uint32_t j = 0; j < per; ++j) {
+        const uint32_t sidx = lo + j;
+        if (sidx < sp.SB) {
+            const uint32_t cnt = h[sidx];
+            hist[key0 + sidx] = cnt;
+            offs[key0 + sidx] = start + run;
+            h[sidx] = run;  // becomes the cursor
+            run += cnt;
+        }
+    }
+    __syncthreads();
+    const bool staged = total <= (uint32_t)STAGE_ITEMS;
+    for (uint32_t k0 = start + tid; k0 < end; k0 += 8 * BLOCK) {
+        uint32_t itv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) itv[j] = (k0 + j * BLOCK < end) ? items[k0 + j * BLOCK] : 0xffffffffu;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const uint32_t it = itv[j];
+            if (it == 0xffffffffu) continue;
+            const uint32_t r = atomicAdd(&h[it >> (idx_bits + 1)], 1u);
+            const uint32_t e = (it & idxmask) | (((it >> idx_bits) & 1u) << 31);
+            if (staged) sorted[r] = e;
+            else entries[start + r] = e;  // over-long partition (skewed scalars): direct placement
+        }
+    }
+    if (staged) {
+        __syncthreads();
+        for (uint32_t k = tid; k < total; k += BLOCK) entries[start + k] = sorted[k];
     }
 }
 

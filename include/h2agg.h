@@ -171,7 +171,9 @@ size_t h2agg_schema_point_list_len(h2agg_schema* s);
  * window_bits: Pippenger window c in [2, 16], 0 = choose from n.  Other knobs: 0 = default. */
 int h2agg_msm_configure(h2agg_ctx* ctx, int window_bits, int reduce_segment, int big_bucket_threshold);
 /* Bucket-sort knobs: low bucket bits resolved per partition in LDS (4..12) and scalars per level-1
- * workgroup; 0 = default. */
+ * workgroup; 0 = default.  tile = -1 forces the two-array direct sort kernels (otherwise used only when
+ * n does not fit the packed item's index field, n > 2^(31 - sub_bits)); tile = -2 additionally stages level 1
+ * through LDS (measured slower; kept as a tested variant). */
 int h2agg_msm_configure_sort(h2agg_ctx* ctx, int sub_bits, int tile);
 /* Overlap the serial Horner tail of one MSM (k_msm_final, one wave) with the bulk kernels of the next:
  * the tail runs on a second stream of the context.  With overlap on, a result written by

@@ -242,3 +242,19 @@ def test_eval_flat(eng, n):
 def test_eval_flat_without_scalars_is_the_reference_panic(eng, pkg):
     with pytest.raises(pkg.EmptyMultiExp):
         eng.eval_flat(G_BYTES * 2, bytes(64), bytes(2))
+
+
+@pytest.mark.parametrize("sub_bits,tile", [(0, -1), (0, -2), (4, 0), (12, 0), (9, 256), (0, 4096)])
+def test_msm_sort_variants(eng, sub_bits, tile):
+    """both sort implementations (LDS-staged, direct) and their knobs give the same group element"""
+    rng = O.SplitMix64(5000 + sub_bits)
+    n = 5000
+    bases, sb, want = _msm_case(rng, n, "edges")
+    eng.msm_configure_sort(sub_bits, tile)
+    try:
+        assert norm(eng, eng.g1_msm(bases, sb)) == want
+        eng.msm_configure(window_bits=13)
+        assert norm(eng, eng.g1_msm(bases, sb)) == want
+    finally:
+        eng.msm_configure()
+        eng.msm_configure_sort()
