@@ -137,6 +137,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=1 << 16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the Horner tail in-stream (latency mode)")
+    ap.add_argument("--overlap-level", type=int, default=2, help="1: only the Horner tail overlaps; 2: + bucket reduction")
     ap.add_argument("--agg-proofs", type=int, default=4, help="proofs per GPU in the aggregation leg (0 = skip)")
     ap.add_argument("--agg-commitments", type=int, default=300, help="advice commitments per synthetic proof")
     args = ap.parse_args()
@@ -166,7 +167,7 @@ def main():
     if args.sub_bits or args.tile:
         eng.msm_configure_sort(args.sub_bits, args.tile)
     if not args.no_overlap:
-        eng.msm_set_tail_overlap(True)   # serial Horner tail of MSM k runs under the bulk of MSM k+1
+        eng._check(eng._lib.h2agg_msm_set_tail_overlap(eng._ctx, args.overlap_level))   # serial Horner tail of MSM k runs under the bulk of MSM k+1
 
     n = 1 << args.log2n
     seed = 0x48324147

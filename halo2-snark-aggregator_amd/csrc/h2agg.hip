@@ -63,6 +63,7 @@ struct h2agg_ctx {
 
     // optional overlap of the serial tail (k_msm_final) of MSM k with the bulk of MSM k+1
     bool tail_overlap = false;
+    int overlap_level = 2;  // 1: only the Horner tail on the second stream; 2: reduction + window sums + tail
     hipStream_t tail_stream = nullptr;
     hipEvent_t ev_bulk[2] = {}, ev_tail[2] = {};
     bool tail_pending[2] = {false, false};
@@ -251,8 +252,10 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     TRY(ensure(c, c->item_idx, nent * 4));
     TRY(ensure(c, c->item_sub, nent * 2));
     TRY(ensure(c, c->entries, nent * 4));
-    TRY(ensure(c, c->buckets, (size_t)p.NBT * XYZZ_BYTES));
-    TRY(ensure(c, c->segsum, (size_t)nseg_total * XYZZ_BYTES));
+    // buckets / segsum / wsum are double-buffered: in overlap mode the reduction of MSM k (tail stream)
+    // runs while MSM k+1 fills the other set
+    TRY(ensure(c, c->buckets, 2 * (size_t)p.NBT * XYZZ_BYTES));
+    TRY(ensure(c, c->segsum, 2 * (size_t)nseg_total * XYZZ_BYTES));
     TRY(ensure(c, c->wsum, 2 * (size_t)p.W * XYZZ_BYTES));
     TRY(ensure(c, c->big_list, (size_t)p.NBT * 4));
     uint32_t* meta = (uint32_t*)c->pmeta.p;
@@ -264,9 +267,9 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     uint32_t* item_idx = (uint32_t*)c->item_idx.p;
     uint16_t* item_sub = (uint16_t*)c->item_sub.p;
     uint32_t* entries = (uint32_t*)c->entries.p;
-    uint8_t* buckets = (uint8_t*)c->buckets.p;
-    uint8_t* segsum = (uint8_t*)c->segsum.p;
     const int par = c->parity;
+    uint8_t* buckets = (uint8_t*)c->buckets.p + (size_t)par * p.NBT * XYZZ_BYTES;
+    uint8_t* segsum = (uint8_t*)c->segsum.p + (size_t)par * nseg_total * XYZZ_BYTES;
     uint8_t* wsum = (uint8_t*)c->wsum.p + (size_t)par * p.W * XYZZ_BYTES;
     uint32_t* big_list = (uint32_t*)c->big_list.p;
     uint32_t* big_count = c->d_flags + 1;
@@ -328,6 +331,10 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
                            bin_cursor);
         hipLaunchKernelGGL(k_size_scatter, dim3(g), dim3(BLOCK), 0, st, hist, p.NBT, bin_cursor, order);
     }
+    if (c->tail_pending[par]) {  // the reduction two MSMs ago read this parity's buckets / segsum / wsum
+        HIP_TRY(c, hipStreamWaitEvent(st, c->ev_tail[par], 0));
+        c->tail_pending[par] = false;
+    }
     {
         StageTimer t(c, ST_ACCUM);
         hipLaunchKernelGGL(k_msm_accumulate, dim3((p.NBT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d_bases, entries,
@@ -341,35 +348,37 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         hipLaunchKernelGGL(k_msm_accumulate_big, dim3((unsigned)maxbig), dim3(BLOCK), 0, st, d_bases, entries, offs,
                            hist, buckets, big_list, big_count);
     }
+    // Everything after the bucket accumulation is latency-shaped (one wave per SIMD or less): bucket
+    // reduction, per-window sums, Horner tail.  In overlap mode it runs on the context's second stream,
+    // under the sort + accumulation of the next MSM; results are picked up by join_tails().
+    hipStream_t ts = st;
+    if (c->tail_overlap && c->overlap_level >= 2) {
+        HIP_TRY(c, hipEventRecord(c->ev_bulk[par], st));
+        HIP_TRY(c, hipStreamWaitEvent(c->tail_stream, c->ev_bulk[par], 0));
+        ts = c->tail_stream;
+    }
     {
-        StageTimer t(c, ST_REDUCE);
-        hipLaunchKernelGGL(k_msm_reduce_segments, dim3((nseg_total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, buckets,
+        StageTimer t(c, ST_REDUCE, ts);
+        hipLaunchKernelGGL(k_msm_reduce_segments, dim3((nseg_total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ts, buckets,
                            p.NB, p.seg, p.spw, nseg_total, segsum);
     }
     {
-        StageTimer t(c, ST_WINDOW_SUM);
-        hipLaunchKernelGGL(k_msm_window_sum, dim3(p.W), dim3(BLOCK), 0, st, segsum, p.spw, wsum);
+        StageTimer t(c, ST_WINDOW_SUM, ts);
+        hipLaunchKernelGGL(k_msm_window_sum, dim3(p.W), dim3(BLOCK), 0, ts, segsum, p.spw, wsum);
     }
-    if (c->tail_overlap) {
-        // serial Horner tail on its own stream: it overlaps the bulk of the next MSM.  The main stream
-        // picks the result up (join_tails) before anything that consumes it or reuses wsum[par].
+    if (c->tail_overlap && c->overlap_level < 2) {
         HIP_TRY(c, hipEventRecord(c->ev_bulk[par], st));
         HIP_TRY(c, hipStreamWaitEvent(c->tail_stream, c->ev_bulk[par], 0));
-        {
-            StageTimer t(c, ST_FINAL, c->tail_stream);
-            hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, c->tail_stream, wsum, p.c, p.W, c->d_res_xyzz,
-                               d_out_jac);
-        }
+        ts = c->tail_stream;
+    }
+    {
+        StageTimer t(c, ST_FINAL, ts);
+        hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, ts, wsum, p.c, p.W, c->d_res_xyzz, d_out_jac);
+    }
+    if (c->tail_overlap) {
         HIP_TRY(c, hipEventRecord(c->ev_tail[par], c->tail_stream));
         c->tail_pending[par] = true;
-        if (c->tail_pending[par ^ 1]) {  // previous MSM's tail: its wsum slot is reused by the next call
-            HIP_TRY(c, hipStreamWaitEvent(st, c->ev_tail[par ^ 1], 0));
-            c->tail_pending[par ^ 1] = false;
-        }
         c->parity ^= 1;
-    } else {
-        StageTimer t(c, ST_FINAL);
-        hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, st, wsum, p.c, p.W, c->d_res_xyzz, d_out_jac);
     }
     HIP_TRY(c, hipGetLastError());
     profile_end_call(c);
@@ -792,6 +801,7 @@ int h2agg_msm_set_tail_overlap(h2agg_ctx* c, int enable) {
     TRY(join_tails(c));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->tail_overlap = enable != 0;
+    if (enable == 1 || enable == 2) c->overlap_level = enable;
     return H2AGG_OK;
 }
 

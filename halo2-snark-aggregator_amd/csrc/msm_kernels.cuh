@@ -140,6 +140,9 @@ __global__ void __launch_bounds__(BLOCK) k_msm_window_sum(const uint8_t* __restr
 __global__ void k_msm_final(const uint8_t* __restrict__ wsum, int c, int W, uint8_t* __restrict__ out_xyzz,
                             uint8_t* __restrict__ out_jac) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    // one wave carries the whole latency chain: let it win issue arbitration against the bulk kernels of the
+    // next MSM that share its SIMD in overlap mode
+    __builtin_amdgcn_s_setprio(3);
     G1XYZZ acc = xyzz_load(wsum + XYZZ_BYTES * (size_t)(W - 1));
     // Everything here is wave-uniform, and hipcc would otherwise move the whole chain onto the scalar
     // ALU (s_mul_hi_u32 sequences: 3.4 ms for 240 doublings, profiles/r01_kernel_stats_baseline_u32x8.txt).

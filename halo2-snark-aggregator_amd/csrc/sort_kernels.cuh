@@ -360,12 +360,12 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_sort_staged(const uint32_t* __
     for (uint32_t s = tid; s < sp.SB; s += BLOCK) h[s] = 0;
     __syncthreads();
     for (uint32_t k0 = start + tid; k0 < end; k0 += 8 * BLOCK) {  // 8 independent loads in flight
-        uint32_t it[8];
+        uint32_t it[8];  // every 32-bit pattern is a legal item (sub = max, negative, last index): no sentinel
 #pragma unroll
-        for (int j = 0; j < 8; ++j) it[j] = (k0 + j * BLOCK < end) ? items[k0 + j * BLOCK] : 0xffffffffu;
+        for (int j = 0; j < 8; ++j) it[j] = (k0 + j * BLOCK < end) ? items[k0 + j * BLOCK] : 0u;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (it[j] != 0xffffffffu) atomicAdd(&h[it[j] >> (idx_bits + 1)], 1u);
+            if (k0 + j * BLOCK < end) atomicAdd(&h[it[j] >> (idx_bits + 1)], 1u);
     }
     __syncthreads();
     const uint32_t per = (sp.SB + BLOCK - 1) / BLOCK;
@@ -400,11 +400,11 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_sort_staged(const uint32_t* __
     for (uint32_t k0 = start + tid; k0 < end; k0 += 8 * BLOCK) {
         uint32_t itv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) itv[j] = (k0 + j * BLOCK < end) ? items[k0 + j * BLOCK] : 0xffffffffu;
+        for (int j = 0; j < 8; ++j) itv[j] = (k0 + j * BLOCK < end) ? items[k0 + j * BLOCK] : 0u;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const uint32_t it = itv[j];
-            if (it == 0xffffffffu) continue;
+            if (k0 + j * BLOCK >= end) continue;
             const uint32_t r = atomicAdd(&h[it >> (idx_bits + 1)], 1u);
             const uint32_t e = (it & idxmask) | (((it >> idx_bits) & 1u) << 31);
             if (staged) sorted[r] = e;

@@ -258,3 +258,4 @@ def test_msm_sort_variants(eng, sub_bits, tile):
     finally:
         eng.msm_configure()
         eng.msm_configure_sort()
+
