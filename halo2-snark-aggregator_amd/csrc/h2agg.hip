@@ -48,7 +48,8 @@ struct h2agg_ctx {
 
     // grow-only device workspace
     DevBuf in_a, in_b, in_c, out, tmp_bases;                      // host-buffer entry points
-    DevBuf hist, offs, pmeta, item_idx, item_sub, order, entries, buckets, segsum, wsum, big_list, small;  // MSM
+    DevBuf hist, offs, pmeta, item_idx, item_sub, order, entries, buckets, segsum, wsum, big_list, big_keys, big_part,
+        small;  // MSM
     uint32_t* d_flags = nullptr;      // in `small`: [0] status flags, [1] big_count
     uint8_t* d_res_xyzz = nullptr;    // in `small` + 64
     uint8_t* d_res_jac = nullptr;     // in `small` + 256
@@ -138,12 +139,21 @@ int finish(h2agg_ctx* c) {
     return H2AGG_OK;
 }
 
+// bits of the scalar that fall into the top window (a narrow top window means a few huge buckets)
+int top_window_bits(int c) {
+    const int W = (255 + c - 1) / c;
+    return 254 - c * (W - 1);
+}
 int choose_window(size_t n) {
     int lg = 0;
     while (((size_t)1 << (lg + 1)) <= n) ++lg;
     int c = lg - 4;
     if (c < 3) c = 3;
     if (c > 16) c = 16;
+    if (n >= 4096 && top_window_bits(c) < 6) {  // e.g. c = 14 -> 2 bits, c = 12 -> 2, c = 11 -> 1
+        if (c < 16 && top_window_bits(c + 1) >= 6) c += 1;
+        else if (c > 3 && top_window_bits(c - 1) >= 6) c -= 1;
+    }
     return c;
 }
 
@@ -257,7 +267,11 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     TRY(ensure(c, c->buckets, 2 * (size_t)p.NBT * XYZZ_BYTES));
     TRY(ensure(c, c->segsum, 2 * (size_t)nseg_total * XYZZ_BYTES));
     TRY(ensure(c, c->wsum, 2 * (size_t)p.W * XYZZ_BYTES));
-    TRY(ensure(c, c->big_list, (size_t)p.NBT * 4));
+    const size_t max_slots = nent / BIG_CHUNK + nent / ((size_t)p.big + 1) + 2;   // chunks of over-long buckets
+    const size_t max_keys = nent / ((size_t)p.big + 1) + 2;
+    TRY(ensure(c, c->big_list, max_slots * 12));
+    TRY(ensure(c, c->big_keys, max_keys * 12));
+    TRY(ensure(c, c->big_part, max_slots * XYZZ_BYTES));
     uint32_t* meta = (uint32_t*)c->pmeta.p;
     uint32_t *pcount = meta, *pstart = meta + 2048, *pcursor = meta + 4096;
     uint32_t *bin_count = meta + 6144, *bin_start = meta + 8192, *bin_cursor = meta + 10240;
@@ -272,7 +286,9 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     uint8_t* segsum = (uint8_t*)c->segsum.p + (size_t)par * nseg_total * XYZZ_BYTES;
     uint8_t* wsum = (uint8_t*)c->wsum.p + (size_t)par * p.W * XYZZ_BYTES;
     uint32_t* big_list = (uint32_t*)c->big_list.p;
-    uint32_t* big_count = c->d_flags + 1;
+    uint32_t* big_keys = (uint32_t*)c->big_keys.p;
+    uint8_t* big_part = (uint8_t*)c->big_part.p;
+    uint32_t* big_count = c->d_flags + 2;   // [0] chunk slots, [1] multi-chunk buckets
     hipStream_t st = c->stream;
     const unsigned ntiles = (unsigned)((n + sp.tile - 1) / sp.tile);
     profile_begin_call(c);
@@ -280,7 +296,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     {
         StageTimer t(c, ST_PART_COUNT);
         HIP_TRY(c, hipMemsetAsync(meta, 0, 12288 * 4, st));
-        HIP_TRY(c, hipMemsetAsync(big_count, 0, 4, st));
+        HIP_TRY(c, hipMemsetAsync(big_count, 0, 8, st));
         hipLaunchKernelGGL(k_part_count, dim3(ntiles), dim3(BLOCK), 0, st, d_scalars, n, p.c, p.W, sp, pcount,
                            c->d_flags);
         hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(BLOCK), 0, st, pcount, sp.PW, pstart, pcursor);
@@ -338,15 +354,18 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     {
         StageTimer t(c, ST_ACCUM);
         hipLaunchKernelGGL(k_msm_accumulate, dim3((p.NBT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d_bases, entries,
-                           offs, hist, order, p.NBT, p.big, buckets, big_list, big_count);
+                           offs, hist, order, p.NBT, p.big, buckets, big_list, big_keys, big_count);
     }
     {
         StageTimer t(c, ST_ACCUM_BIG);
-        size_t maxbig = nent / ((size_t)p.big + 1) + 1;
-        size_t cap = (size_t)c->cu_count * 4;
-        if (maxbig > cap) maxbig = cap;
-        hipLaunchKernelGGL(k_msm_accumulate_big, dim3((unsigned)maxbig), dim3(BLOCK), 0, st, d_bases, entries, offs,
-                           hist, buckets, big_list, big_count);
+        size_t grid = max_slots;
+        const size_t cap = (size_t)c->cu_count * 4;
+        if (grid > cap) grid = cap;
+        hipLaunchKernelGGL(k_msm_accumulate_big, dim3((unsigned)grid), dim3(BLOCK), 0, st, d_bases, entries, offs, hist,
+                           buckets, big_part, big_list, big_count);
+        size_t gk = max_keys < cap ? max_keys : cap;
+        hipLaunchKernelGGL(k_msm_big_combine, dim3((unsigned)gk), dim3(BLOCK), 0, st, big_part, big_keys, big_count,
+                           buckets);
     }
     // Everything after the bucket accumulation is latency-shaped (one wave per SIMD or less): bucket
     // reduction, per-window sums, Horner tail.  In overlap mode it runs on the context's second stream,
@@ -457,7 +476,7 @@ void h2agg_destroy(h2agg_ctx* c) {
     if (c->tail_stream) hipStreamSynchronize(c->tail_stream);
     DevBuf* bufs[] = {&c->in_a,  &c->in_b,     &c->in_c,     &c->out,   &c->tmp_bases, &c->hist,
                       &c->offs,  &c->pmeta,    &c->item_idx, &c->item_sub, &c->order,  &c->entries,
-                      &c->buckets, &c->segsum, &c->wsum,     &c->big_list, &c->small};
+                      &c->buckets, &c->segsum, &c->wsum,     &c->big_list, &c->big_keys, &c->big_part, &c->small};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     for (auto& kv : c->tables)

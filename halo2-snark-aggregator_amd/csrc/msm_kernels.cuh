@@ -38,19 +38,38 @@ FP_INLINE G1Affine msm_gather(const uint8_t* __restrict__ bases, uint32_t e) {
     return (e >> 31) ? affine_neg(p) : p;
 }
 
+// Buckets longer than `big` are cut into chunks of BIG_CHUNK entries, one workgroup per chunk (a narrow top
+// window or skewed scalars can put a large share of all points into a handful of buckets — a 2-bit top
+// window at c = 14 holds n/4 points per bucket).  big_list: 3 words per chunk slot {key, chunk, nchunks};
+// big_keys: 3 words per multi-chunk bucket {key, first slot, nchunks}.
+constexpr uint32_t BIG_CHUNK = 2048;
+
 __global__ void __launch_bounds__(BLOCK) k_msm_accumulate(const uint8_t* __restrict__ bases,
                                                           const uint32_t* __restrict__ entries,
                                                           const uint32_t* __restrict__ offs,
                                                           const uint32_t* __restrict__ hist,
                                                           const uint32_t* __restrict__ order, uint32_t nbt, uint32_t big,
                                                           uint8_t* __restrict__ buckets, uint32_t* __restrict__ big_list,
-                                                          uint32_t* __restrict__ big_count) {
+                                                          uint32_t* __restrict__ big_keys,
+                                                          uint32_t* __restrict__ counters /* [0] chunks, [1] keys */) {
     const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
     if (t >= nbt) return;
     const uint32_t key = order[t];  // buckets sorted by length, longest first: a wave's lanes finish together
     const uint32_t len = hist[key];
     if (len > big) {
-        big_list[atomicAdd(big_count, 1u)] = key;
+        const uint32_t nch = (len + BIG_CHUNK - 1) / BIG_CHUNK;
+        const uint32_t base = atomicAdd(&counters[0], nch);
+        for (uint32_t j = 0; j < nch; ++j) {
+            big_list[3 * (base + j)] = key;
+            big_list[3 * (base + j) + 1] = j;
+            big_list[3 * (base + j) + 2] = nch;
+        }
+        if (nch > 1) {
+            const uint32_t k = atomicAdd(&counters[1], 1u);
+            big_keys[3 * k] = key;
+            big_keys[3 * k + 1] = base;
+            big_keys[3 * k + 2] = nch;
+        }
         return;
     }
     const uint32_t* run = entries + offs[key];
@@ -67,23 +86,44 @@ __global__ void __launch_bounds__(BLOCK) k_msm_accumulate(const uint8_t* __restr
     xyzz_store(buckets + XYZZ_BYTES * (size_t)key, acc);
 }
 
-// one workgroup per over-long bucket
+// one workgroup per chunk of an over-long bucket
 __global__ void __launch_bounds__(BLOCK) k_msm_accumulate_big(const uint8_t* __restrict__ bases,
                                                               const uint32_t* __restrict__ entries,
                                                               const uint32_t* __restrict__ offs,
                                                               const uint32_t* __restrict__ hist,
                                                               uint8_t* __restrict__ buckets,
+                                                              uint8_t* __restrict__ big_part,
                                                               const uint32_t* __restrict__ big_list,
-                                                              const uint32_t* __restrict__ big_count) {
+                                                              const uint32_t* __restrict__ counters) {
     __shared__ uint32_t lds[XYZZ_WORDS * BLOCK];
-    const uint32_t nbig = *big_count;
-    for (uint32_t b = blockIdx.x; b < nbig; b += gridDim.x) {
-        const uint32_t key = big_list[b];
+    const uint32_t nslots = counters[0];
+    for (uint32_t b = blockIdx.x; b < nslots; b += gridDim.x) {
+        const uint32_t key = big_list[3 * b], chunk = big_list[3 * b + 1], nch = big_list[3 * b + 2];
         const uint32_t len = hist[key];
+        const uint32_t lo = chunk * BIG_CHUNK, hi = (lo + BIG_CHUNK < len) ? lo + BIG_CHUNK : len;
         const uint32_t* run = entries + offs[key];
         G1XYZZ acc = G1XYZZ::identity();
 #pragma unroll 1
-        for (uint32_t k = threadIdx.x; k < len; k += BLOCK) xyzz_add_affine(acc, msm_gather(bases, run[k]));
+        for (uint32_t k = lo + threadIdx.x; k < hi; k += BLOCK) xyzz_add_affine(acc, msm_gather(bases, run[k]));
+        G1XYZZ tot = block_sum_xyzz(acc, lds);
+        if (threadIdx.x == 0)
+            xyzz_store(nch == 1 ? buckets + XYZZ_BYTES * (size_t)key : big_part + XYZZ_BYTES * (size_t)b, tot);
+        __syncthreads();
+    }
+}
+// sum the chunk partials of every multi-chunk bucket
+__global__ void __launch_bounds__(BLOCK) k_msm_big_combine(const uint8_t* __restrict__ big_part,
+                                                           const uint32_t* __restrict__ big_keys,
+                                                           const uint32_t* __restrict__ counters,
+                                                           uint8_t* __restrict__ buckets) {
+    __shared__ uint32_t lds[XYZZ_WORDS * BLOCK];
+    const uint32_t nkeys = counters[1];
+    for (uint32_t k = blockIdx.x; k < nkeys; k += gridDim.x) {
+        const uint32_t key = big_keys[3 * k], base = big_keys[3 * k + 1], nch = big_keys[3 * k + 2];
+        G1XYZZ acc = G1XYZZ::identity();
+#pragma unroll 1
+        for (uint32_t j = threadIdx.x; j < nch; j += BLOCK)
+            acc = xyzz_add(acc, xyzz_load(big_part + XYZZ_BYTES * (size_t)(base + j)));
         G1XYZZ tot = block_sum_xyzz(acc, lds);
         if (threadIdx.x == 0) xyzz_store(buckets + XYZZ_BYTES * (size_t)key, tot);
         __syncthreads();
