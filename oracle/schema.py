@@ -351,3 +351,25 @@ def final_pair_bytes(left, right, instances=()) -> bytes:
     for s in instances:
         out += O.fe_to_bytes(s)
     return out
+
+
+def final_pair_to_instances(left, right, instances=()):
+    """final_pair_to_instances (halo2-snark-aggregator-circuit/src/verify_circuit.rs:768-804) restated with
+    field arithmetic, as the reference does: limbs via % and >>, combined with limb_modulus_exps in Fr."""
+    lm = 1 << 68
+    exps = [pow(lm, k, O.R) for k in range(4)]                       # limb_modulus_exps (integer_chip.rs:105-110)
+
+    def limbs(v):
+        out = []
+        for _ in range(3):
+            out.append(v % lm)
+            v >>= 68
+        out.append(v)
+        return [x % O.R for x in out]
+    res = []
+    for pt in (left, right):
+        x, y = limbs(pt[0]), limbs(pt[1])
+        last = exps[2] if (y[0] & 1) else 0
+        res.append((x[0] * exps[0] + x[1] * exps[1]) % O.R)
+        res.append((x[2] * exps[0] + x[3] * exps[1] + last) % O.R)
+    return res + [s % O.R for s in instances]
