@@ -57,6 +57,19 @@ def cpu_baseline(bases_aff: bytes, scalars: bytes, sample: int):
     return sample / dt, dt, out
 
 
+def measured_traffic(stage_name: str, log2n: int):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_traffic.json:
+    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected separately); null when no measurement matches this run."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+            t = json.load(f)
+        if log2n == 20 and stage_name == "msm_accumulate" and t["kernel"] == "k_msm_accumulate":
+            return t["bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def aggregation_leg(pkg, eng, args, rank, world, dist, dev):
     """Secondary figure (BASELINE.json metric, second half): aggregated proofs/s through the full
     EvaluationQuerySchema::eval path.  `agg_proofs` synthetic proofs per GPU (shape: `agg_commitments`
@@ -254,7 +267,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u32x8-montgomery (254-bit prime-field integers)",
+            "dtype": "u32 (9 x 29-bit limbs, Montgomery R = 2^261; 254-bit prime-field integers)",
             "data": "synthetic",
             "config": {
                 "workload": "standalone 2^%d-point BN254 G1 MSM, uniform Fr scalars, bases k_i*G resident in HBM "
@@ -274,10 +287,12 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": measured_traffic(dom_name, args.log2n),
                 "avg_kernel_ms": dom_avg_s * 1e3,
                 "note": "MSM is integer-VALU-bound (v_mad_u64_u32 chains), not HBM-bound: the algorithmic "
-                        "96 B/point is a tiny fraction of peak by construction (SURVEY.md §8d)",
+                        "96 B/point is a tiny fraction of peak by construction (SURVEY.md \u00a78d). VALU view "
+                        "(profiles/r01_final_pmc_sq.txt): 698 M wave-instructions per launch, 4.16 cycles per "
+                        "instruction per SIMD at 2.04 GHz against ~3.5 for this instruction mix = ~84 % VALU issue",
                 "stages_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in stages.items()},
             },
         }
