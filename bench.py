@@ -102,12 +102,20 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, dev):
         spec = [(rot, key, z, pts[(i * 131 + k) % pool_n], fr()) for k, (rot, key, z) in enumerate(qs)]
         specs.append((spec, [pts[(i + 1) % pool_n], pts[(i + 2) % pool_n], pts[(i + 3) % pool_n]], fr(), fr()))
 
+    packed = []
+    for spec, w, v, u in specs:      # byte-level packing of the proof data (what a transcript reader hands over)
+        packed.append(([k for _r, k, _z, _c, _e in spec], b"".join(c for *_x, c, _e in spec),
+                       b"".join(e for *_x, e in spec), [r for r, *_x in spec], b"".join(z for _r, _k, z, _c, _e in spec),
+                       b"".join(w), v, u))
+
     def build(b, idx):
+        """per proof: n x EvaluationQuery::new + batch_multi_open_proofs, both in the C++ host layer"""
         out = []
         for i in idx:
-            spec, w, v, u = specs[i]
-            queries = [mo.evaluation_query(b, backend.CommitQuery, rot, key, z, c, e) for rot, key, z, c, e in spec]
-            out.append(mo.batch_multi_open_proofs(b, backend.CommitQuery, "p%d" % i, queries, w, v, u))
+            keys, commitments, evals, rots, zs, wbytes, v, u = packed[i]
+            qnodes = b.evaluation_queries(keys, commitments, evals)
+            w_x, w_g = b.batch_multi_open("p%d" % i, rots, zs, qnodes, wbytes, v, u)
+            out.append(mo.MultiOpenProof(w_x, w_g))
         return out
 
     agg.aggregate_sharded(backend, build, n_total, lam, dist=dist, device=dev)          # warm-up
@@ -248,7 +256,15 @@ def main():
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
     dt_max = float(t_all.item())
 
-    agg_info = aggregation_leg(pkg, eng, args, rank, world, dist, dev) if args.agg_proofs > 0 else None
+    agg_info = None
+    if args.agg_proofs > 0:
+        agg_info = aggregation_leg(pkg, eng, args, rank, world, dist, dev)       # configs[2]/[3]: 4 proofs per GPU
+        big = argparse.Namespace(**vars(args))
+        big.agg_proofs = 4 * args.agg_proofs                                       # configs[4]: 16 proofs per GPU
+        more = aggregation_leg(pkg, eng, big, rank, world, dist, dev)
+        if agg_info is not None and more is not None:
+            agg_info["at_%d_proofs_per_gpu" % big.agg_proofs] = {
+                k: more[k] for k in ("proofs_per_sec", "proofs", "seconds_per_aggregation")}
 
     if rank == 0:
         stages = eng.profile_stages()

@@ -83,6 +83,11 @@ def load_library():
         "h2agg_schema_node_add": (i32, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
         "h2agg_schema_node_mul": (i32, [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32)]),
         "h2agg_schema_estimate": (i32, [C.c_void_p, C.c_uint32, C.POINTER(C.c_size_t)]),
+        "h2agg_schema_evaluation_queries": (i32, [C.c_void_p, sz, C.POINTER(C.c_char_p), u8p, u8p,
+                                                  C.POINTER(C.c_uint32)]),
+        "h2agg_schema_batch_multi_open": (i32, [C.c_void_p, C.c_char_p, sz, C.POINTER(C.c_int32), u8p,
+                                                C.POINTER(C.c_uint32), sz, u8p, u8p, u8p,
+                                                C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
         "h2agg_schema_eval": (i32, [C.c_void_p, C.c_uint32, vp, C.POINTER(i32), vp]),
         "h2agg_evaluate_multiopen_proof": (i32, [C.c_void_p, C.c_uint32, C.c_uint32, vp, vp]),
         "h2agg_schema_name_count": (C.c_size_t, [C.c_void_p]),
@@ -305,6 +310,25 @@ class SchemaBuilder:
 
     def scalar(self, s: bytes) -> "EvaluationQuerySchema":               # scalar!  evaluation.rs:55-60
         return self._node(self._lib.h2agg_schema_node_scalar, s)
+
+    def evaluation_queries(self, keys: Sequence[str], commitments: bytes, evals: bytes):
+        """n x EvaluationQuery::new in one call -> list of schema nodes ([C_i] + eval_i)."""
+        n = len(keys)
+        arr = (C.c_char_p * n)(*[k.encode() for k in keys])
+        out = (C.c_uint32 * n)()
+        self.eng._check(self._lib.h2agg_schema_evaluation_queries(self._s, n, arr, commitments, evals, out))
+        return [EvaluationQuerySchema(self, out[i]) for i in range(n)]
+
+    def batch_multi_open(self, key: str, rotations: Sequence[int], points: bytes, query_nodes, w: bytes,
+                         v: bytes, u: bytes):
+        """multiopen.rs:23-102 in the C++ host layer -> (w_x, w_g) schema nodes."""
+        nq = len(rotations)
+        rot = (C.c_int32 * nq)(*rotations)
+        qn = (C.c_uint32 * nq)(*[q.node if isinstance(q, EvaluationQuerySchema) else int(q) for q in query_nodes])
+        wx, wg = C.c_uint32(), C.c_uint32()
+        self.eng._check(self._lib.h2agg_schema_batch_multi_open(self._s, key.encode(), nq, rot, points, qn,
+                                                                len(w) // 64, w, v, u, C.byref(wx), C.byref(wg)))
+        return EvaluationQuerySchema(self, wx.value), EvaluationQuerySchema(self, wg.value)
 
     def evaluate_multiopen_proof(self, w_x: "EvaluationQuerySchema", w_g: "EvaluationQuerySchema"):
         """verify.rs:705-731 -> (left_aff, right_aff, names)"""

@@ -79,6 +79,30 @@ __global__ void __launch_bounds__(BLOCK) k_tape_level(const TapeOp* __restrict__
     else r = fr_fold_2r(fp_sub<2, FrParams>(a, b));                         // a - b + 2r < 4r -> < 2r
     reg_store(regs, op.dst, r);
 }
+// The whole tape in ONE launch: a single 1024-lane workgroup walks the dependency levels with a barrier
+// in between.  Horner chains make tapes deep and narrow (hundreds of levels of a few operations), which is
+// launch-bound as one kernel per level; wide levels are strip-mined by the 1024 lanes.
+constexpr int TAPE_THREADS = 1024;
+__global__ void __launch_bounds__(TAPE_THREADS) k_tape_run(const TapeOp* __restrict__ ops,
+                                                           const uint32_t* __restrict__ level_start,
+                                                           uint32_t nlevels, uint32_t* __restrict__ regs) {
+#pragma unroll 1
+    for (uint32_t l = 0; l < nlevels; ++l) {
+        const uint32_t lo = level_start[l], hi = level_start[l + 1];
+#pragma unroll 1
+        for (uint32_t i = lo + threadIdx.x; i < hi; i += TAPE_THREADS) {
+            const TapeOp op = ops[i];
+            const Fr a = reg_load(regs, op.a), b = reg_load(regs, op.b);
+            Fr r;
+            if (op.op == TAPE_MUL) r = fp_mul<FrParams>(a, b);
+            else if (op.op == TAPE_ADD) r = fr_fold_2r(fp_add<FrParams>(a, b));
+            else r = fr_fold_2r(fp_sub<2, FrParams>(a, b));
+            reg_store(regs, op.dst, r);
+        }
+        __syncthreads();  // workgroup-scope release/acquire: the next level reads these registers
+    }
+}
+
 // registers -> canonical 32-byte scalars (MSM scalar buffer / results)
 __global__ void __launch_bounds__(BLOCK) k_tape_gather(const uint32_t* __restrict__ regs,
                                                        const uint32_t* __restrict__ idx, uint32_t n,
@@ -184,6 +208,77 @@ struct Schema {
         return (uint32_t)nodes.size() - 1;
     }
 
+    // EvaluationQuery::new (evaluation.rs:100-118): schema = commit!(cq) + eval!(cq)
+    uint32_t add_evaluation_query(const char* key, const uint8_t commitment[64], const uint8_t eval[32]) {
+        const uint32_t cnode = add_commitment(key, commitment);
+        const uint32_t enode = add_leaf_scalar(SchemaNode::EVAL, eval);
+        return add_binary(SchemaNode::ADD, cnode, enode);
+    }
+
+    // VerifierParams::get_point_schemas + batch_multi_open_proofs (multiopen.rs:23-102).
+    // queries: (rotation, evaluation point z, schema node) in VerifierParams::queries order; w: one W
+    // commitment per rotation group in first-seen order.  Returns false if the counts differ (the
+    // reference's assert_eq!, multiopen.rs:48).
+    bool batch_multi_open(const char* key, size_t nq, const int32_t* rotation, const uint8_t* points /*32 B each*/,
+                          const uint32_t* qnodes, size_t nw, const uint8_t* w /*64 B each*/, const uint8_t v[32],
+                          const uint8_t u[32], uint32_t& w_x_out, uint32_t& w_g_out) {
+        struct Group {
+            int32_t rot;
+            const uint8_t* point;
+            std::vector<uint32_t> schemas;
+        };
+        std::vector<Group> groups;
+        for (size_t i = 0; i < nq; ++i) {                                     // :33-43
+            if (!valid(qnodes[i])) {
+                err = "unknown schema node";
+                return false;
+            }
+            size_t g = 0;
+            for (; g < groups.size(); ++g)
+                if (groups[g].rot == rotation[i]) break;
+            if (g == groups.size()) groups.push_back({rotation[i], points + 32 * i, {}});
+            groups[g].schemas.push_back(qnodes[i]);
+        }
+        if (nw != groups.size()) {
+            err = "assert_eq!(self.w.len(), points.len()) failed (multiopen.rs:48)";
+            return false;
+        }
+        std::vector<uint32_t> s_of(groups.size());
+        for (size_t g = 0; g < groups.size(); ++g) {                          // :56-60  rev().reduce(v*acc + q)
+            const std::vector<uint32_t>& sc = groups[g].schemas;
+            uint32_t acc = sc.back();
+            for (size_t k = sc.size() - 1; k-- > 0;) {
+                const uint32_t vn = add_leaf_scalar(SchemaNode::SCALAR, v);
+                acc = add_binary(SchemaNode::ADD, add_binary(SchemaNode::MUL, vn, acc), sc[k]);
+            }
+            s_of[g] = acc;
+        }
+        bool have = false;
+        uint32_t w_x = 0, w_g = 0;
+        for (size_t gi = groups.size(); gi-- > 0;) {                          // :82-96  enumerate().rev()
+            const std::string wkey = std::string(key) + "_w" + std::to_string(gi);
+            const uint32_t cw = add_commitment(wkey.c_str(), w + 64 * gi);
+            const uint32_t zc = add_binary(SchemaNode::MUL, add_leaf_scalar(SchemaNode::SCALAR, groups[gi].point),
+                                           add_commitment(wkey.c_str(), w + 64 * gi));
+            if (!have) {
+                w_x = cw;
+                w_g = add_binary(SchemaNode::ADD, zc, s_of[gi]);
+                have = true;
+            } else {
+                w_x = add_binary(SchemaNode::ADD, add_binary(SchemaNode::MUL, add_leaf_scalar(SchemaNode::SCALAR, u), w_x), cw);
+                const uint32_t uw = add_binary(SchemaNode::MUL, add_leaf_scalar(SchemaNode::SCALAR, u), w_g);
+                w_g = add_binary(SchemaNode::ADD, add_binary(SchemaNode::ADD, uw, zc), s_of[gi]);
+            }
+        }
+        if (!have) {
+            err = "no queries";
+            return false;
+        }
+        w_x_out = w_x;
+        w_g_out = w_g;
+        return true;
+    }
+
     // estimate (evaluation.rs:295-330)
     size_t estimate(uint32_t id, bool scalar) const {
         const SchemaNode& n = nodes[id];
@@ -235,32 +330,29 @@ struct Schema {
                 out.v.push_back({std::string(), -1, sum});
                 return true;
             }
-            // :245-268  merge entries with equal key by adding their scalars (None == one)
+            // :245-268  merge entries with equal key by adding their scalars (None == one).
+            // Every list eval_prepare returns has unique keys (a single entry, or the `res` of an Add), so
+            // pushing the LEFT entries through the reference's find-or-push loop never merges anything:
+            // the left list is taken over as `res` (with its hash index carried along), and only the right
+            // entries are looked up.  Same result and order as the reference, without its O(n^2) scan.
             Prepared res;
             if (!eval_prepare(l, scalar, res)) return false;
             Prepared rhs;
             if (!eval_prepare(r, scalar, rhs)) return false;
-            // the left list itself may hold duplicate keys only if a child produced them; the reference
-            // pushes left entries through the same find-or-push loop, so do that too
-            Prepared merged;
-            merged.v.reserve(res.v.size() + rhs.v.size());
-            merged.index.reserve((res.v.size() + rhs.v.size()) * 2 + 8);
-            merged.indexed = true;
-            for (Prepared* side : {&res, &rhs}) {
-                for (PreparedEntry& ev : side->v) {
-                    auto it = merged.index.find(ev.key);
-                    if (it != merged.index.end()) {
-                        PreparedEntry& p = merged.v[it->second];
-                        const uint32_t a = p.scalar >= 0 ? (uint32_t)p.scalar : one();
-                        const uint32_t b = ev.scalar >= 0 ? (uint32_t)ev.scalar : one();
-                        p.scalar = tape.record(TAPE_ADD, a, b);
-                    } else {
-                        merged.index.emplace(ev.key, (uint32_t)merged.v.size());
-                        merged.v.push_back(std::move(ev));
-                    }
+            res.build_index();
+            for (PreparedEntry& ev : rhs.v) {
+                auto it = res.index.find(ev.key);
+                if (it != res.index.end()) {
+                    PreparedEntry& p = res.v[it->second];
+                    const uint32_t a = p.scalar >= 0 ? (uint32_t)p.scalar : one();
+                    const uint32_t b = ev.scalar >= 0 ? (uint32_t)ev.scalar : one();
+                    p.scalar = tape.record(TAPE_ADD, a, b);
+                } else {
+                    res.index.emplace(ev.key, (uint32_t)res.v.size());
+                    res.v.push_back(std::move(ev));
                 }
             }
-            out = std::move(merged);
+            out = std::move(res);
             return true;
         }
         case SchemaNode::MUL: {                                              // :271-291

@@ -150,6 +150,17 @@ int h2agg_schema_node_scalar(h2agg_schema* s, const uint8_t scalar[32], uint32_t
 int h2agg_schema_node_add(h2agg_schema* s, uint32_t l, uint32_t r, uint32_t* node_out);      /* l + r       */
 int h2agg_schema_node_mul(h2agg_schema* s, uint32_t l, uint32_t r, uint32_t* node_out);      /* l * r       */
 int h2agg_schema_estimate(h2agg_schema* s, uint32_t node, size_t* out);                      /* estimate(None) */
+/* n x EvaluationQuery::new (evaluation.rs:100-118): nodes_out[i] = commit!(cq_i) + eval!(cq_i). */
+int h2agg_schema_evaluation_queries(h2agg_schema* s, size_t n, const char* const* keys, const uint8_t* commitments,
+                                    const uint8_t* evals, uint32_t* nodes_out);
+/* replaces: VerifierParams::get_point_schemas + batch_multi_open_proofs
+ * (halo2-snark-aggregator-api/src/systems/halo2/multiopen.rs:23-102): queries (rotation, evaluation point,
+ * schema node) in VerifierParams::queries order are grouped by rotation in first-seen order, Horner-folded
+ * in v per group and in u over groups; `w` holds one W commitment per group (nw must equal the number of
+ * groups — the reference's assert_eq!, multiopen.rs:48).  Keys of the W commitments: "{key}_w{i}". */
+int h2agg_schema_batch_multi_open(h2agg_schema* s, const char* key, size_t nq, const int32_t* rotations,
+                                  const uint8_t* points, const uint32_t* query_nodes, size_t nw, const uint8_t* w,
+                                  const uint8_t v[32], const uint8_t u[32], uint32_t* w_x_out, uint32_t* w_g_out);
 /* eval(): out_jac = multi_exp(points with scalars) + sum(points without); *has_scalar / out_scalar = the
  * accumulated pure-scalar term (key ""), None -> *has_scalar = 0.  A Mul whose both sides hold
  * commitments, or an Add of non-singleton scalar sides, fails with H2AGG_ERR_INVALID (the reference's

@@ -92,3 +92,48 @@ def test_aggregation_vs_oracle(eng, pkg, nproofs, shape):
     assert left + right == S.final_pair_bytes(want_l, want_r)
     assert names == want_names and b.point_list_len() == len(ctx.point_list)
     b.close()
+
+
+def test_cpp_batch_builders_match_oracle(eng, pkg):
+    """h2agg_schema_evaluation_queries + h2agg_schema_batch_multi_open (multiopen.rs:23-102 in the C++ host
+    layer) against the oracle's batch_multi_open_proofs on the same simple queries; also the w-count assert."""
+    rng = O.SplitMix64(0xB17C)
+    nproofs = 3
+    want_proofs, specs = [], []
+    for i in range(nproofs):
+        key = "c_p%d" % i
+        x = rng.fr()
+        rp = {0: x, 1: x * 7 % O.R, -6: x * 11 % O.R}
+        rots = [0] * 5 + [1, 0, -6, 1, 0, -6, 0]
+        spec = [(rot, "%s_q%d" % (key, k), rp[rot], O.scalar_mul(rng.fr(), O.G1), rng.fr()) for k, rot in enumerate(rots)]
+        w = [O.scalar_mul(rng.fr(), O.G1) for _ in range(3)]
+        v, u = rng.fr(), rng.fr()
+        qs = [S.evaluation_query(rot, k, z, c, e) for rot, k, z, c, e in spec]
+        want_proofs.append(S.batch_multi_open_proofs(key, qs, w, v, u))
+        specs.append((key, spec, w, v, u))
+    lam = rng.fr()
+    agg = S.aggregate_fold(want_proofs, lam)
+    want_l, want_r, want_names = S.evaluate_multiopen_proof(S.OracleCtx(), S.OracleFieldChip(), S.OracleEccChip(), agg)
+    b = pkg.SchemaBuilder(eng)
+    got = []
+    for key, spec, w, v, u in specs:
+        qn = b.evaluation_queries([k for _r, k, _z, _c, _e in spec], b"".join(O.aff_to_bytes(c) for *_x, c, _e in spec),
+                                  b"".join(O.fe_to_bytes(e) for *_x, e in spec))
+        w_x, w_g = b.batch_multi_open(key, [r for r, *_x in spec], b"".join(O.fe_to_bytes(z) for _r, _k, z, _c, _e in spec),
+                                      qn, b"".join(O.aff_to_bytes(p) for p in w), O.fe_to_bytes(v), O.fe_to_bytes(u))
+        got.append((w_x, w_g))
+    lam_b = O.fe_to_bytes(lam)
+    acc_x, acc_g = got[0]
+    for w_x, w_g in got[1:]:
+        acc_x, acc_g = acc_x * b.scalar(lam_b) + w_x, acc_g * b.scalar(lam_b) + w_g     # verify.rs:926-938
+    assert acc_x.estimate() + acc_g.estimate() == agg.w_x.estimate() + agg.w_g.estimate()
+    left, right, names = b.evaluate_multiopen_proof(acc_x, acc_g)
+    assert left + right == S.final_pair_bytes(want_l, want_r) and names == want_names
+    # wrong number of W commitments: the reference's assert_eq! (multiopen.rs:48)
+    key, spec, w, v, u = specs[0]
+    qn = b.evaluation_queries([k for _r, k, _z, _c, _e in spec], b"".join(O.aff_to_bytes(c) for *_x, c, _e in spec),
+                              b"".join(O.fe_to_bytes(e) for *_x, e in spec))
+    with pytest.raises(pkg.H2AggError):
+        b.batch_multi_open(key, [r for r, *_x in spec], b"".join(O.fe_to_bytes(z) for _r, _k, z, _c, _e in spec),
+                           qn, b"".join(O.aff_to_bytes(p) for p in w[:2]), O.fe_to_bytes(v), O.fe_to_bytes(u))
+    b.close()
