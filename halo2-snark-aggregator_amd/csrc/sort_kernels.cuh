@@ -232,7 +232,7 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_sort(const uint32_t* __restric
 }
 
 // ------------------------------------------------------------------ LDS-staged variants (n < 2^idx_bits)
-// Round-1 PMC (profiles/r01_pmc_write.txt): the direct versions above write 563 MB (level 1) and 426 MB
+// Round-1 PMC (profiles/earlier/r01_pmc_write.txt): the direct versions above write 563 MB (level 1) and 426 MB
 // (level 2) for 96 MB + 64 MB of payload — single 4- and 2-byte stores to ~1000 open runs per workgroup are
 // evicted from L2 as partial lines.  Here the keys of a tile (level 1) / of a partition (level 2) are
 // first ordered in LDS and then leave the CU as contiguous runs written by consecutive lanes.
