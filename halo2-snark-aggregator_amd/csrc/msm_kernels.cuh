@@ -175,33 +175,68 @@ __global__ void __launch_bounds__(BLOCK) k_msm_window_sum(const uint8_t* __restr
     if (threadIdx.x == 0) xyzz_store(wsum + XYZZ_BYTES * (size_t)w, tot);
 }
 
+// ---- 4-lane cooperative doubling for the serial Horner tail --------------------------------------------
+// A doubling is 9 field products on one lane (~2 300 VALU instructions, nothing to overlap with).  Its
+// dependency graph is only three products deep:   {V = U^2, XX = X^2} -> {W = U*V, S = X*V, M^2, V*ZZ}
+// -> {M*(S - X3), W*(4p - Y), W*ZZZ}.  Four lanes hold the point replicated, each computes one product per
+// level (operands picked by lane id) and the results are broadcast back with cross-lane shuffles, so the
+// chain is 3 products deep instead of 9.  Measured: k_msm_final 1.20 -> 0.97 ms at c = 16 (for a lone wave
+// every instruction costs an issue slot, so the selects and shuffles are not free; a v_readlane variant that
+// broadcasts through SGPRs was slower: 1.27 ms).
+FP_INLINE Fq fq_bcast4(const Fq& v, int src) {
+    Fq r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = (uint32_t)__shfl((int)v.l[i], src, 4);
+    return r;
+}
+FP_INLINE Fq fq_sel4(int lane, const Fq& a, const Fq& b, const Fq& c, const Fq& d) {
+    Fq r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = lane == 0 ? a.l[i] : (lane == 1 ? b.l[i] : (lane == 2 ? c.l[i] : d.l[i]));
+    return r;
+}
+// 2 * p with p replicated in the 4 lanes of a group; `lane` = lane index within the group.  Same formulas
+// and bounds as xyzz_double (dbl-2008-s-1), Y3 = M*(S - X3 + 6p) + W*(4p - Y) as a sum of two products [4].
+FP_INLINE G1XYZZ xyzz_double_par4(const G1XYZZ& p, int lane) {
+    if (p.is_identity()) return p;  // uniform: the state is replicated
+    const Fq u = FQ_DBL(p.y);                                           // [8]
+    const Fq r1 = FQ_SQR(lane == 0 ? u : p.x);                          // lane 0: V = U^2, lane 1: XX = X^2
+    const Fq v = fq_bcast4(r1, 0), xx = fq_bcast4(r1, 1);
+    const Fq m = fp_triple<FqParams>(xx);                               // [6]
+    const Fq r2 = FQ_MUL(fq_sel4(lane, u, p.x, m, v), fq_sel4(lane, v, v, m, p.zz));
+    const Fq w = fq_bcast4(r2, 0), s = fq_bcast4(r2, 1), mm = fq_bcast4(r2, 2), zz3 = fq_bcast4(r2, 3);
+    G1XYZZ o;
+    o.x = fp_sub2<4, FqParams>(mm, s);                                  // [6]
+    const Fq d = FQ_SUB(6, s, o.x);                                     // [8]
+    const Fq ny = fp_neg<4, FqParams>(p.y);                             // [4]
+    const Fq r3 = FQ_MUL(fq_sel4(lane, m, w, w, w), fq_sel4(lane, d, ny, p.zzz, p.zzz));
+    o.y = FQ_ADD(fq_bcast4(r3, 0), fq_bcast4(r3, 1));                   // [2] + [2] -> [4]
+    o.zz = zz3;
+    o.zzz = fq_bcast4(r3, 2);
+    return o;
+}
+
 // result = sum_w 2^(c*w) * wsum[w]  (Horner, top window first).  Writes the XYZZ value (Montgomery, for
 // on-device consumers such as the eval tail) and the canonical Jacobian encoding of the C ABI.
-__global__ void k_msm_final(const uint8_t* __restrict__ wsum, int c, int W, uint8_t* __restrict__ out_xyzz,
-                            uint8_t* __restrict__ out_jac) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    // one wave carries the whole latency chain: let it win issue arbitration against the bulk kernels of the
+// One wave; the point is replicated across lanes, lanes cooperate in groups of 4 on every doubling.
+__global__ void __launch_bounds__(64) k_msm_final(const uint8_t* __restrict__ wsum, int c, int W,
+                                                  uint8_t* __restrict__ out_xyzz, uint8_t* __restrict__ out_jac) {
+    if (blockIdx.x != 0) return;
+    // this wave carries the whole latency chain: let it win issue arbitration against the bulk kernels of the
     // next MSM that share its SIMD in overlap mode
     __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x & 3;
     G1XYZZ acc = xyzz_load(wsum + XYZZ_BYTES * (size_t)(W - 1));
-    // Everything here is wave-uniform, and hipcc would otherwise move the whole chain onto the scalar
-    // ALU (s_mul_hi_u32 sequences: 3.4 ms for 240 doublings, profiles/r01_kernel_stats_baseline_u32x8.txt).
-    // Pin the accumulator in VGPRs so the 64-bit multiply-adds run on the vector ALU.
-#pragma unroll
-    for (int i = 0; i < NL; ++i) {
-        asm volatile("" : "+v"(acc.x.l[i]));
-        asm volatile("" : "+v"(acc.y.l[i]));
-        asm volatile("" : "+v"(acc.zz.l[i]));
-        asm volatile("" : "+v"(acc.zzz.l[i]));
-    }
 #pragma unroll 1
     for (int w = W - 2; w >= 0; --w) {
 #pragma unroll 1
-        for (int k = 0; k < c; ++k) acc = xyzz_double(acc);
+        for (int k = 0; k < c; ++k) acc = xyzz_double_par4(acc, lane);
         acc = xyzz_add(acc, xyzz_load(wsum + XYZZ_BYTES * (size_t)w));
     }
-    if (out_xyzz) xyzz_store(out_xyzz, acc);
-    if (out_jac) jac_store_canonical(out_jac, jac_from_xyzz(acc));
+    if (threadIdx.x == 0) {
+        if (out_xyzz) xyzz_store(out_xyzz, acc);
+        if (out_jac) jac_store_canonical(out_jac, jac_from_xyzz(acc));
+    }
 }
 
 // eval()'s tail (evaluation.rs:198-200): acc = msm_result + sum of the scalar-less points (canonical affine)
