@@ -73,6 +73,7 @@ def load_library():
         "h2agg_bases_download": (i32, [ctxp, u64, sz, sz, vp]),
         "h2agg_bases_free": (i32, [ctxp, u64]),
         "h2agg_g1_msm_preloaded": (i32, [ctxp, u64, u8p, sz, vp]),
+        "h2agg_instance_commitment": (i32, [ctxp, u64, u8p, sz, sz, vp]),
         "h2agg_g1_msm_device": (i32, [ctxp, u64, vp, sz, vp]),
         "h2agg_g1_msm_device_async": (i32, [ctxp, u64, vp, sz, vp]),
         "h2agg_schema_create": (i32, [ctxp, C.POINTER(C.c_void_p)]),
@@ -232,6 +233,12 @@ class H2Agg:
     def g1_msm_preloaded(self, handle: int, scalars: bytes) -> bytes:
         out = C.create_string_buffer(96)
         self._check(self._lib.h2agg_g1_msm_preloaded(self._ctx, handle, scalars, len(scalars) // 32, out))
+        return out.raw
+
+    def instance_commitment(self, g_lagrange_handle: int, instance: bytes, max_len: int) -> bytes:
+        out = C.create_string_buffer(96)
+        self._check(self._lib.h2agg_instance_commitment(self._ctx, g_lagrange_handle, instance, len(instance) // 32,
+                                                        max_len, out))
         return out.raw
 
     def g1_msm_device(self, handle: int, d_scalars_ptr: int, n: int) -> bytes:

@@ -733,6 +733,18 @@ int h2agg_g1_msm_preloaded(h2agg_ctx* c, uint64_t handle, const uint8_t* scalars
     return h2agg_g1_msm_device(c, handle, c->in_b.p, n, out);
 }
 
+// assign_instance_commitment for one instance column (verify.rs:601-603, 623-639)
+int h2agg_instance_commitment(h2agg_ctx* c, uint64_t g_lagrange_handle, const uint8_t* instance, size_t len,
+                              size_t max_len, uint8_t out_jac[96]) {
+    TRY(bind(c));
+    if (!out_jac) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    set_identity_jac(out_jac);
+    if (len > max_len)
+        return fail(c, H2AGG_ERR_INVALID, "assert!(instance.len() <= params.n() - (blinding_factors + 1)) failed (verify.rs:601-603)");
+    if (len == 0) return H2AGG_OK;  // None => pchip.assign_const(identity)  (verify.rs:638)
+    return h2agg_g1_msm_preloaded(c, g_lagrange_handle, instance, len, out_jac);
+}
+
 int h2agg_g1_msm(h2agg_ctx* c, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[96]) {
     TRY(bind(c));
     if (!out) return fail(c, H2AGG_ERR_INVALID, "null buffer");

@@ -126,6 +126,12 @@ int h2agg_bases_free(h2agg_ctx* ctx, uint64_t handle);
 /* scalars in host memory, bases preloaded; uses the first n bases of the table */
 int h2agg_g1_msm_preloaded(h2agg_ctx* ctx, uint64_t bases_handle, const uint8_t* scalars, size_t n,
                            uint8_t out_jac[96]);
+/* replaces: the per-column body of assign_instance_commitment
+ * (halo2-snark-aggregator-api/src/systems/halo2/verify.rs:601-603 bound, :623-635 sum inst_i * g_lagrange[i],
+ * :637-640 identity for an empty column) against a preloaded `params.g_lagrange` table.  max_len =
+ * params.n() - (blinding_factors + 1); len > max_len -> H2AGG_ERR_INVALID (the reference's assert!). */
+int h2agg_instance_commitment(h2agg_ctx* ctx, uint64_t g_lagrange_handle, const uint8_t* instance, size_t len,
+                              size_t max_len, uint8_t out_jac[96]);
 /* scalars in DEVICE memory (n x 32 B canonical); synchronous, result to host */
 int h2agg_g1_msm_device(h2agg_ctx* ctx, uint64_t bases_handle, const void* d_scalars, size_t n,
                         uint8_t out_jac[96]);

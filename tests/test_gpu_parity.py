@@ -259,3 +259,27 @@ def test_msm_sort_variants(eng, sub_bits, tile):
         eng.msm_configure()
         eng.msm_configure_sort()
 
+
+
+def test_instance_commitment(eng, pkg):
+    """assign_instance_commitment for one column (verify.rs:601-603, 623-640): sum inst_i * g_lagrange[i] against a
+    preloaded table, identity for an empty column, the length bound as an error."""
+    rng = O.SplitMix64(7000)
+    n_table, blinding = 64, 5
+    ks = rand_frs(rng, n_table)
+    g_lagrange = points_from_scalars(ks)
+    h = eng.bases_upload(g_lagrange)
+    try:
+        max_len = n_table - (blinding + 1)
+        for m in (1, 7, max_len):
+            inst = rand_frs(rng, m)
+            got = norm(eng, eng.instance_commitment(h, fr_bytes(inst), max_len))
+            acc = O.INF
+            for i, s in enumerate(inst):                       # the reference loop: scalar_mul_constant + add
+                acc = O.add(acc, O.scalar_mul(s, O.aff_from_bytes(g_lagrange[64 * i:64 * i + 64])))
+            assert got == O.aff_to_bytes(acc)
+        assert norm(eng, eng.instance_commitment(h, b"", max_len)) == bytes(64)
+        with pytest.raises(pkg.H2AggError):
+            eng.instance_commitment(h, fr_bytes(rand_frs(rng, max_len + 1)), max_len)
+    finally:
+        eng.bases_free(h)
