@@ -155,6 +155,7 @@ def main():
     ap.add_argument("--seg", type=int, default=0)
     ap.add_argument("--sub-bits", type=int, default=0)
     ap.add_argument("--tile", type=int, default=0)
+    ap.add_argument("--glv", type=int, default=0, help="-1: off, 0/1: on (endomorphism split of the scalars)")
     ap.add_argument("--cpu-sample", type=int, default=1 << 16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the Horner tail in-stream (latency mode)")
@@ -185,6 +186,8 @@ def main():
     eng.set_stream(stream.cuda_stream)
     if args.window or args.seg:
         eng.msm_configure(window_bits=args.window, reduce_segment=args.seg)
+    if args.glv:
+        eng.msm_configure_glv(args.glv)
     if args.sub_bits or args.tile:
         eng.msm_configure_sort(args.sub_bits, args.tile)
     if not args.no_overlap:
@@ -291,6 +294,7 @@ def main():
                 "points_per_msm": n,
                 "window_bits": args.window or "auto",
                 "tail_overlap": not args.no_overlap,
+                "glv": args.glv >= 0,
                 "proofs_per_sec": world * args.steps / dt_max,
                 "exchange": "none (1 GPU)" if world == 1 else "1 all-gather of %d x 96 B + local fold" % world,
                 "bases_generate_s": t_gen,

@@ -49,7 +49,7 @@ struct h2agg_ctx {
     // grow-only device workspace
     DevBuf in_a, in_b, in_c, out, tmp_bases;                      // host-buffer entry points
     DevBuf hist, offs, pmeta, item_idx, item_sub, order, entries, buckets, segsum, wsum, big_list, big_keys, big_part,
-        small;  // MSM
+        glv_buf, small;  // MSM
     uint32_t* d_flags = nullptr;      // in `small`: [0] status flags, [1] big_count
     uint8_t* d_res_xyzz = nullptr;    // in `small` + 64
     uint8_t* d_res_jac = nullptr;     // in `small` + 256
@@ -60,6 +60,7 @@ struct h2agg_ctx {
 
     // tuning
     int cfg_c = 0, cfg_seg = 0, cfg_big = 0, cfg_sub_bits = 0, cfg_tile = 0;
+    int cfg_glv = 0;   // 0 = auto (on), 1 = on, -1 = off
     bool cfg_no_stage = false, cfg_stage_l1 = false, staged_attr_set = false;
 
     // optional overlap of the serial tail (k_msm_final) of MSM k with the bulk of MSM k+1
@@ -139,28 +140,29 @@ int finish(h2agg_ctx* c) {
     return H2AGG_OK;
 }
 
-// bits of the scalar that fall into the top window (a narrow top window means a few huge buckets)
-int top_window_bits(int c) {
-    const int W = (255 + c - 1) / c;
-    return 254 - c * (W - 1);
-}
-int choose_window(size_t n) {
+// bits of the scalar that fall into the top window (a narrow top window means a few huge buckets).
+// plain: 254-bit scalars, W*c >= 255; GLV: 127-bit magnitudes, W*c >= 128
+int window_count(int c, bool glv) { return glv ? (128 + c - 1) / c : (255 + c - 1) / c; }
+int top_window_bits(int c, bool glv) { return (glv ? 127 : 254) - c * (window_count(c, glv) - 1); }
+int choose_window(size_t n, bool glv) {
+    size_t m = glv ? 2 * n : n;  // points per window
     int lg = 0;
-    while (((size_t)1 << (lg + 1)) <= n) ++lg;
+    while (((size_t)1 << (lg + 1)) <= m) ++lg;
     int c = lg - 4;
     if (c < 3) c = 3;
     if (c > 16) c = 16;
-    if (n >= 4096 && top_window_bits(c) < 6) {  // e.g. c = 14 -> 2 bits, c = 12 -> 2, c = 11 -> 1
-        if (c < 16 && top_window_bits(c + 1) >= 6) c += 1;
-        else if (c > 3 && top_window_bits(c - 1) >= 6) c -= 1;
+    if (n >= 4096 && top_window_bits(c, glv) < 6) {  // e.g. plain c = 14 -> 2 bits; GLV c = 14 -> 1 bit
+        if (c < 16 && top_window_bits(c + 1, glv) >= 6) c += 1;
+        else if (c > 3 && top_window_bits(c - 1, glv) >= 6) c -= 1;
     }
     return c;
 }
 
 MsmPlan make_plan(const h2agg_ctx* c, size_t n) {
     MsmPlan p;
-    p.c = c->cfg_c ? c->cfg_c : choose_window(n);
-    p.W = (255 + p.c - 1) / p.c;
+    p.glv = c->cfg_glv >= 0;
+    p.c = c->cfg_c ? c->cfg_c : choose_window(n, p.glv);
+    p.W = window_count(p.c, p.glv);
     p.NB = 1u << (p.c - 1);
     p.NBT = (uint32_t)p.W * p.NB;
     uint32_t seg = c->cfg_seg ? (uint32_t)c->cfg_seg : 8u;
@@ -231,9 +233,9 @@ int join_tails(h2agg_ctx* c) {
 // The MSM proper.  d_bases: Montgomery affine table; d_scalars: canonical 32-B scalars (device).
 // Result: c->d_res_xyzz (Montgomery XYZZ) and, if d_out_jac != nullptr, canonical Jacobian there.
 int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size_t n, uint8_t* d_out_jac) {
-    if (n >= ((size_t)1 << 31)) return fail(c, H2AGG_ERR_INVALID, "n must be < 2^31");
+    if (n >= ((size_t)1 << 30)) return fail(c, H2AGG_ERR_INVALID, "n must be < 2^30");
     const MsmPlan p = make_plan(c, n);
-    const size_t nent = n * (size_t)p.W;
+    const size_t nent = n * (size_t)p.W * (p.glv ? 2 : 1);   // bucket insertions
     if (nent >= ((size_t)1 << 32)) return fail(c, H2AGG_ERR_INVALID, "n * windows must be < 2^32");
     SortPlan sp;
     const int want_sub = c->cfg_sub_bits ? c->cfg_sub_bits : SORT_SUB_BITS;
@@ -246,10 +248,12 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     sp.PW = (uint32_t)p.W * sp.ppw;
     sp.tile = c->cfg_tile ? (uint32_t)c->cfg_tile : 2048u;
     // packed-item staged path: index field of 31 - sub_bits bits, a tile's keys must fit the LDS stage
-    const int idx_bits = 31 - sp.sub_bits;
+    sp.glv = p.glv;
+    const int idx_bits = 30 - sp.sub_bits;
     bool staged = !c->cfg_no_stage && n <= ((size_t)1 << idx_bits);
-    if (staged && c->cfg_stage_l1 && (size_t)sp.tile * p.W > (size_t)STAGE_ITEMS)
-        sp.tile = (uint32_t)(STAGE_ITEMS / p.W);
+    const size_t keys_per_scalar = (size_t)p.W * (p.glv ? 2 : 1);
+    if (staged && c->cfg_stage_l1 && (size_t)sp.tile * keys_per_scalar > (size_t)STAGE_ITEMS)
+        sp.tile = (uint32_t)(STAGE_ITEMS / keys_per_scalar);
     if (staged && sp.tile < (uint32_t)BLOCK) staged = false;
     if (sp.PW > (uint32_t)SORT_MAX_PW) return fail(c, H2AGG_ERR_INVALID, "too many sort partitions");
     const uint32_t nseg_total = (uint32_t)p.W * p.spw;
@@ -293,6 +297,13 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     const unsigned ntiles = (unsigned)((n + sp.tile - 1) / sp.tile);
     profile_begin_call(c);
 
+    if (p.glv) {  // k = k1 + lambda*k2: the sort below reads the decomposed words instead of the scalars
+        TRY(ensure(c, c->glv_buf, n * 32));
+        StageTimer t(c, ST_PART_COUNT);
+        hipLaunchKernelGGL(k_glv_decompose, dim3(grid_for(c, n)), dim3(BLOCK), 0, st, d_scalars, n,
+                           (uint8_t*)c->glv_buf.p, c->d_flags);
+        d_scalars = (const uint8_t*)c->glv_buf.p;
+    }
     {
         StageTimer t(c, ST_PART_COUNT);
         HIP_TRY(c, hipMemsetAsync(meta, 0, 12288 * 4, st));
@@ -476,7 +487,7 @@ void h2agg_destroy(h2agg_ctx* c) {
     if (c->tail_stream) hipStreamSynchronize(c->tail_stream);
     DevBuf* bufs[] = {&c->in_a,  &c->in_b,     &c->in_c,     &c->out,   &c->tmp_bases, &c->hist,
                       &c->offs,  &c->pmeta,    &c->item_idx, &c->item_sub, &c->order,  &c->entries,
-                      &c->buckets, &c->segsum, &c->wsum,     &c->big_list, &c->big_keys, &c->big_part, &c->small};
+                      &c->buckets, &c->segsum, &c->wsum,     &c->big_list, &c->big_keys, &c->big_part, &c->glv_buf, &c->small};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     for (auto& kv : c->tables)
@@ -811,6 +822,13 @@ int h2agg_msm_configure(h2agg_ctx* c, int window_bits, int reduce_segment, int b
     c->cfg_c = window_bits;
     c->cfg_seg = reduce_segment;
     c->cfg_big = big_bucket_threshold;
+    return H2AGG_OK;
+}
+
+int h2agg_msm_configure_glv(h2agg_ctx* c, int mode) {
+    if (!c) return H2AGG_ERR_INVALID;
+    if (mode < -1 || mode > 1) return fail(c, H2AGG_ERR_INVALID, "mode must be -1 (off), 0 (auto) or 1 (on)");
+    c->cfg_glv = mode;
     return H2AGG_OK;
 }
 

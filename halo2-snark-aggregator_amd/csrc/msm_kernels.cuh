@@ -30,12 +30,19 @@ struct MsmPlan {
     uint32_t seg;   // buckets per reduce segment (power of two, <= NB)
     uint32_t spw;   // segments per window = NB / seg
     uint32_t big;   // bucket length above which a workgroup takes the bucket
+    bool glv;       // scalars split by the endomorphism: W*c >= 128, two insertions per (point, window)
 };
 
 // ------------------------------------------------------------------ bucket accumulation
 FP_INLINE G1Affine msm_gather(const uint8_t* __restrict__ bases, uint32_t e) {
-    G1Affine p = affine_load(bases + 64 * (size_t)(e & 0x7fffffffu));
-    return (e >> 31) ? affine_neg(p) : p;
+    G1Affine p = affine_load(bases + 64 * (size_t)(e & ENT_IDX));
+    if (e & ENT_ENDO) {  // phi(P) = (beta * x, y); the identity (0, 0) maps to itself
+        Fq beta;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) beta.l[i] = GlvConst::BETA_MONT[i];
+        p.x = FQ_MUL(p.x, beta);                          // 2*1/169 + 1 -> [2]
+    }
+    return (e & ENT_NEG) ? affine_neg(p) : p;
 }
 
 // Buckets longer than `big` are cut into chunks of BIG_CHUNK entries, one workgroup per chunk (a narrow top

@@ -32,27 +32,186 @@ struct SortPlan {
     uint32_t ppw;      // partitions per window = NB >> sub_bits
     uint32_t PW;       // partitions = W * ppw (<= SORT_MAX_PW)
     uint32_t tile;     // scalars per level-1 workgroup
+    bool glv;          // `scalars` are glv_decompose() words
 };
 
-// Signed-digit recode of a canonical scalar; calls f(window, bucket_index(0-based), negative) for every
-// non-zero digit.  Digits lie in [-2^(c-1), 2^(c-1)]; W*c >= 255 guarantees no carry out of the top window.
-template <class F>
-FP_INLINE void msm_for_each_digit(U256 s, int c, int W, F&& f) {
-    const uint32_t mask = (1u << c) - 1u;
-    const uint32_t half = 1u << (c - 1);
-    uint32_t carry = 0;
-#pragma unroll 1
-    for (int w = 0; w < W; ++w) {
-        uint32_t raw = (s.w[0] & mask) + carry;
+// ------------------------------------------------------------------ GLV (endomorphism) decomposition
+// BN254 G1 has the endomorphism phi(x, y) = (beta*x, y) = lambda*(x, y).  A scalar k splits as
+// k = k1 + lambda*k2 (mod r) with |k1|, |k2| < 2^127, so s*P = k1*P + k2*phi(P): twice the points, half the
+// windows — the bucket additions stay 16 per point at c = 16, but the bucket reduction and the serial Horner
+// tail (c doublings per window) are halved.  Any integers (c1, c2) give an exact congruence; the rounding
+// constants below only control the size: c_i is within 0.6 of the real solution, so
+// |k1| <= 0.6 (a1 + a2) < 2^126.4 and |k2| <= 0.6 (|b1| + b2) < 2^126.4  (lattice basis from the extended
+// Euclid on (r, lambda); a1 + b1*lambda = a2 + b2*lambda = 0 mod r; b1 < 0).  The kernel still checks the
+// 127-bit bound and raises FLAG_NONCANONICAL if it is ever violated.
+//   lambda = 0x30644e72e131a029048b6e193fd84104cc37a73fec2bc5e9b8ca0b2d36636f23
+//   beta   = 0x30644e72e131a0295e6dd9e7e0acccb0c28f069fbb966e3de4bd44e5607cfd48
+struct GlvConst {
+    static constexpr uint32_t A1[4] = {0x7d4f1128u, 0x8211bbebu, 0xeeb859fcu, 0x6f4d8248u};
+    static constexpr uint32_t B1N[2] = {0x94d213e3u, 0x89d32568u};   // -b1
+    static constexpr uint32_t A2[2] = {0x94d213e3u, 0x89d32568u};
+    static constexpr uint32_t B2[4] = {0x1221250bu, 0x0be4e154u, 0xeeb859fdu, 0x6f4d8248u};
+    static constexpr uint32_t G1[5] = {0x00ff6565u, 0x5398fd03u, 0xa773d2d2u, 0x4ccef014u, 0x00000002u};  // round(2^256 b2 / r)
+    static constexpr uint32_t G2[3] = {0xc7e0b3d7u, 0xd91d232eu, 0x00000002u};                            // round(2^256 |b1| / r)
+    static constexpr uint32_t BETA_MONT[9] = {0x18ccb791u, 0x175b1c3au, 0x0b83d6e2u, 0x0e8ed071u, 0x1282bee2u,
+                                              0x04220e84u, 0x1fe4017fu, 0x15084d4au, 0x00169119u};
+};
+
+// out[0 .. NA+NB) = a * b  (little-endian 32-bit words, schoolbook with 64-bit column sums)
+template <int NA, int NB>
+FP_INLINE void mw_mul(const uint32_t (&a)[NA], const uint32_t (&b)[NB], uint32_t (&out)[NA + NB]) {
+    uint64_t carry = 0;
 #pragma unroll
-        for (int i = 0; i < 7; ++i) s.w[i] = (s.w[i] >> c) | (s.w[i + 1] << (32 - c));
-        s.w[7] >>= c;
-        const bool neg = raw > half;
-        carry = neg ? 1u : 0u;
-        const uint32_t mag = neg ? ((1u << c) - raw) : raw;
-        if (mag != 0) f(w, mag - 1u, neg);
+    for (int k = 0; k < NA + NB; ++k) {
+        uint64_t lo = carry & 0xffffffffu, hi = carry >> 32;  // carry can exceed 32 bits: keep it as two halves
+#pragma unroll
+        for (int i = 0; i < NA; ++i) {
+            const int j = k - i;
+            if (j >= 0 && j < NB) {
+                const uint64_t pr = (uint64_t)a[i] * b[j];
+                lo += pr & 0xffffffffu;
+                hi += pr >> 32;
+            }
+        }
+        out[k] = (uint32_t)lo;
+        carry = hi + (lo >> 32);
     }
 }
+// r -= x (8 words, wraps mod 2^256); x given with NX <= 8 words
+template <int NX>
+FP_INLINE void mw_sub8(uint32_t (&r)[8], const uint32_t (&x)[NX]) {
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const uint64_t d = (uint64_t)r[i] - (i < NX ? x[i] : 0u) - br;
+        r[i] = (uint32_t)d;
+        br = (d >> 32) & 1;
+    }
+}
+// canonical k -> 256-bit word: low 128 = |k1| | sign1 << 127, high 128 = |k2| | sign2 << 127.  Returns false
+// if a magnitude does not fit 127 bits (cannot happen for k < r, see above).
+FP_INLINE bool glv_decompose(const U256& k, U256& d) {
+    // c1 = (k*G1 + 2^255) >> 256, c2 = (k*G2 + 2^255) >> 256
+    uint32_t t1[13], t2[11];
+    mw_mul<8, 5>(k.w, GlvConst::G1, t1);
+    mw_mul<8, 3>(k.w, GlvConst::G2, t2);
+    uint32_t c1[4], c2[2];
+    {
+        uint64_t cy = (uint64_t)(t1[7] >> 31);  // + 2^255 rounding: carry into word 8 iff bit 255 is set
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            cy += t1[8 + i];
+            c1[i] = (uint32_t)cy;
+            cy >>= 32;
+        }
+        cy = (uint64_t)(t2[7] >> 31);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            cy += t2[8 + i];
+            c2[i] = (uint32_t)cy;
+            cy >>= 32;
+        }
+    }
+    // k1 = k - c1*a1 - c2*a2      k2 = c1*|b1| - c2*b2     (two's complement, 256 bits)
+    uint32_t p11[8], p22[4], q1[6], q2[6];
+    mw_mul<4, 4>(c1, GlvConst::A1, p11);
+    mw_mul<2, 2>(c2, GlvConst::A2, p22);
+    mw_mul<4, 2>(c1, GlvConst::B1N, q1);
+    mw_mul<2, 4>(c2, GlvConst::B2, q2);
+    uint32_t k1[8], k2[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        k1[i] = k.w[i];
+        k2[i] = i < 6 ? q1[i] : 0u;
+    }
+    mw_sub8<8>(k1, p11);
+    mw_sub8<4>(k1, p22);
+    mw_sub8<6>(k2, q2);
+    bool ok = true;
+    uint32_t* halves[2] = {k1, k2};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        uint32_t* v = halves[h];
+        const uint32_t neg = v[7] >> 31;
+        if (neg) {  // magnitude = -v
+            uint64_t cy = 1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                cy += (uint32_t)~v[i];
+                v[i] = (uint32_t)cy;
+                cy >>= 32;
+            }
+        }
+        ok = ok && ((v[4] | v[5] | v[6] | v[7]) == 0) && ((v[3] >> 31) == 0);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) d.w[4 * h + i] = v[i];
+        d.w[4 * h + 3] |= neg << 31;
+    }
+    return ok;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_glv_decompose(const uint8_t* __restrict__ scalars, size_t n,
+                                                         uint8_t* __restrict__ out, uint32_t* flags) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        U256 k = u256_load(scalars + 32 * i);
+        uint32_t bad = !u256_is_canonical_fr(k);
+        U256 d;
+        bad |= !glv_decompose(k, d);
+        if (bad) atomicOr(flags, FLAG_NONCANONICAL);
+        uint4* q = reinterpret_cast<uint4*>(out + 32 * i);
+        q[0] = make_uint4(d.w[0], d.w[1], d.w[2], d.w[3]);
+        q[1] = make_uint4(d.w[4], d.w[5], d.w[6], d.w[7]);
+    }
+}
+
+// Signed-digit recode; calls f(window, bucket_index(0-based), negative, endo) for every non-zero digit.
+// Digits lie in [-2^(c-1), 2^(c-1)].  glv = false: `s` is the canonical 256-bit scalar, W*c >= 255 guarantees
+// no carry out of the top window.  glv = true: `s` is a glv_decompose() word — two sign-magnitude 127-bit
+// halves, each recoded over the same W windows (W*c >= 128), the second half flagged `endo`.
+template <class F>
+FP_INLINE void msm_for_each_digit(U256 s, int c, int W, bool glv, F&& f) {
+    const uint32_t mask = (1u << c) - 1u;
+    const uint32_t half = 1u << (c - 1);
+    if (!glv) {
+        uint32_t carry = 0;
+#pragma unroll 1
+        for (int w = 0; w < W; ++w) {
+            uint32_t raw = (s.w[0] & mask) + carry;
+#pragma unroll
+            for (int i = 0; i < 7; ++i) s.w[i] = (s.w[i] >> c) | (s.w[i + 1] << (32 - c));
+            s.w[7] >>= c;
+            const bool neg = raw > half;
+            carry = neg ? 1u : 0u;
+            const uint32_t mag = neg ? ((1u << c) - raw) : raw;
+            if (mag != 0) f(w, mag - 1u, neg, false);
+        }
+        return;
+    }
+#pragma unroll 1
+    for (int h = 0; h < 2; ++h) {
+        uint32_t m0 = s.w[4 * h], m1 = s.w[4 * h + 1], m2 = s.w[4 * h + 2], m3 = s.w[4 * h + 3];
+        const bool sgn = (m3 >> 31) != 0;
+        m3 &= 0x7fffffffu;
+        uint32_t carry = 0;
+#pragma unroll 1
+        for (int w = 0; w < W; ++w) {
+            uint32_t raw = (m0 & mask) + carry;
+            m0 = (m0 >> c) | (m1 << (32 - c));
+            m1 = (m1 >> c) | (m2 << (32 - c));
+            m2 = (m2 >> c) | (m3 << (32 - c));
+            m3 >>= c;
+            const bool neg = raw > half;
+            carry = neg ? 1u : 0u;
+            const uint32_t mag = neg ? ((1u << c) - raw) : raw;
+            if (mag != 0) f(w, mag - 1u, neg != sgn, h != 0);
+        }
+    }
+}
+
+// entry / item bit layout of the point reference
+constexpr uint32_t ENT_NEG = 0x80000000u;    // subtract the point
+constexpr uint32_t ENT_ENDO = 0x40000000u;   // use phi(point) = (beta*x, y)
+constexpr uint32_t ENT_IDX = 0x3fffffffu;
 
 // Walk this thread's scalars of the tile (index i, value s) with the NEXT scalar's two 16-byte loads already
 // in flight while the current one is recoded: the loop is otherwise one exposed memory latency per scalar.
@@ -85,8 +244,8 @@ __global__ void __launch_bounds__(BLOCK) k_part_count(const uint8_t* __restrict_
     const size_t base = (size_t)blockIdx.x * sp.tile;
     uint32_t bad = 0;
     TILE_SCALARS_BEGIN(threadIdx.x)
-        bad |= !u256_is_canonical_fr(s);
-        msm_for_each_digit(s, c, W, [&](int w, uint32_t b, bool) {
+        if (!sp.glv) bad |= !u256_is_canonical_fr(s);  // (GLV words were range-checked by k_glv_decompose)
+        msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool, bool) {
             atomicAdd(&cnt[(uint32_t)w * sp.ppw + (b >> sp.sub_bits)], 1u);
         });
     TILE_SCALARS_END
@@ -143,7 +302,7 @@ __global__ void __launch_bounds__(BLOCK) k_part_scatter(const uint8_t* __restric
     __syncthreads();
     const size_t base = (size_t)blockIdx.x * sp.tile;
     TILE_SCALARS_BEGIN(threadIdx.x)
-        msm_for_each_digit(s, c, W, [&](int w, uint32_t b, bool) {
+        msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool, bool) {
             atomicAdd(&cnt[(uint32_t)w * sp.ppw + (b >> sp.sub_bits)], 1u);
         });
     TILE_SCALARS_END
@@ -156,10 +315,10 @@ __global__ void __launch_bounds__(BLOCK) k_part_scatter(const uint8_t* __restric
     __syncthreads();
     const uint32_t submask = sp.SB - 1u;
     TILE_SCALARS_BEGIN(threadIdx.x)
-        msm_for_each_digit(s, c, W, [&](int w, uint32_t b, bool neg) {
+        msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool neg, bool endo) {
             const uint32_t p = (uint32_t)w * sp.ppw + (b >> sp.sub_bits);
             const uint32_t pos = basep[p] + atomicAdd(&cnt[p], 1u);
-            item_idx[pos] = (uint32_t)i | (neg ? 0x80000000u : 0u);
+            item_idx[pos] = (uint32_t)i | (neg ? ENT_NEG : 0u) | (endo ? ENT_ENDO : 0u);
             item_sub[pos] = (uint16_t)(b & submask);
         });
     TILE_SCALARS_END
@@ -236,7 +395,7 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_sort(const uint32_t* __restric
 // (level 2) for 96 MB + 64 MB of payload — single 4- and 2-byte stores to ~1000 open runs per workgroup are
 // evicted from L2 as partial lines.  Here the keys of a tile (level 1) / of a partition (level 2) are
 // first ordered in LDS and then leave the CU as contiguous runs written by consecutive lanes.
-// Item = sub-bucket << (idx_bits + 1) | negative << idx_bits | point index.
+// Item = sub-bucket << (idx_bits + 2) | negative << (idx_bits + 1) | endo << idx_bits | point index.
 constexpr int STAGE_ITEMS = 32768;  // 128 KiB of LDS
 
 __global__ void __launch_bounds__(BLOCK) k_part_scatter_staged(const uint8_t* __restrict__ scalars, size_t n, int c,
@@ -257,7 +416,7 @@ __global__ void __launch_bounds__(BLOCK) k_part_scatter_staged(const uint8_t* __
     __syncthreads();
     const size_t base = (size_t)blockIdx.x * sp.tile;
     TILE_SCALARS_BEGIN(tid)
-        msm_for_each_digit(s, c, W, [&](int w, uint32_t b, bool) {
+        msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool, bool) {
             atomicAdd(&len[(uint32_t)w * sp.ppw + (b >> sp.sub_bits)], 1u);
         });
     TILE_SCALARS_END
@@ -296,10 +455,10 @@ __global__ void __launch_bounds__(BLOCK) k_part_scatter_staged(const uint8_t* __
     __syncthreads();
     const uint32_t submask = sp.SB - 1u;
     TILE_SCALARS_BEGIN(tid)
-        msm_for_each_digit(s, c, W, [&](int w, uint32_t b, bool neg) {
+        msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool neg, bool endo) {
             const uint32_t p = (uint32_t)w * sp.ppw + (b >> sp.sub_bits);
             const uint32_t r = atomicAdd(&cur[p], 1u);
-            stage[lbase[p] + r] = ((b & submask) << (idx_bits + 1)) | ((neg ? 1u : 0u) << idx_bits) | (uint32_t)i;
+            stage[lbase[p] + r] = ((b & submask) << (idx_bits + 2)) | ((neg ? 2u : 0u) << idx_bits) | ((endo ? 1u : 0u) << idx_bits) | (uint32_t)i;
         });
     TILE_SCALARS_END
     __syncthreads();
@@ -323,7 +482,7 @@ __global__ void __launch_bounds__(BLOCK) k_part_scatter_packed(const uint8_t* __
     __syncthreads();
     const size_t base = (size_t)blockIdx.x * sp.tile;
     TILE_SCALARS_BEGIN(threadIdx.x)
-        msm_for_each_digit(s, c, W, [&](int w, uint32_t b, bool) {
+        msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool, bool) {
             atomicAdd(&cnt[(uint32_t)w * sp.ppw + (b >> sp.sub_bits)], 1u);
         });
     TILE_SCALARS_END
@@ -336,10 +495,10 @@ __global__ void __launch_bounds__(BLOCK) k_part_scatter_packed(const uint8_t* __
     __syncthreads();
     const uint32_t submask = sp.SB - 1u;
     TILE_SCALARS_BEGIN(threadIdx.x)
-        msm_for_each_digit(s, c, W, [&](int w, uint32_t b, bool neg) {
+        msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool neg, bool endo) {
             const uint32_t p = (uint32_t)w * sp.ppw + (b >> sp.sub_bits);
             const uint32_t pos = basep[p] + atomicAdd(&cnt[p], 1u);
-            items[pos] = ((b & submask) << (idx_bits + 1)) | ((neg ? 1u : 0u) << idx_bits) | (uint32_t)i;
+            items[pos] = ((b & submask) << (idx_bits + 2)) | ((neg ? 2u : 0u) << idx_bits) | ((endo ? 1u : 0u) << idx_bits) | (uint32_t)i;
         });
     TILE_SCALARS_END
 }
@@ -365,7 +524,7 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_sort_staged(const uint32_t* __
         for (int j = 0; j < 8; ++j) it[j] = (k0 + j * BLOCK < end) ? items[k0 + j * BLOCK] : 0u;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (k0 + j * BLOCK < end) atomicAdd(&h[it[j] >> (idx_bits + 1)], 1u);
+            if (k0 + j * BLOCK < end) atomicAdd(&h[it[j] >> (idx_bits + 2)], 1u);
     }
     __syncthreads();
     const uint32_t per = (sp.SB + BLOCK - 1) / BLOCK;
@@ -405,8 +564,8 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_sort_staged(const uint32_t* __
         for (int j = 0; j < 8; ++j) {
             const uint32_t it = itv[j];
             if (k0 + j * BLOCK >= end) continue;
-            const uint32_t r = atomicAdd(&h[it >> (idx_bits + 1)], 1u);
-            const uint32_t e = (it & idxmask) | (((it >> idx_bits) & 1u) << 31);
+            const uint32_t r = atomicAdd(&h[it >> (idx_bits + 2)], 1u);
+            const uint32_t e = (it & idxmask) | (((it >> idx_bits) & 1u) << 30) | (((it >> (idx_bits + 1)) & 1u) << 31);
             if (staged) sorted[r] = e;
             else entries[start + r] = e;  // over-long partition (skewed scalars): direct placement
         }

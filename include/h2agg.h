@@ -187,6 +187,10 @@ size_t h2agg_schema_point_list_len(h2agg_schema* s);
 /* ---- tuning / measurement -------------------------------------------------------------------------
  * window_bits: Pippenger window c in [2, 16], 0 = choose from n.  Other knobs: 0 = default. */
 int h2agg_msm_configure(h2agg_ctx* ctx, int window_bits, int reduce_segment, int big_bucket_threshold);
+/* GLV / endomorphism split of the scalars (k = k1 + lambda*k2, |k_i| < 2^127; phi(P) = (beta*x, y)): halves the
+ * number of windows — same bucket additions, half the bucket reduction and half the serial doubling chain.
+ * mode: 0 = default (on), 1 = on, -1 = off (254-bit windows). */
+int h2agg_msm_configure_glv(h2agg_ctx* ctx, int mode);
 /* Bucket-sort knobs: low bucket bits resolved per partition in LDS (4..12) and scalars per level-1
  * workgroup; 0 = default.  tile = -1 forces the two-array direct sort kernels (otherwise used only when
  * n does not fit the packed item's index field, n > 2^(31 - sub_bits)); tile = -2 additionally stages level 1

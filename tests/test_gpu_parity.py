@@ -170,29 +170,36 @@ def test_msm_vs_reference_algorithm(eng, n, kind):
     assert got == want                                    # (sum k_i s_i) G
 
 
+@pytest.mark.parametrize("glv", [1, -1])
 @pytest.mark.parametrize("c", [2, 3, 5, 8, 11, 13, 16])
-def test_msm_every_window_size(eng, c):
+def test_msm_every_window_size(eng, c, glv):
     rng = O.SplitMix64(2000 + c)
     n = 600
     bases, sb, want = _msm_case(rng, n, "edges")
     eng.msm_configure(window_bits=c)
+    eng.msm_configure_glv(glv)
     try:
         assert norm(eng, eng.g1_msm(bases, sb)) == want
     finally:
         eng.msm_configure()
+        eng.msm_configure_glv(0)
 
 
+@pytest.mark.parametrize("glv", [1, -1])
 @pytest.mark.parametrize("kind", ["equal_scalars", "small_scalars"])
-def test_msm_skewed_buckets(eng, kind):
+def test_msm_skewed_buckets(eng, kind, glv):
     rng = O.SplitMix64(3000)
     n = 3000
     bases, sb, want = _msm_case(rng, n, kind)
+    eng.msm_configure_glv(glv)
     eng.msm_configure(window_bits=8, big_bucket_threshold=64)
     try:
         assert norm(eng, eng.g1_msm(bases, sb)) == want
+        eng.msm_configure()
+        assert norm(eng, eng.g1_msm(bases, sb)) == want
     finally:
         eng.msm_configure()
-    assert norm(eng, eng.g1_msm(bases, sb)) == want
+        eng.msm_configure_glv(0)
 
 
 def test_msm_all_zero_scalars_and_identity_bases(eng):

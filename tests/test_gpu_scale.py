@@ -57,19 +57,59 @@ def test_msm_identity_and_linearity(eng, log2n):
         eng.bases_free(table)
 
 
+# Python model of csrc/sort_kernels.cuh glv_decompose (same constants), used to craft scalars
+_LAM = 0x30644e72e131a029048b6e193fd84104cc37a73fec2bc5e9b8ca0b2d36636f23
+_A1, _B1N = 147946756881789319000765030803803410728, 9931322734385697763
+_A2, _B2 = 9931322734385697763, 147946756881789319010696353538189108491
+_G1, _G2 = 0x24ccef014a773d2d25398fd0300ff6565, 0x2d91d232ec7e0b3d7
+
+
+def glv_model(k):
+    c1 = (k * _G1 + (1 << 255)) >> 256
+    c2 = (k * _G2 + (1 << 255)) >> 256
+    return k - c1 * _A1 - c2 * _A2, c1 * _B1N - c2 * _B2
+
+
+def test_glv_model_and_extremes(eng):
+    """The endomorphism split must be exact for every scalar: k1 + lambda*k2 = k (mod r), |k_i| < 2^127.
+    Checked on the model for structured values, and on the GPU through MSM parity with GLV on vs off."""
+    special = [0, 1, 2, O.R - 1, O.R - 2, _LAM, O.R - _LAM, (_LAM * _LAM) % O.R, (O.R - 1) // 2, (O.R + 1) // 2,
+               (1 << 127) - 1, 1 << 127, (1 << 128) - 1, 1 << 253, _A1, _B2, O.R - _A1, (1 << 254) % O.R]
+    rng = O.SplitMix64(31)
+    special += [rng.fr() for _ in range(2000)]
+    for k in special:
+        k1, k2 = glv_model(k)
+        assert (k1 + k2 * _LAM - k) % O.R == 0 and abs(k1) < (1 << 127) and abs(k2) < (1 << 127)
+    n = len(special)
+    ks = [rng.fr() for _ in range(n)]
+    from tests.util import points_from_scalars, fr_bytes
+    bases = points_from_scalars(ks)
+    want = O.aff_to_bytes(O.scalar_mul(sum(a * b for a, b in zip(ks, special)) % O.R, O.G1))
+    try:
+        for mode in (1, -1):
+            eng.msm_configure_glv(mode)
+            for c in (0, 7, 16):
+                eng.msm_configure(window_bits=c)
+                assert eng.g1_batch_to_affine(eng.g1_msm(bases, fr_bytes(special))) == want, (mode, c)
+    finally:
+        eng.msm_configure()
+        eng.msm_configure_glv(0)
+
+
 def test_msm_packed_sort_item_all_ones(eng):
-    """Regression (found at 2^22 points with bench.py's seed): the packed sort item of the LAST point is
-    0xFFFFFFFF when one of its digits is negative with sub-bucket SB-1 — it must not be taken for padding.
-    Reproduced with a 19-bit index field: n = 2^19, c = 14, sub_bits = 12, last scalar crafted so that
-    window 1 has raw digit 12288 (negative, magnitude 4096 -> bucket 4095 -> sub 4095)."""
-    n, c = 1 << 19, 14
+    """Regression (found at 2^22 points with bench.py's seed): the packed sort item of the LAST point can be
+    0xFFFFFFFF — sub-bucket SB-1, negative, endo, index 2^idx_bits - 1 — and must not be taken for padding.
+    Reproduced with an 18-bit index field: n = 2^18, c = 14, sub_bits = 12; the last scalar is built as
+    k1 + lambda*k2 with k2's window-1 digit raw = 12288 (negative, magnitude 4096 -> bucket 4095 -> sub 4095)
+    and the model confirms the device decomposition returns exactly (k1, k2)."""
+    n, c = 1 << 18, 14
     ks, k_np = _workload(n, 21)
     ss, _ = _workload(n, 22)
-    last = ss[-1]
-    last &= ~((1 << (2 * c)) - 1)            # clear windows 0 and 1
-    last |= 1 | (12288 << c)                  # window 0 = +1 (no carry), window 1 raw = 12288
-    ss[-1] = last % O.R
-    assert (ss[-1] >> c) & ((1 << c) - 1) == 12288
+    k1 = 5
+    k2 = 1 | (12288 << c) | (3 << (2 * c))      # window 0 = +1 (no carry), window 1 raw = 12288, window 2 = 3 (+1 carry)
+    last = (k1 + _LAM * k2) % O.R
+    assert glv_model(last) == (k1, k2)
+    ss[-1] = last
     s_np = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in ss), dtype=np.uint8).reshape(n, 32)
     dev = torch.device("cuda", 0)
     d_k = torch.from_numpy(k_np.copy()).to(dev)
@@ -78,6 +118,7 @@ def test_msm_packed_sort_item_all_ones(eng):
     want_k = sum(k * s for k, s in zip(ks, ss)) % O.R
     want = eng.g1_batch_to_affine(eng.g1_batch_scalar_mul(O.aff_to_bytes(O.G1), O.fe_to_bytes(want_k)))
     eng.msm_configure(window_bits=c)
+    eng.msm_configure_glv(1)
     try:
         for sub_bits, tile in ((12, 0), (12, -2), (12, -1)):
             eng.msm_configure_sort(sub_bits, tile)
@@ -85,4 +126,5 @@ def test_msm_packed_sort_item_all_ones(eng):
     finally:
         eng.msm_configure()
         eng.msm_configure_sort()
+        eng.msm_configure_glv(0)
         eng.bases_free(table)
