@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--sub-bits", type=int, default=0)
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--glv", type=int, default=0, help="-1: off, 0/1: on (endomorphism split of the scalars)")
+    ap.add_argument("--lpb", type=int, default=0, help="lanes per bucket in the accumulate kernel (0 = auto)")
     ap.add_argument("--cpu-sample", type=int, default=1 << 16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the Horner tail in-stream (latency mode)")
@@ -188,6 +189,8 @@ def main():
         eng.msm_configure(window_bits=args.window, reduce_segment=args.seg)
     if args.glv:
         eng.msm_configure_glv(args.glv)
+    if args.lpb:
+        eng.msm_configure_lanes_per_bucket(args.lpb)
     if args.sub_bits or args.tile:
         eng.msm_configure_sort(args.sub_bits, args.tile)
     if not args.no_overlap:
@@ -294,7 +297,9 @@ def main():
                 "points_per_msm": n,
                 "window_bits": args.window or "auto",
                 "tail_overlap": not args.no_overlap,
-                "glv": args.glv >= 0,
+                "glv": {0: "auto (off here: overlap mode and n >= 2^19; on in the aggregation leg's small MSMs)",
+                        1: "on", -1: "off"}[args.glv] if args.log2n >= 19 and not args.no_overlap else
+                       {0: "auto (on)", 1: "on", -1: "off"}[args.glv],
                 "proofs_per_sec": world * args.steps / dt_max,
                 "exchange": "none (1 GPU)" if world == 1 else "1 all-gather of %d x 96 B + local fold" % world,
                 "bases_generate_s": t_gen,

@@ -96,6 +96,7 @@ def load_library():
         "h2agg_schema_point_list_len": (C.c_size_t, [C.c_void_p]),
         "h2agg_msm_configure": (i32, [ctxp, i32, i32, i32]),
         "h2agg_msm_configure_glv": (i32, [ctxp, i32]),
+        "h2agg_msm_configure_lanes_per_bucket": (i32, [ctxp, i32]),
         "h2agg_msm_configure_sort": (i32, [ctxp, i32, i32]),
         "h2agg_msm_set_tail_overlap": (i32, [ctxp, i32]),
         "h2agg_profile_enable": (i32, [ctxp, i32]),
@@ -256,6 +257,9 @@ class H2Agg:
 
     def msm_configure_glv(self, mode: int = 0):
         self._check(self._lib.h2agg_msm_configure_glv(self._ctx, mode))
+
+    def msm_configure_lanes_per_bucket(self, lanes: int = 0):
+        self._check(self._lib.h2agg_msm_configure_lanes_per_bucket(self._ctx, lanes))
 
     def msm_configure_sort(self, sub_bits: int = 0, tile: int = 0):
         self._check(self._lib.h2agg_msm_configure_sort(self._ctx, sub_bits, tile))

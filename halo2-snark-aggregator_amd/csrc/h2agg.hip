@@ -49,7 +49,7 @@ struct h2agg_ctx {
     // grow-only device workspace
     DevBuf in_a, in_b, in_c, out, tmp_bases;                      // host-buffer entry points
     DevBuf hist, offs, pmeta, item_idx, item_sub, order, entries, buckets, segsum, wsum, big_list, big_keys, big_part,
-        glv_buf, small;  // MSM
+        glv_buf, parts, small;  // MSM
     uint32_t* d_flags = nullptr;      // in `small`: [0] status flags, [1] big_count
     uint8_t* d_res_xyzz = nullptr;    // in `small` + 64
     uint8_t* d_res_jac = nullptr;     // in `small` + 256
@@ -60,7 +60,8 @@ struct h2agg_ctx {
 
     // tuning
     int cfg_c = 0, cfg_seg = 0, cfg_big = 0, cfg_sub_bits = 0, cfg_tile = 0;
-    int cfg_glv = 0;   // 0 = auto (on), 1 = on, -1 = off
+    int cfg_glv = 0;   // 0 = auto, 1 = on, -1 = off
+    int cfg_lpb = 0;   // lanes per bucket in the accumulate kernel: 0 = auto, 1 / 2 / 4
     bool cfg_no_stage = false, cfg_stage_l1 = false, staged_attr_set = false;
 
     // optional overlap of the serial tail (k_msm_final) of MSM k with the bulk of MSM k+1
@@ -160,12 +161,16 @@ int choose_window(size_t n, bool glv) {
 
 MsmPlan make_plan(const h2agg_ctx* c, size_t n) {
     MsmPlan p;
-    p.glv = c->cfg_glv >= 0;
+    // GLV halves the latency-shaped stages (reduction, Horner tail) at the price of ~5 % more work in the
+    // accumulation (beta multiplications): a win whenever those stages are exposed — single-MSM latency mode, or
+    // small / medium MSMs — and a small loss when a large MSM's tail is hidden under the next one's bulk
+    // (profiles/r01_sweeps.txt).  auto = on unless (overlap mode and n >= 2^19).
+    p.glv = c->cfg_glv > 0 || (c->cfg_glv == 0 && !(c->tail_overlap && n >= ((size_t)1 << 19)));
     p.c = c->cfg_c ? c->cfg_c : choose_window(n, p.glv);
     p.W = window_count(p.c, p.glv);
     p.NB = 1u << (p.c - 1);
     p.NBT = (uint32_t)p.W * p.NB;
-    uint32_t seg = c->cfg_seg ? (uint32_t)c->cfg_seg : 8u;
+    uint32_t seg = c->cfg_seg ? (uint32_t)c->cfg_seg : (p.glv ? 4u : 8u);   // keep ~1024 waves in the reduction
     if (seg > p.NB) seg = p.NB;
     p.seg = seg;
     p.spw = p.NB / seg;
@@ -362,10 +367,21 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         HIP_TRY(c, hipStreamWaitEvent(st, c->ev_tail[par], 0));
         c->tail_pending[par] = false;
     }
+    // lanes per bucket: keep >= ~8192 waves in flight (3 per SIMD x 1024 SIMDs, 2-3 rounds) when buckets are few
+    uint32_t lpb = 1;
+    if (c->cfg_lpb) lpb = (uint32_t)c->cfg_lpb;
+    else
+        while (lpb < 4 && (size_t)p.NBT * lpb < (size_t)8192 * 64) lpb *= 2;
+    uint8_t* acc_out = buckets;
+    if (lpb > 1) {
+        TRY(ensure(c, c->parts, (size_t)p.NBT * lpb * XYZZ_BYTES));
+        acc_out = (uint8_t*)c->parts.p;
+    }
     {
         StageTimer t(c, ST_ACCUM);
-        hipLaunchKernelGGL(k_msm_accumulate, dim3((p.NBT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st, d_bases, entries,
-                           offs, hist, order, p.NBT, p.big, buckets, big_list, big_keys, big_count);
+        hipLaunchKernelGGL(k_msm_accumulate, dim3((unsigned)(((size_t)p.NBT * lpb + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0,
+                           st, d_bases, entries, offs, hist, order, p.NBT, p.big, lpb, acc_out, big_list, big_keys,
+                           big_count);
     }
     {
         StageTimer t(c, ST_ACCUM_BIG);
@@ -373,10 +389,13 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         const size_t cap = (size_t)c->cu_count * 4;
         if (grid > cap) grid = cap;
         hipLaunchKernelGGL(k_msm_accumulate_big, dim3((unsigned)grid), dim3(BLOCK), 0, st, d_bases, entries, offs, hist,
-                           buckets, big_part, big_list, big_count);
+                           acc_out, lpb, big_part, big_list, big_count);
         size_t gk = max_keys < cap ? max_keys : cap;
         hipLaunchKernelGGL(k_msm_big_combine, dim3((unsigned)gk), dim3(BLOCK), 0, st, big_part, big_keys, big_count,
-                           buckets);
+                           acc_out, lpb);
+        if (lpb > 1)
+            hipLaunchKernelGGL(k_msm_bucket_combine, dim3((p.NBT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st,
+                               (const uint8_t*)acc_out, hist, p.NBT, p.big, lpb, buckets);
     }
     // Everything after the bucket accumulation is latency-shaped (one wave per SIMD or less): bucket
     // reduction, per-window sums, Horner tail.  In overlap mode it runs on the context's second stream,
@@ -487,7 +506,7 @@ void h2agg_destroy(h2agg_ctx* c) {
     if (c->tail_stream) hipStreamSynchronize(c->tail_stream);
     DevBuf* bufs[] = {&c->in_a,  &c->in_b,     &c->in_c,     &c->out,   &c->tmp_bases, &c->hist,
                       &c->offs,  &c->pmeta,    &c->item_idx, &c->item_sub, &c->order,  &c->entries,
-                      &c->buckets, &c->segsum, &c->wsum,     &c->big_list, &c->big_keys, &c->big_part, &c->glv_buf, &c->small};
+                      &c->buckets, &c->segsum, &c->wsum,     &c->big_list, &c->big_keys, &c->big_part, &c->glv_buf, &c->parts, &c->small};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     for (auto& kv : c->tables)
@@ -829,6 +848,12 @@ int h2agg_msm_configure_glv(h2agg_ctx* c, int mode) {
     if (!c) return H2AGG_ERR_INVALID;
     if (mode < -1 || mode > 1) return fail(c, H2AGG_ERR_INVALID, "mode must be -1 (off), 0 (auto) or 1 (on)");
     c->cfg_glv = mode;
+    return H2AGG_OK;
+}
+int h2agg_msm_configure_lanes_per_bucket(h2agg_ctx* c, int lanes) {
+    if (!c) return H2AGG_ERR_INVALID;
+    if (lanes != 0 && lanes != 1 && lanes != 2 && lanes != 4) return fail(c, H2AGG_ERR_INVALID, "lanes must be 0, 1, 2 or 4");
+    c->cfg_lpb = lanes;
     return H2AGG_OK;
 }
 

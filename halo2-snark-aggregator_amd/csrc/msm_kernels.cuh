@@ -56,14 +56,21 @@ __global__ void __launch_bounds__(BLOCK) k_msm_accumulate(const uint8_t* __restr
                                                           const uint32_t* __restrict__ offs,
                                                           const uint32_t* __restrict__ hist,
                                                           const uint32_t* __restrict__ order, uint32_t nbt, uint32_t big,
+                                                          uint32_t lpb /* lanes per bucket: 1, 2 or 4 */,
                                                           uint8_t* __restrict__ buckets, uint32_t* __restrict__ big_list,
                                                           uint32_t* __restrict__ big_keys,
                                                           uint32_t* __restrict__ counters /* [0] chunks, [1] keys */) {
     const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
-    if (t >= nbt) return;
-    const uint32_t key = order[t];  // buckets sorted by length, longest first: a wave's lanes finish together
+    if (t >= nbt * lpb) return;
+    // buckets sorted by length, longest first: a wave's lanes finish together.  With lpb > 1 each bucket's run
+    // is cut into lpb slices handled by adjacent lanes (more, shorter waves: fills the 3072 wave slots when
+    // there are few buckets — GLV halves their number); the slices' partial sums go to buckets[key*lpb + part]
+    // and are folded by k_msm_bucket_combine.
+    const uint32_t part = t % lpb;
+    const uint32_t key = order[t / lpb];
     const uint32_t len = hist[key];
     if (len > big) {
+        if (part != 0) return;
         const uint32_t nch = (len + BIG_CHUNK - 1) / BIG_CHUNK;
         const uint32_t base = atomicAdd(&counters[0], nch);
         for (uint32_t j = 0; j < nch; ++j) {
@@ -79,16 +86,32 @@ __global__ void __launch_bounds__(BLOCK) k_msm_accumulate(const uint8_t* __restr
         }
         return;
     }
+    const uint32_t lo = (uint32_t)(((uint64_t)len * part) / lpb), hi = (uint32_t)(((uint64_t)len * (part + 1)) / lpb);
     const uint32_t* run = entries + offs[key];
     G1XYZZ acc = G1XYZZ::identity();
-    if (len) {
-        G1Affine nxt = msm_gather(bases, run[0]);
+    if (hi > lo) {
+        G1Affine nxt = msm_gather(bases, run[lo]);
 #pragma unroll 1
-        for (uint32_t k = 0; k < len; ++k) {
+        for (uint32_t k = lo; k < hi; ++k) {
             G1Affine cur = nxt;
-            if (k + 1 < len) nxt = msm_gather(bases, run[k + 1]);  // next gather in flight under this add
+            if (k + 1 < hi) nxt = msm_gather(bases, run[k + 1]);  // next gather in flight under this add
             xyzz_add_affine(acc, cur);
         }
+    }
+    xyzz_store(buckets + XYZZ_BYTES * ((size_t)key * lpb + part), acc);
+}
+
+// buckets[key] = sum of the lpb slice sums written by k_msm_accumulate (skipped for over-long buckets, whose
+// sum the chunk path writes to slot key*lpb directly)
+__global__ void __launch_bounds__(BLOCK) k_msm_bucket_combine(const uint8_t* __restrict__ parts,
+                                                              const uint32_t* __restrict__ hist, uint32_t nbt,
+                                                              uint32_t big, uint32_t lpb, uint8_t* __restrict__ buckets) {
+    const uint32_t key = blockIdx.x * BLOCK + threadIdx.x;
+    if (key >= nbt) return;
+    G1XYZZ acc = xyzz_load(parts + XYZZ_BYTES * (size_t)key * lpb);
+    if (hist[key] <= big) {
+#pragma unroll 1
+        for (uint32_t j = 1; j < lpb; ++j) acc = xyzz_add(acc, xyzz_load(parts + XYZZ_BYTES * ((size_t)key * lpb + j)));
     }
     xyzz_store(buckets + XYZZ_BYTES * (size_t)key, acc);
 }
@@ -98,7 +121,7 @@ __global__ void __launch_bounds__(BLOCK) k_msm_accumulate_big(const uint8_t* __r
                                                               const uint32_t* __restrict__ entries,
                                                               const uint32_t* __restrict__ offs,
                                                               const uint32_t* __restrict__ hist,
-                                                              uint8_t* __restrict__ buckets,
+                                                              uint8_t* __restrict__ buckets, uint32_t stride /* lpb */,
                                                               uint8_t* __restrict__ big_part,
                                                               const uint32_t* __restrict__ big_list,
                                                               const uint32_t* __restrict__ counters) {
@@ -114,7 +137,7 @@ __global__ void __launch_bounds__(BLOCK) k_msm_accumulate_big(const uint8_t* __r
         for (uint32_t k = lo + threadIdx.x; k < hi; k += BLOCK) xyzz_add_affine(acc, msm_gather(bases, run[k]));
         G1XYZZ tot = block_sum_xyzz(acc, lds);
         if (threadIdx.x == 0)
-            xyzz_store(nch == 1 ? buckets + XYZZ_BYTES * (size_t)key : big_part + XYZZ_BYTES * (size_t)b, tot);
+            xyzz_store(nch == 1 ? buckets + XYZZ_BYTES * (size_t)key * stride : big_part + XYZZ_BYTES * (size_t)b, tot);
         __syncthreads();
     }
 }
@@ -122,7 +145,7 @@ __global__ void __launch_bounds__(BLOCK) k_msm_accumulate_big(const uint8_t* __r
 __global__ void __launch_bounds__(BLOCK) k_msm_big_combine(const uint8_t* __restrict__ big_part,
                                                            const uint32_t* __restrict__ big_keys,
                                                            const uint32_t* __restrict__ counters,
-                                                           uint8_t* __restrict__ buckets) {
+                                                           uint8_t* __restrict__ buckets, uint32_t stride /* lpb */) {
     __shared__ uint32_t lds[XYZZ_WORDS * BLOCK];
     const uint32_t nkeys = counters[1];
     for (uint32_t k = blockIdx.x; k < nkeys; k += gridDim.x) {
@@ -132,7 +155,7 @@ __global__ void __launch_bounds__(BLOCK) k_msm_big_combine(const uint8_t* __rest
         for (uint32_t j = threadIdx.x; j < nch; j += BLOCK)
             acc = xyzz_add(acc, xyzz_load(big_part + XYZZ_BYTES * (size_t)(base + j)));
         G1XYZZ tot = block_sum_xyzz(acc, lds);
-        if (threadIdx.x == 0) xyzz_store(buckets + XYZZ_BYTES * (size_t)key, tot);
+        if (threadIdx.x == 0) xyzz_store(buckets + XYZZ_BYTES * (size_t)key * stride, tot);
         __syncthreads();
     }
 }

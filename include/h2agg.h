@@ -189,8 +189,11 @@ size_t h2agg_schema_point_list_len(h2agg_schema* s);
 int h2agg_msm_configure(h2agg_ctx* ctx, int window_bits, int reduce_segment, int big_bucket_threshold);
 /* GLV / endomorphism split of the scalars (k = k1 + lambda*k2, |k_i| < 2^127; phi(P) = (beta*x, y)): halves the
  * number of windows — same bucket additions, half the bucket reduction and half the serial doubling chain.
- * mode: 0 = default (on), 1 = on, -1 = off (254-bit windows). */
+ * It costs ~5 % more work in the accumulation (the beta multiplications), so mode 0 = auto turns it on
+ * unless the tail is hidden anyway (overlap mode and n >= 2^19); 1 = on, -1 = off (254-bit windows). */
 int h2agg_msm_configure_glv(h2agg_ctx* ctx, int mode);
+/* Lanes per bucket in the accumulation kernel (1, 2, 4; 0 = chosen so that at least ~8192 waves are launched). */
+int h2agg_msm_configure_lanes_per_bucket(h2agg_ctx* ctx, int lanes);
 /* Bucket-sort knobs: low bucket bits resolved per partition in LDS (4..12) and scalars per level-1
  * workgroup; 0 = default.  tile = -1 forces the two-array direct sort kernels (otherwise used only when
  * n does not fit the packed item's index field, n > 2^(31 - sub_bits)); tile = -2 additionally stages level 1

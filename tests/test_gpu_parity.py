@@ -290,3 +290,21 @@ def test_instance_commitment(eng, pkg):
             eng.instance_commitment(h, fr_bytes(rand_frs(rng, max_len + 1)), max_len)
     finally:
         eng.bases_free(h)
+
+
+@pytest.mark.parametrize("lanes", [1, 2, 4])
+@pytest.mark.parametrize("glv", [1, -1])
+def test_msm_lanes_per_bucket(eng, lanes, glv):
+    rng = O.SplitMix64(8000 + lanes)
+    n = 4000
+    for kind in ("edges", "equal_scalars"):
+        bases, sb, want = _msm_case(rng, n, kind)
+        eng.msm_configure_lanes_per_bucket(lanes)
+        eng.msm_configure_glv(glv)
+        eng.msm_configure(big_bucket_threshold=40)
+        try:
+            assert norm(eng, eng.g1_msm(bases, sb)) == want
+        finally:
+            eng.msm_configure()
+            eng.msm_configure_glv(0)
+            eng.msm_configure_lanes_per_bucket(0)
