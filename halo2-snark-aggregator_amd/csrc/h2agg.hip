@@ -51,7 +51,7 @@ struct h2agg_ctx {
     DevBuf hist, offs, pmeta, item_idx, item_sub, order, entries, buckets, segsum, wsum, big_list, big_keys, big_part,
         glv_buf, parts, small;  // MSM
     uint32_t* d_flags = nullptr;      // in `small`: [0] status flags, [1] big_count
-    uint8_t* d_res_xyzz = nullptr;    // in `small` + 64
+    uint8_t* d_res_xyzz = nullptr;    // in `small` + 1024 + 144 * slot of the LAST msm_run (see msm_run)
     uint8_t* d_res_jac = nullptr;     // in `small` + 256
     uint8_t* h_pinned = nullptr;      // 4 KiB pinned staging for small results / flags
 
@@ -67,10 +67,14 @@ struct h2agg_ctx {
     // optional overlap of the serial tail (k_msm_final) of MSM k with the bulk of MSM k+1
     bool tail_overlap = false;
     int overlap_level = 2;  // 1: only the Horner tail on the second stream; 2: reduction + window sums + tail
-    hipStream_t tail_stream = nullptr;
-    hipEvent_t ev_bulk[2] = {}, ev_tail[2] = {};
-    bool tail_pending[2] = {false, false};
-    int parity = 0;
+    // TAIL_SLOTS tail streams used round-robin, each with its own buckets / segsum / wsum set: the latency-shaped
+    // tails of consecutive MSMs overlap one another as well as the next MSMs' bulk (small MSMs are otherwise
+    // bound by one tail chain: ~0.7 ms per MSM at 2^14 points against 0.5 ms of bulk).
+    static constexpr int TAIL_SLOTS = 3;
+    hipStream_t tail_streams[TAIL_SLOTS] = {};
+    hipEvent_t ev_bulk[TAIL_SLOTS] = {}, ev_tail[TAIL_SLOTS] = {};
+    bool tail_pending[TAIL_SLOTS] = {};
+    int parity = 0;   // slot of the next MSM
 
     // profiling: a ring of per-call event sets, harvested lazily so that measuring does not serialise
     // back-to-back asynchronous MSMs
@@ -170,7 +174,8 @@ MsmPlan make_plan(const h2agg_ctx* c, size_t n) {
     p.W = window_count(p.c, p.glv);
     p.NB = 1u << (p.c - 1);
     p.NBT = (uint32_t)p.W * p.NB;
-    uint32_t seg = c->cfg_seg ? (uint32_t)c->cfg_seg : (p.glv ? 4u : 8u);   // keep ~1024 waves in the reduction
+    // segment length of the bucket reduction: ~1024 waves of running sums (profiles/r01_sweeps.txt)
+    uint32_t seg = c->cfg_seg ? (uint32_t)c->cfg_seg : (p.NBT >= (1u << 18) ? 8u : (p.NBT >= (1u << 15) ? 4u : 2u));
     if (seg > p.NB) seg = p.NB;
     p.seg = seg;
     p.spw = p.NB / seg;
@@ -226,7 +231,7 @@ void profile_harvest_all(h2agg_ctx* c) {
 
 // make everything queued on the tail stream visible to the main stream
 int join_tails(h2agg_ctx* c) {
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < h2agg_ctx::TAIL_SLOTS; ++k) {
         if (c->tail_pending[k]) {
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_tail[k], 0));
             c->tail_pending[k] = false;
@@ -239,8 +244,14 @@ int join_tails(h2agg_ctx* c) {
 // Result: c->d_res_xyzz (Montgomery XYZZ) and, if d_out_jac != nullptr, canonical Jacobian there.
 int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size_t n, uint8_t* d_out_jac) {
     if (n >= ((size_t)1 << 30)) return fail(c, H2AGG_ERR_INVALID, "n must be < 2^30");
-    const MsmPlan p = make_plan(c, n);
+    MsmPlan p = make_plan(c, n);
     const size_t nent = n * (size_t)p.W * (p.glv ? 2 : 1);   // bucket insertions
+    if (!c->cfg_big) {
+        // a lane walks a bucket alone up to `big` entries: 8x the mean keeps a denser top window (up to 4x the mean
+        // when it holds c-2 bits) out of the workgroup-per-chunk path, whose LDS tree only pays for real outliers
+        const size_t mean = nent / p.NBT;
+        if (8 * mean > p.big) p.big = (uint32_t)(8 * mean);
+    }
     if (nent >= ((size_t)1 << 32)) return fail(c, H2AGG_ERR_INVALID, "n * windows must be < 2^32");
     SortPlan sp;
     const int want_sub = c->cfg_sub_bits ? c->cfg_sub_bits : SORT_SUB_BITS;
@@ -254,7 +265,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     sp.tile = c->cfg_tile ? (uint32_t)c->cfg_tile : 2048u;
     // packed-item staged path: index field of 31 - sub_bits bits, a tile's keys must fit the LDS stage
     sp.glv = p.glv;
-    const int idx_bits = 30 - sp.sub_bits;
+    const int idx_bits = (p.glv ? 30 : 31) - sp.sub_bits;   // packed item: sub | neg | (endo) | idx
     bool staged = !c->cfg_no_stage && n <= ((size_t)1 << idx_bits);
     const size_t keys_per_scalar = (size_t)p.W * (p.glv ? 2 : 1);
     if (staged && c->cfg_stage_l1 && (size_t)sp.tile * keys_per_scalar > (size_t)STAGE_ITEMS)
@@ -273,9 +284,9 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     TRY(ensure(c, c->entries, nent * 4));
     // buckets / segsum / wsum are double-buffered: in overlap mode the reduction of MSM k (tail stream)
     // runs while MSM k+1 fills the other set
-    TRY(ensure(c, c->buckets, 2 * (size_t)p.NBT * XYZZ_BYTES));
-    TRY(ensure(c, c->segsum, 2 * (size_t)nseg_total * XYZZ_BYTES));
-    TRY(ensure(c, c->wsum, 2 * (size_t)p.W * XYZZ_BYTES));
+    TRY(ensure(c, c->buckets, h2agg_ctx::TAIL_SLOTS * (size_t)p.NBT * XYZZ_BYTES));
+    TRY(ensure(c, c->segsum, h2agg_ctx::TAIL_SLOTS * (size_t)nseg_total * XYZZ_BYTES));
+    TRY(ensure(c, c->wsum, h2agg_ctx::TAIL_SLOTS * (size_t)p.W * XYZZ_BYTES));
     const size_t max_slots = nent / BIG_CHUNK + nent / ((size_t)p.big + 1) + 2;   // chunks of over-long buckets
     const size_t max_keys = nent / ((size_t)p.big + 1) + 2;
     TRY(ensure(c, c->big_list, max_slots * 12));
@@ -291,6 +302,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     uint16_t* item_sub = (uint16_t*)c->item_sub.p;
     uint32_t* entries = (uint32_t*)c->entries.p;
     const int par = c->parity;
+    c->d_res_xyzz = (uint8_t*)c->small.p + 1024 + 144 * par;   // each tail slot has its own XYZZ result
     uint8_t* buckets = (uint8_t*)c->buckets.p + (size_t)par * p.NBT * XYZZ_BYTES;
     uint8_t* segsum = (uint8_t*)c->segsum.p + (size_t)par * nseg_total * XYZZ_BYTES;
     uint8_t* wsum = (uint8_t*)c->wsum.p + (size_t)par * p.W * XYZZ_BYTES;
@@ -363,15 +375,17 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
                            bin_cursor);
         hipLaunchKernelGGL(k_size_scatter, dim3(g), dim3(BLOCK), 0, st, hist, p.NBT, bin_cursor, order);
     }
-    if (c->tail_pending[par]) {  // the reduction two MSMs ago read this parity's buckets / segsum / wsum
+    if (c->tail_pending[par]) {  // the tail TAIL_SLOTS MSMs ago read this slot's buckets / segsum / wsum
         HIP_TRY(c, hipStreamWaitEvent(st, c->ev_tail[par], 0));
         c->tail_pending[par] = false;
     }
     // lanes per bucket: keep >= ~8192 waves in flight (3 per SIMD x 1024 SIMDs, 2-3 rounds) when buckets are few
+    // With few buckets the kernel is bound by its longest run (one mixed add is ~6 us of dependent latency): 8 lanes
+    // per bucket turn a 60-entry run into 8 entries + 7 adds of the combine.
     uint32_t lpb = 1;
     if (c->cfg_lpb) lpb = (uint32_t)c->cfg_lpb;
     else
-        while (lpb < 4 && (size_t)p.NBT * lpb < (size_t)8192 * 64) lpb *= 2;
+        while (lpb < 8 && (size_t)p.NBT * lpb < (size_t)8192 * 64) lpb *= 2;
     uint8_t* acc_out = buckets;
     if (lpb > 1) {
         TRY(ensure(c, c->parts, (size_t)p.NBT * lpb * XYZZ_BYTES));
@@ -403,8 +417,8 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     hipStream_t ts = st;
     if (c->tail_overlap && c->overlap_level >= 2) {
         HIP_TRY(c, hipEventRecord(c->ev_bulk[par], st));
-        HIP_TRY(c, hipStreamWaitEvent(c->tail_stream, c->ev_bulk[par], 0));
-        ts = c->tail_stream;
+        HIP_TRY(c, hipStreamWaitEvent(c->tail_streams[par], c->ev_bulk[par], 0));
+        ts = c->tail_streams[par];
     }
     {
         StageTimer t(c, ST_REDUCE, ts);
@@ -417,17 +431,17 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     }
     if (c->tail_overlap && c->overlap_level < 2) {
         HIP_TRY(c, hipEventRecord(c->ev_bulk[par], st));
-        HIP_TRY(c, hipStreamWaitEvent(c->tail_stream, c->ev_bulk[par], 0));
-        ts = c->tail_stream;
+        HIP_TRY(c, hipStreamWaitEvent(c->tail_streams[par], c->ev_bulk[par], 0));
+        ts = c->tail_streams[par];
     }
     {
         StageTimer t(c, ST_FINAL, ts);
         hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, ts, wsum, p.c, p.W, c->d_res_xyzz, d_out_jac);
     }
     if (c->tail_overlap) {
-        HIP_TRY(c, hipEventRecord(c->ev_tail[par], c->tail_stream));
+        HIP_TRY(c, hipEventRecord(c->ev_tail[par], c->tail_streams[par]));
         c->tail_pending[par] = true;
-        c->parity ^= 1;
+        c->parity = (c->parity + 1) % h2agg_ctx::TAIL_SLOTS;
     }
     HIP_TRY(c, hipGetLastError());
     profile_end_call(c);
@@ -478,23 +492,23 @@ int h2agg_create(int device_ordinal, h2agg_ctx** out) {
     snprintf(buf, sizeof buf, "h2agg 0.1 %s cu=%d", prop.gcnArchName, c->cu_count);
     c->desc = buf;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipHostMalloc((void**)&c->h_pinned, 4096) != hipSuccess || ensure(c, c->small, 1024) != H2AGG_OK) {
+        hipHostMalloc((void**)&c->h_pinned, 4096) != hipSuccess || ensure(c, c->small, 2048) != H2AGG_OK) {
         h2agg_destroy(c);
         return H2AGG_ERR_HIP;
     }
     c->stream = c->own_stream;
-    if (hipStreamCreateWithFlags(&c->tail_stream, hipStreamNonBlocking) != hipSuccess) {
-        h2agg_destroy(c);
-        return H2AGG_ERR_HIP;
-    }
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < h2agg_ctx::TAIL_SLOTS; ++k) {
+        if (hipStreamCreateWithFlags(&c->tail_streams[k], hipStreamNonBlocking) != hipSuccess) {
+            h2agg_destroy(c);
+            return H2AGG_ERR_HIP;
+        }
         hipEventCreateWithFlags(&c->ev_bulk[k], hipEventDisableTiming);
         hipEventCreateWithFlags(&c->ev_tail[k], hipEventDisableTiming);
     }
     c->d_flags = (uint32_t*)c->small.p;
-    c->d_res_xyzz = (uint8_t*)c->small.p + 64;   // 144 B
+    c->d_res_xyzz = (uint8_t*)c->small.p + 1024;   // 144 B
     c->d_res_jac = (uint8_t*)c->small.p + 256;   // 96 B
-    hipMemset(c->small.p, 0, 1024);
+    hipMemset(c->small.p, 0, 2048);
     *out = c;
     return H2AGG_OK;
 }
@@ -503,7 +517,8 @@ void h2agg_destroy(h2agg_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    if (c->tail_stream) hipStreamSynchronize(c->tail_stream);
+    for (int k = 0; k < h2agg_ctx::TAIL_SLOTS; ++k)
+        if (c->tail_streams[k]) hipStreamSynchronize(c->tail_streams[k]);
     DevBuf* bufs[] = {&c->in_a,  &c->in_b,     &c->in_c,     &c->out,   &c->tmp_bases, &c->hist,
                       &c->offs,  &c->pmeta,    &c->item_idx, &c->item_sub, &c->order,  &c->entries,
                       &c->buckets, &c->segsum, &c->wsum,     &c->big_list, &c->big_keys, &c->big_part, &c->glv_buf, &c->parts, &c->small};
@@ -516,11 +531,11 @@ void h2agg_destroy(h2agg_ctx* c) {
         for (int s = 0; s < ST_N; ++s)
             for (int k = 0; k < 2; ++k)
                 if (c->prof[r].ev[s][k]) hipEventDestroy(c->prof[r].ev[s][k]);
-    for (int k = 0; k < 2; ++k) {
+    for (int k = 0; k < h2agg_ctx::TAIL_SLOTS; ++k) {
         if (c->ev_bulk[k]) hipEventDestroy(c->ev_bulk[k]);
         if (c->ev_tail[k]) hipEventDestroy(c->ev_tail[k]);
+        if (c->tail_streams[k]) hipStreamDestroy(c->tail_streams[k]);
     }
-    if (c->tail_stream) hipStreamDestroy(c->tail_stream);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -852,7 +867,8 @@ int h2agg_msm_configure_glv(h2agg_ctx* c, int mode) {
 }
 int h2agg_msm_configure_lanes_per_bucket(h2agg_ctx* c, int lanes) {
     if (!c) return H2AGG_ERR_INVALID;
-    if (lanes != 0 && lanes != 1 && lanes != 2 && lanes != 4) return fail(c, H2AGG_ERR_INVALID, "lanes must be 0, 1, 2 or 4");
+    if (lanes != 0 && lanes != 1 && lanes != 2 && lanes != 4 && lanes != 8 && lanes != 16)
+        return fail(c, H2AGG_ERR_INVALID, "lanes must be 0, 1, 2, 4, 8 or 16");
     c->cfg_lpb = lanes;
     return H2AGG_OK;
 }

@@ -208,6 +208,12 @@ FP_INLINE void msm_for_each_digit(U256 s, int c, int W, bool glv, F&& f) {
     }
 }
 
+// packed level-1 sort item (32 bits): [ sub-bucket | neg | endo (only when glv) | idx : idx_bits ]
+FP_INLINE uint32_t pack_item(uint32_t sub, bool neg, bool endo, uint32_t idx, int idx_bits, bool glv) {
+    const int fb = glv ? 2 : 1;
+    return (sub << (idx_bits + fb)) | ((neg ? 1u : 0u) << (idx_bits + fb - 1)) | ((glv && endo ? 1u : 0u) << idx_bits) | idx;
+}
+
 // entry / item bit layout of the point reference
 constexpr uint32_t ENT_NEG = 0x80000000u;    // subtract the point
 constexpr uint32_t ENT_ENDO = 0x40000000u;   // use phi(point) = (beta*x, y)
@@ -395,7 +401,7 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_sort(const uint32_t* __restric
 // (level 2) for 96 MB + 64 MB of payload — single 4- and 2-byte stores to ~1000 open runs per workgroup are
 // evicted from L2 as partial lines.  Here the keys of a tile (level 1) / of a partition (level 2) are
 // first ordered in LDS and then leave the CU as contiguous runs written by consecutive lanes.
-// Item = sub-bucket << (idx_bits + 2) | negative << (idx_bits + 1) | endo << idx_bits | point index.
+// Item = sub-bucket | negative | endo (GLV only) | point index, packed from the top; see pack_item().
 constexpr int STAGE_ITEMS = 32768;  // 128 KiB of LDS
 
 __global__ void __launch_bounds__(BLOCK) k_part_scatter_staged(const uint8_t* __restrict__ scalars, size_t n, int c,
@@ -458,7 +464,7 @@ __global__ void __launch_bounds__(BLOCK) k_part_scatter_staged(const uint8_t* __
         msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool neg, bool endo) {
             const uint32_t p = (uint32_t)w * sp.ppw + (b >> sp.sub_bits);
             const uint32_t r = atomicAdd(&cur[p], 1u);
-            stage[lbase[p] + r] = ((b & submask) << (idx_bits + 2)) | ((neg ? 2u : 0u) << idx_bits) | ((endo ? 1u : 0u) << idx_bits) | (uint32_t)i;
+            stage[lbase[p] + r] = pack_item(b & submask, neg, endo, (uint32_t)i, idx_bits, sp.glv);
         });
     TILE_SCALARS_END
     __syncthreads();
@@ -498,7 +504,7 @@ __global__ void __launch_bounds__(BLOCK) k_part_scatter_packed(const uint8_t* __
         msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool neg, bool endo) {
             const uint32_t p = (uint32_t)w * sp.ppw + (b >> sp.sub_bits);
             const uint32_t pos = basep[p] + atomicAdd(&cnt[p], 1u);
-            items[pos] = ((b & submask) << (idx_bits + 2)) | ((neg ? 2u : 0u) << idx_bits) | ((endo ? 1u : 0u) << idx_bits) | (uint32_t)i;
+            items[pos] = pack_item(b & submask, neg, endo, (uint32_t)i, idx_bits, sp.glv);
         });
     TILE_SCALARS_END
 }
@@ -516,6 +522,7 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_sort_staged(const uint32_t* __
     const uint32_t start = pstart[p], end = pstart[p + 1], total = end - start;
     const int tid = threadIdx.x;
     const uint32_t idxmask = (1u << idx_bits) - 1u;
+    const int fb = sp.glv ? 2 : 1;  // flag bits between the index and the sub-bucket: neg, and endo under GLV
     for (uint32_t s = tid; s < sp.SB; s += BLOCK) h[s] = 0;
     __syncthreads();
     for (uint32_t k0 = start + tid; k0 < end; k0 += 8 * BLOCK) {  // 8 independent loads in flight
@@ -524,7 +531,7 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_sort_staged(const uint32_t* __
         for (int j = 0; j < 8; ++j) it[j] = (k0 + j * BLOCK < end) ? items[k0 + j * BLOCK] : 0u;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (k0 + j * BLOCK < end) atomicAdd(&h[it[j] >> (idx_bits + 2)], 1u);
+            if (k0 + j * BLOCK < end) atomicAdd(&h[it[j] >> (idx_bits + fb)], 1u);
     }
     __syncthreads();
     const uint32_t per = (sp.SB + BLOCK - 1) / BLOCK;
@@ -564,8 +571,9 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_sort_staged(const uint32_t* __
         for (int j = 0; j < 8; ++j) {
             const uint32_t it = itv[j];
             if (k0 + j * BLOCK >= end) continue;
-            const uint32_t r = atomicAdd(&h[it >> (idx_bits + 2)], 1u);
-            const uint32_t e = (it & idxmask) | (((it >> idx_bits) & 1u) << 30) | (((it >> (idx_bits + 1)) & 1u) << 31);
+            const uint32_t r = atomicAdd(&h[it >> (idx_bits + fb)], 1u);
+            const uint32_t e = (it & idxmask) | ((sp.glv ? ((it >> idx_bits) & 1u) : 0u) << 30) |
+                               (((it >> (idx_bits + fb - 1)) & 1u) << 31);
             if (staged) sorted[r] = e;
             else entries[start + r] = e;  // over-long partition (skewed scalars): direct placement
         }

@@ -192,7 +192,7 @@ int h2agg_msm_configure(h2agg_ctx* ctx, int window_bits, int reduce_segment, int
  * It costs ~5 % more work in the accumulation (the beta multiplications), so mode 0 = auto turns it on
  * unless the tail is hidden anyway (overlap mode and n >= 2^19); 1 = on, -1 = off (254-bit windows). */
 int h2agg_msm_configure_glv(h2agg_ctx* ctx, int mode);
-/* Lanes per bucket in the accumulation kernel (1, 2, 4; 0 = chosen so that at least ~8192 waves are launched). */
+/* Lanes per bucket in the accumulation kernel (1, 2, 4, 8, 16; 0 = chosen so that ~8192 waves are launched, at most 8). */
 int h2agg_msm_configure_lanes_per_bucket(h2agg_ctx* ctx, int lanes);
 /* Bucket-sort knobs: low bucket bits resolved per partition in LDS (4..12) and scalars per level-1
  * workgroup; 0 = default.  tile = -1 forces the two-array direct sort kernels (otherwise used only when

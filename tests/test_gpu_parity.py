@@ -292,7 +292,7 @@ def test_instance_commitment(eng, pkg):
         eng.bases_free(h)
 
 
-@pytest.mark.parametrize("lanes", [1, 2, 4])
+@pytest.mark.parametrize("lanes", [1, 2, 4, 8, 16])
 @pytest.mark.parametrize("glv", [1, -1])
 def test_msm_lanes_per_bucket(eng, lanes, glv):
     rng = O.SplitMix64(8000 + lanes)

@@ -128,3 +128,33 @@ def test_msm_packed_sort_item_all_ones(eng):
         eng.msm_configure_sort()
         eng.msm_configure_glv(0)
         eng.bases_free(table)
+
+
+def test_msm_packed_sort_item_all_ones_plain(eng):
+    """Same regression without GLV (19-bit index field, no endo bit): n = 2^19, c = 14, sub_bits = 12, the last scalar's
+    window 1 has raw digit 12288 (negative, magnitude 4096 -> bucket 4095 -> sub 4095) -> item 0xFFFFFFFF."""
+    n, c = 1 << 19, 14
+    ks, k_np = _workload(n, 23)
+    ss, _ = _workload(n, 24)
+    last = ss[-1] & ~((1 << (2 * c)) - 1)
+    last |= 1 | (12288 << c)
+    ss[-1] = last % O.R
+    assert (ss[-1] >> c) & ((1 << c) - 1) == 12288
+    s_np = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in ss), dtype=np.uint8).reshape(n, 32)
+    dev = torch.device("cuda", 0)
+    d_k = torch.from_numpy(k_np.copy()).to(dev)
+    d_s = torch.from_numpy(s_np.copy()).to(dev)
+    table = eng.bases_generate(d_k.data_ptr(), n)
+    want_k = sum(k * s for k, s in zip(ks, ss)) % O.R
+    want = eng.g1_batch_to_affine(eng.g1_batch_scalar_mul(O.aff_to_bytes(O.G1), O.fe_to_bytes(want_k)))
+    eng.msm_configure(window_bits=c)
+    eng.msm_configure_glv(-1)
+    try:
+        for sub_bits, tile in ((12, 0), (12, -2), (12, -1)):
+            eng.msm_configure_sort(sub_bits, tile)
+            assert eng.g1_batch_to_affine(eng.g1_msm_device(table, d_s.data_ptr(), n)) == want, (sub_bits, tile)
+    finally:
+        eng.msm_configure()
+        eng.msm_configure_sort()
+        eng.msm_configure_glv(0)
+        eng.bases_free(table)
