@@ -134,6 +134,10 @@ class H2Agg:
     # ------------------------------------------------------------------ plumbing
     def close(self):
         if getattr(self, "_ctx", None):
+            for ref in list(getattr(self, "_builders", ())):   # schemas hold device buffers of this context
+                b = ref()
+                if b is not None:
+                    b.close()
             self._lib.h2agg_destroy(self._ctx)
             self._ctx = None
 
@@ -142,6 +146,13 @@ class H2Agg:
             self.close()
         except Exception:
             pass
+
+    def _register_builder(self, b):
+        import weakref
+        if not hasattr(self, "_builders"):
+            self._builders = []
+        self._builders = [r for r in self._builders if r() is not None]
+        self._builders.append(weakref.ref(b))
 
     def _check(self, rc: int):
         if rc == OK:
@@ -300,11 +311,12 @@ class SchemaBuilder:
         self._lib = eng._lib
         self._s = C.c_void_p()
         eng._check(self._lib.h2agg_schema_create(eng._ctx, C.byref(self._s)))
+        eng._register_builder(self)
 
     def close(self):
-        if getattr(self, "_s", None):
+        if getattr(self, "_s", None) and getattr(self.eng, "_ctx", None):
             self._lib.h2agg_schema_destroy(self._s)
-            self._s = None
+        self._s = None
 
     def __del__(self):
         try:

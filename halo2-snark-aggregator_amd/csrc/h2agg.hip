@@ -441,8 +441,10 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     if (c->tail_overlap) {
         HIP_TRY(c, hipEventRecord(c->ev_tail[par], c->tail_streams[par]));
         c->tail_pending[par] = true;
-        c->parity = (c->parity + 1) % h2agg_ctx::TAIL_SLOTS;
     }
+    // the slot (buckets / segsum / wsum / XYZZ result) rotates on every MSM, overlap or not: a caller may queue
+    // two MSMs and read both results afterwards (evaluate_multiopen_proof does)
+    c->parity = (c->parity + 1) % h2agg_ctx::TAIL_SLOTS;
     HIP_TRY(c, hipGetLastError());
     profile_end_call(c);
     return H2AGG_OK;
