@@ -316,8 +316,8 @@ def main():
                 "avg_kernel_ms": dom_avg_s * 1e3,
                 "note": "MSM is integer-VALU-bound (v_mad_u64_u32 chains), not HBM-bound: the algorithmic "
                         "96 B/point is a tiny fraction of peak by construction (SURVEY.md \u00a78d). VALU view "
-                        "(profiles/r01_final_pmc_sq.txt): 698 M wave-instructions per launch, 4.16 cycles per "
-                        "instruction per SIMD at 2.04 GHz against ~3.5 for this instruction mix = ~84 % VALU issue",
+                        "(profiles/r01_final_pmc_sq.txt): 692 M wave-instructions per launch, 4.29 cycles per "
+                        "instruction per SIMD at 2.05 GHz against ~3.5 for this instruction mix = ~82 % VALU issue",
                 "stages_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in stages.items()},
             },
         }
