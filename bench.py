@@ -339,6 +339,19 @@ def main():
                               sample, secs, os.cpu_count() or 0),
                 "matches_gpu": cpu_out == gpu_same,
             }
+            # BASELINE.md "B1": not the reference's algorithm — a multi-threaded CPU Pippenger (oracle/, one thread
+            # per window) on the FULL workload, so the headline is not only compared with the naive loop
+            from oracle import cref
+            full_bases = eng.bases_download(table, 0, n)
+            t0 = time.perf_counter()
+            b1 = cref.msm_pippenger(full_bases, bytes(s_np.tobytes()), n, 16, 16)
+            t_b1 = time.perf_counter() - t0
+            out["cpu_baseline"]["fair_cpu_pippenger"] = {
+                "value": n / t_b1, "unit": "points/s", "threads": 16, "seconds": t_b1,
+                "matches_gpu": b1 == eng.g1_batch_to_affine(bytes(d_out[0].cpu().numpy().tobytes())),
+                "note": "oracle_msm_pippenger, unsigned 16-bit windows, 16 threads (one per window), full 2^%d points; "
+                        "NOT the reference algorithm" % args.log2n,
+            }
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
