@@ -70,11 +70,12 @@ def measured_traffic(stage_name: str, log2n: int):
     return None
 
 
-def aggregation_leg(pkg, eng, args, rank, world, dist, dev):
+def aggregation_leg(pkg, eng, args, rank, world, dist, devs):
     """Secondary figure (BASELINE.json metric, second half): aggregated proofs/s through the full
     EvaluationQuerySchema::eval path.  `agg_proofs` synthetic proofs per GPU (shape: `agg_commitments`
     advice columns, 3 rotation groups), sharded round-robin, one all-gather of the partial (W_x, W_g)."""
     import importlib
+    dev, coll_dev = devs if isinstance(devs, tuple) else (devs, devs)
     agg = importlib.import_module(entry.PKG_NAME + ".aggregate")
     mo = importlib.import_module(entry.PKG_NAME + ".multiopen")
     backend = agg.GpuBackend(pkg, eng)
@@ -118,19 +119,19 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, dev):
             out.append(mo.MultiOpenProof(w_x, w_g))
         return out
 
-    agg.aggregate_sharded(backend, build, n_total, lam, dist=dist, device=dev)          # warm-up
+    agg.aggregate_sharded(backend, build, n_total, lam, dist=dist, device=coll_dev)     # warm-up
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     reps = 3
     for _ in range(reps):
-        pair = agg.aggregate_sharded(backend, build, n_total, lam, dist=dist, device=dev)
+        pair = agg.aggregate_sharded(backend, build, n_total, lam, dist=dist, device=coll_dev)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / reps
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
@@ -172,17 +173,25 @@ def main():
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path is the product; there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # One rank per GPU over RCCL.  H2AGG_DIST_BACKEND=gloo (collectives through host tensors, ranks may share a
+    # GPU) exists only to exercise the multi-rank control flow on a 1-GPU box; it is not a measurement mode.
+    backend = os.environ.get("H2AGG_DIST_BACKEND", "nccl")
+    dev_index = local_rank % torch.cuda.device_count() if backend == "gloo" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
+    coll_dev = dev if backend == "nccl" else torch.device("cpu")
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     pkg = entry.load_package()
-    eng = pkg.H2Agg(local_rank)
+    eng = pkg.H2Agg(dev_index)
     stream = torch.cuda.current_stream(dev)
     eng.set_stream(stream.cuda_stream)
     if args.window or args.seg:
@@ -215,7 +224,7 @@ def main():
         """all-gather of the per-rank accumulators + local fold (the only collective on the path)"""
         if dist is None:
             return None
-        mine = d_out[0].contiguous()
+        mine = d_out[0].contiguous().to(coll_dev)
         gathered = [torch.empty_like(mine) for _ in range(world)]
         dist.all_gather(gathered, mine)
         return torch.stack(gathered)
@@ -257,17 +266,17 @@ def main():
         folded = eng.g1_sum(bytes(gathered.cpu().numpy().tobytes()))     # W = sum of per-rank accumulators
         folded_ok = len(folded) == 96
 
-    t_all = torch.tensor([dt], dtype=torch.float64, device=dev)
+    t_all = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
     if dist is not None:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
     dt_max = float(t_all.item())
 
     agg_info = None
     if args.agg_proofs > 0:
-        agg_info = aggregation_leg(pkg, eng, args, rank, world, dist, dev)       # configs[2]/[3]: 4 proofs per GPU
+        agg_info = aggregation_leg(pkg, eng, args, rank, world, dist, (dev, coll_dev))  # configs[2]/[3]: 4 proofs per GPU
         big = argparse.Namespace(**vars(args))
         big.agg_proofs = 4 * args.agg_proofs                                       # configs[4]: 16 proofs per GPU
-        more = aggregation_leg(pkg, eng, big, rank, world, dist, dev)
+        more = aggregation_leg(pkg, eng, big, rank, world, dist, (dev, coll_dev))
         if agg_info is not None and more is not None:
             agg_info["at_%d_proofs_per_gpu" % big.agg_proofs] = {
                 k: more[k] for k in ("proofs_per_sec", "proofs", "seconds_per_aggregation")}
