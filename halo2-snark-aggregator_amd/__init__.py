@@ -93,6 +93,7 @@ def load_library():
         "h2agg_evaluate_multiopen_proof": (i32, [C.c_void_p, C.c_uint32, C.c_uint32, vp, vp]),
         "h2agg_schema_name_count": (C.c_size_t, [C.c_void_p]),
         "h2agg_schema_name": (C.c_char_p, [C.c_void_p, C.c_size_t]),
+        "h2agg_schema_names_joined": (C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t]),
         "h2agg_schema_point_list_len": (C.c_size_t, [C.c_void_p]),
         "h2agg_msm_configure": (i32, [ctxp, i32, i32, i32]),
         "h2agg_msm_configure_glv": (i32, [ctxp, i32]),
@@ -278,8 +279,10 @@ class H2Agg:
     def msm_set_tail_overlap(self, on: bool = True):
         self._check(self._lib.h2agg_msm_set_tail_overlap(self._ctx, int(on)))
 
-    def profile_enable(self, on: bool = True):
-        self._check(self._lib.h2agg_profile_enable(self._ctx, int(on)))
+    def profile_enable(self, on=True, only_stage: Optional[int] = None):
+        """only_stage: index into profile_stages() order -> bracket just that stage (cheaper)."""
+        mode = (2 + int(only_stage)) if (on and only_stage is not None) else int(bool(on))
+        self._check(self._lib.h2agg_profile_enable(self._ctx, mode))
 
     def profile_reset(self):
         self._check(self._lib.h2agg_profile_reset(self._ctx))
@@ -338,12 +341,16 @@ class SchemaBuilder:
     def scalar(self, s: bytes) -> "EvaluationQuerySchema":               # scalar!  evaluation.rs:55-60
         return self._node(self._lib.h2agg_schema_node_scalar, s)
 
-    def evaluation_queries(self, keys: Sequence[str], commitments: bytes, evals: bytes):
-        """n x EvaluationQuery::new in one call -> list of schema nodes ([C_i] + eval_i)."""
+    def evaluation_queries(self, keys: Sequence[str], commitments: bytes, evals: bytes, wrap: bool = True):
+        """n x EvaluationQuery::new in one call -> list of schema nodes ([C_i] + eval_i).
+        wrap=False returns the raw node-id array (accepted by batch_multi_open): a proof has hundreds of
+        queries and one Python object per query costs more than the device work."""
         n = len(keys)
         arr = (C.c_char_p * n)(*[k.encode() for k in keys])
         out = (C.c_uint32 * n)()
         self.eng._check(self._lib.h2agg_schema_evaluation_queries(self._s, n, arr, commitments, evals, out))
+        if not wrap:
+            return out
         return [EvaluationQuerySchema(self, out[i]) for i in range(n)]
 
     def batch_multi_open(self, key: str, rotations: Sequence[int], points: bytes, query_nodes, w: bytes,
@@ -351,7 +358,10 @@ class SchemaBuilder:
         """multiopen.rs:23-102 in the C++ host layer -> (w_x, w_g) schema nodes."""
         nq = len(rotations)
         rot = (C.c_int32 * nq)(*rotations)
-        qn = (C.c_uint32 * nq)(*[q.node if isinstance(q, EvaluationQuerySchema) else int(q) for q in query_nodes])
+        if isinstance(query_nodes, C.Array):
+            qn = query_nodes
+        else:
+            qn = (C.c_uint32 * nq)(*[q.node if isinstance(q, EvaluationQuerySchema) else int(q) for q in query_nodes])
         wx, wg = C.c_uint32(), C.c_uint32()
         self.eng._check(self._lib.h2agg_schema_batch_multi_open(self._s, key.encode(), nq, rot, points, qn,
                                                                 len(w) // 64, w, v, u, C.byref(wx), C.byref(wg)))
@@ -364,8 +374,12 @@ class SchemaBuilder:
         return left.raw, right.raw, self.names()
 
     def names(self):
-        n = self._lib.h2agg_schema_name_count(self._s)
-        return [self._lib.h2agg_schema_name(self._s, i).decode() for i in range(n)]
+        need = self._lib.h2agg_schema_names_joined(self._s, None, 0)
+        if need == 0:
+            return []
+        buf = C.create_string_buffer(need)
+        self._lib.h2agg_schema_names_joined(self._s, buf, need)
+        return buf.raw[:need].decode().split("\n")[:-1]
 
     def point_list_len(self) -> int:
         return self._lib.h2agg_schema_point_list_len(self._s)

@@ -5,6 +5,8 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -55,6 +57,13 @@ struct h2agg_ctx {
     uint8_t* d_res_jac = nullptr;     // in `small` + 256
     uint8_t* h_pinned = nullptr;      // 4 KiB pinned staging for small results / flags
 
+    // schema-layer scratch (grow-only; the schema API is synchronous, one evaluation is in flight per context):
+    // the Fr register file, the uploaded staging block, per-side MSM scalars / Montgomery bases, pinned staging
+    DevBuf sch_regs, sch_in, sch_scalars[2], sch_bases[2];
+    uint8_t* h_stage = nullptr;
+    size_t h_stage_cap = 0;
+    const void* sch_owner = nullptr;  // the schema whose tape sch_regs reflects
+
     std::map<uint64_t, Table> tables;
     uint64_t next_handle = 1;
 
@@ -85,6 +94,7 @@ struct h2agg_ctx {
         bool pending = false;
     };
     bool profiling = false;
+    int prof_only = -1;   // >= 0: only this stage is bracketed (one event pair per MSM instead of nine)
     bool prof_events_created = false;
     ProfSlot prof[PROF_RING];
     int prof_cur = 0;
@@ -192,12 +202,12 @@ struct StageTimer {
     int st;
     hipStream_t s;
     StageTimer(h2agg_ctx* c_, int st_, hipStream_t s_ = nullptr) : c(c_), st(st_), s(s_ ? s_ : c_->stream) {
-        if (c->profiling) {
+        if (c->profiling && (c->prof_only < 0 || c->prof_only == st)) {
             hipEventRecord(c->prof[c->prof_cur].ev[st][0], s);
         }
     }
     ~StageTimer() {
-        if (c->profiling) {
+        if (c->profiling && (c->prof_only < 0 || c->prof_only == st)) {
             hipEventRecord(c->prof[c->prof_cur].ev[st][1], s);
             c->prof[c->prof_cur].used[st] = true;
         }
@@ -277,6 +287,9 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     if (staged && sp.tile < (uint32_t)BLOCK) staged = false;
     if (sp.PW > (uint32_t)SORT_MAX_PW) return fail(c, H2AGG_ERR_INVALID, "too many sort partitions");
     const uint32_t nseg_total = (uint32_t)p.W * p.spw;
+    // 4 lanes per chain in the bucket reduction / window sums (latency) or 1 (least work): see msm_kernels.cuh
+    static const int par4_env = getenv("H2AGG_PAR4") ? atoi(getenv("H2AGG_PAR4")) : 0;
+    const bool par4 = par4_env ? par4_env > 0 : nseg_total <= 16384;   // measured: wins up to c = 13, loses (extra work) above
     // pmeta words: [0,PW] pcount | [2048, +PW+1] pstart | [4096, +PW] pcursor | [6144,+1024] bin_count |
     //              [8192,+1025] bin_start | [10240,+1024] bin_cursor
     TRY(ensure(c, c->pmeta, 12288 * 4));
@@ -426,12 +439,19 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     }
     {
         StageTimer t(c, ST_REDUCE, ts);
-        hipLaunchKernelGGL(k_msm_reduce_segments, dim3((nseg_total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ts, buckets,
-                           p.NB, p.seg, p.spw, nseg_total, segsum);
+        if (par4)
+            hipLaunchKernelGGL(k_msm_reduce_segments_par4, dim3((4 * nseg_total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ts,
+                               buckets, p.NB, p.seg, p.spw, nseg_total, segsum);
+        else
+            hipLaunchKernelGGL(k_msm_reduce_segments, dim3((nseg_total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ts, buckets,
+                               p.NB, p.seg, p.spw, nseg_total, segsum);
     }
     {
         StageTimer t(c, ST_WINDOW_SUM, ts);
-        hipLaunchKernelGGL(k_msm_window_sum, dim3(p.W), dim3(BLOCK), 0, ts, segsum, p.spw, wsum);
+        if (par4)
+            hipLaunchKernelGGL(k_msm_window_sum_par4, dim3(p.W), dim3(PAR4_THREADS), 0, ts, segsum, p.spw, wsum);
+        else
+            hipLaunchKernelGGL(k_msm_window_sum, dim3(p.W), dim3(BLOCK), 0, ts, segsum, p.spw, wsum);
     }
     if (c->tail_overlap && c->overlap_level < 2) {
         HIP_TRY(c, hipEventRecord(c->ev_bulk[par], st));
@@ -527,12 +547,14 @@ void h2agg_destroy(h2agg_ctx* c) {
         if (c->tail_streams[k]) hipStreamSynchronize(c->tail_streams[k]);
     DevBuf* bufs[] = {&c->in_a,  &c->in_b,     &c->in_c,     &c->out,   &c->tmp_bases, &c->hist,
                       &c->offs,  &c->pmeta,    &c->item_idx, &c->item_sub, &c->order,  &c->entries,
-                      &c->buckets, &c->segsum, &c->wsum,     &c->big_list, &c->big_keys, &c->big_part, &c->glv_buf, &c->parts, &c->small};
+                      &c->buckets, &c->segsum, &c->wsum,     &c->big_list, &c->big_keys, &c->big_part, &c->glv_buf, &c->parts, &c->small,
+                      &c->sch_regs, &c->sch_in, &c->sch_scalars[0], &c->sch_scalars[1], &c->sch_bases[0], &c->sch_bases[1]};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     for (auto& kv : c->tables)
         if (kv.second.d) hipFree(kv.second.d);
     if (c->h_pinned) hipHostFree(c->h_pinned);
+    if (c->h_stage) hipHostFree(c->h_stage);
     for (int r = 0; r < h2agg_ctx::PROF_RING; ++r)
         for (int s = 0; s < ST_N; ++s)
             for (int k = 0; k < 2; ++k)
@@ -911,6 +933,7 @@ int h2agg_profile_enable(h2agg_ctx* c, int enable) {
     }
     if (!enable) profile_harvest_all(c);
     c->profiling = enable != 0;
+    c->prof_only = (enable >= 2 && enable - 2 < ST_N) ? enable - 2 : -1;
     return H2AGG_OK;
 }
 int h2agg_profile_reset(h2agg_ctx* c) {

@@ -213,37 +213,147 @@ __global__ void __launch_bounds__(BLOCK) k_msm_window_sum(const uint8_t* __restr
 // chain is 3 products deep instead of 9.  Measured: k_msm_final 1.20 -> 0.97 ms at c = 16 (for a lone wave
 // every instruction costs an issue slot, so the selects and shuffles are not free; a v_readlane variant that
 // broadcasts through SGPRs was slower: 1.27 ms).
-FP_INLINE Fq fq_bcast4(const Fq& v, int src) {
+template <int SRC>
+FP_INLINE Fq fq_bcast4(const Fq& v) {  // lane SRC of every group of 4 -> all 4: v_mov_b32 with a DPP quad_perm, no LDS
     Fq r;
 #pragma unroll
-    for (int i = 0; i < NL; ++i) r.l[i] = (uint32_t)__shfl((int)v.l[i], src, 4);
+    for (int i = 0; i < NL; ++i)
+        r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[i], SRC * 0x55, 0xF, 0xF, false);
     return r;
 }
-FP_INLINE Fq fq_sel4(int lane, const Fq& a, const Fq& b, const Fq& c, const Fq& d) {
+// Lane-dependent operand selection inside a group of 4, as straight-line v_cndmask_b32 with the lane pattern in an
+// SGPR pair (bit i set: lane i takes `yes`).  Written as inline asm on purpose: the C ternaries this replaces were
+// compiled into exec-masked branches per limb plus scratch traffic (about 15 instructions per limb instead of one
+// to three), which made the cooperative doubling no faster than the one-lane formula (tools/ubench_latency.hip).
+constexpr uint64_t QUAD_LANE0 = 0x1111111111111111ull, QUAD_LANE1 = QUAD_LANE0 << 1, QUAD_LANE2 = QUAD_LANE0 << 2,
+                   QUAD_LANE3 = QUAD_LANE0 << 3;
+FP_INLINE Fq fq_pick(uint64_t mask, const Fq& yes, const Fq& no) {
     Fq r;
 #pragma unroll
-    for (int i = 0; i < NL; ++i) r.l[i] = lane == 0 ? a.l[i] : (lane == 1 ? b.l[i] : (lane == 2 ? c.l[i] : d.l[i]));
+    for (int i = 0; i < NL; ++i)
+        asm("v_cndmask_b32 %0, %1, %2, %3" : "=v"(r.l[i]) : "v"(no.l[i]), "v"(yes.l[i]), "s"(mask));
     return r;
 }
-// 2 * p with p replicated in the 4 lanes of a group; `lane` = lane index within the group.  Same formulas
-// and bounds as xyzz_double (dbl-2008-s-1), Y3 = M*(S - X3 + 6p) + W*(4p - Y) as a sum of two products [4].
-FP_INLINE G1XYZZ xyzz_double_par4(const G1XYZZ& p, int lane) {
+// 2 * p with p replicated in the 4 lanes of a group.  Same formulas and bounds as xyzz_double (dbl-2008-s-1),
+// Y3 = M*(S - X3 + 6p) + W*(4p - Y) as a sum of two products [4].  Three rounds of one multiplication per lane:
+//   round 1   lane 0: V = U^2      lane 1: XX = X^2
+//   round 2   lane 0: W = U*V      lane 1: S = X*V      lane 2: M^2        lane 3: ZZ3 = V*ZZ
+//   round 3   lane 0: M*(S-X3)     lane 1: W*(-Y)       lane 2,3: ZZZ3 = W*ZZZ
+FP_INLINE G1XYZZ xyzz_double_par4(const G1XYZZ& p) {
     if (p.is_identity()) return p;  // uniform: the state is replicated
     const Fq u = FQ_DBL(p.y);                                           // [8]
-    const Fq r1 = FQ_SQR(lane == 0 ? u : p.x);                          // lane 0: V = U^2, lane 1: XX = X^2
-    const Fq v = fq_bcast4(r1, 0), xx = fq_bcast4(r1, 1);
+    const Fq r1 = FQ_SQR(fq_pick(QUAD_LANE0, u, p.x));
+    const Fq v = fq_bcast4<0>(r1), xx = fq_bcast4<1>(r1);
     const Fq m = fp_triple<FqParams>(xx);                               // [6]
-    const Fq r2 = FQ_MUL(fq_sel4(lane, u, p.x, m, v), fq_sel4(lane, v, v, m, p.zz));
-    const Fq w = fq_bcast4(r2, 0), s = fq_bcast4(r2, 1), mm = fq_bcast4(r2, 2), zz3 = fq_bcast4(r2, 3);
+    const Fq a2 = fq_pick(QUAD_LANE0, u, fq_pick(QUAD_LANE1, p.x, fq_pick(QUAD_LANE2, m, v)));
+    const Fq b2 = fq_pick(QUAD_LANE2, m, fq_pick(QUAD_LANE3, p.zz, v));
+    const Fq r2 = FQ_MUL(a2, b2);
+    const Fq w = fq_bcast4<0>(r2), s = fq_bcast4<1>(r2), mm = fq_bcast4<2>(r2), zz3 = fq_bcast4<3>(r2);
     G1XYZZ o;
     o.x = fp_sub2<4, FqParams>(mm, s);                                  // [6]
     const Fq d = FQ_SUB(6, s, o.x);                                     // [8]
     const Fq ny = fp_neg<4, FqParams>(p.y);                             // [4]
-    const Fq r3 = FQ_MUL(fq_sel4(lane, m, w, w, w), fq_sel4(lane, d, ny, p.zzz, p.zzz));
-    o.y = FQ_ADD(fq_bcast4(r3, 0), fq_bcast4(r3, 1));                   // [2] + [2] -> [4]
+    const Fq r3 = FQ_MUL(fq_pick(QUAD_LANE0, m, w), fq_pick(QUAD_LANE0, d, fq_pick(QUAD_LANE1, ny, p.zzz)));
+    o.y = FQ_ADD(fq_bcast4<0>(r3), fq_bcast4<1>(r3));                   // [2] + [2] -> [4]
     o.zz = zz3;
-    o.zzz = fq_bcast4(r3, 2);
+    o.zzz = fq_bcast4<2>(r3);
     return o;
+}
+
+// a + b with both points replicated in the 4 lanes of a group: add-2008-s in four rounds of one multiplication per
+// lane instead of 14 in a row (same exceptional cases as xyzz_add; they are uniform inside a group).
+//   round 1   U1 = X1*ZZ2       U2 = X2*ZZ1       S1 = Y1*ZZZ2        S2 = Y2*ZZZ1
+//   round 2   PP = P^2          RR = R^2          ZZ12 = ZZ1*ZZ2      ZZZ12 = ZZZ1*ZZZ2      (P = U2-U1, R = S2-S1)
+//   round 3   PPP = P*PP        Q = U1*PP         ZZ3 = ZZ12*PP       -
+//   round 4   R*(Q-X3)          (-S1)*PPP         ZZZ3 = ZZZ12*PPP    (same)                 (X3 = RR-PPP-2Q)
+FP_INLINE G1XYZZ xyzz_add_par4(const G1XYZZ& a, const G1XYZZ& b) {
+    if (a.is_identity()) return b;
+    if (b.is_identity()) return a;
+    const Fq a1 = fq_pick(QUAD_LANE0, a.x, fq_pick(QUAD_LANE1, b.x, fq_pick(QUAD_LANE2, a.y, b.y)));
+    const Fq b1 = fq_pick(QUAD_LANE0, b.zz, fq_pick(QUAD_LANE1, a.zz, fq_pick(QUAD_LANE2, b.zzz, a.zzz)));
+    const Fq r1 = FQ_MUL(a1, b1);                                       // 8*2 -> [2]
+    const Fq u1 = fq_bcast4<0>(r1), u2 = fq_bcast4<1>(r1), s1 = fq_bcast4<2>(r1), s2 = fq_bcast4<3>(r1);
+    const Fq p = FQ_SUB(2, u2, u1);                                     // [4]
+    const Fq r = FQ_SUB(2, s2, s1);                                     // [4]
+    if (fp_maybe_zero_mod<4, FqParams>(p)) {
+        if (fp_is_zero_mod<4, FqParams>(p)) {
+            if (fp_is_zero_mod<4, FqParams>(r)) return xyzz_double(a);
+            return G1XYZZ::identity();
+        }
+    }
+    const Fq a2 = fq_pick(QUAD_LANE0, p, fq_pick(QUAD_LANE1, r, fq_pick(QUAD_LANE2, a.zz, a.zzz)));
+    const Fq b2 = fq_pick(QUAD_LANE2, b.zz, fq_pick(QUAD_LANE3, b.zzz, a2));
+    const Fq r2 = FQ_MUL(a2, b2);                                       // 16 -> [2]
+    const Fq pp = fq_bcast4<0>(r2), rr = fq_bcast4<1>(r2), zz12 = fq_bcast4<2>(r2), zzz12 = fq_bcast4<3>(r2);
+    const Fq r3 = FQ_MUL(fq_pick(QUAD_LANE0, p, fq_pick(QUAD_LANE1, u1, zz12)), pp);   // [2]
+    const Fq ppp = fq_bcast4<0>(r3), q = fq_bcast4<1>(r3);
+    G1XYZZ o;
+    o.zz = fq_bcast4<2>(r3);
+    o.x = fp_sub_sub2<6, FqParams>(rr, ppp, q);                         // [8]
+    const Fq a4 = fq_pick(QUAD_LANE0, r, fq_pick(QUAD_LANE1, fp_neg<2, FqParams>(s1), zzz12));
+    const Fq b4 = fq_pick(QUAD_LANE0, FQ_SUB(8, q, o.x), ppp);          // [10] | [2]
+    const Fq r4 = FQ_MUL(a4, b4);                                       // 4*10 -> [2]
+    o.y = FQ_ADD(fq_bcast4<0>(r4), fq_bcast4<1>(r4));                   // [4]
+    o.zzz = fq_bcast4<2>(r4);
+    return o;
+}
+
+// ---- 4-lane cooperative versions of the latency-shaped tail kernels ------------------------------------------
+// The bucket reduction and the window sums are chains of dependent additions (2*seg + a double-and-add per segment,
+// then a strided sum and a tree per window): what bounds them on small and medium MSMs is the length of one chain,
+// not the number of chains.  With 4 lanes per chain every addition is 4 products deep instead of 14.
+__device__ __noinline__ G1XYZZ xyzz_mul_small_par4(const G1XYZZ& p, uint32_t k) {
+    G1XYZZ acc = G1XYZZ::identity();
+#pragma unroll 1
+    for (int bit = 31 - __clz((int)(k | 1u)); bit >= 0; --bit) {
+        acc = xyzz_double_par4(acc);
+        if ((k >> bit) & 1u) acc = xyzz_add_par4(acc, p);
+    }
+    return acc;
+}
+__global__ void __launch_bounds__(BLOCK, 2) k_msm_reduce_segments_par4(const uint8_t* __restrict__ buckets, uint32_t NB,
+                                                                    uint32_t seg, uint32_t spw, uint32_t total,
+                                                                    uint8_t* __restrict__ segsum) {
+    const uint32_t t = (blockIdx.x * BLOCK + threadIdx.x) >> 2;   // one segment per group of 4 lanes
+    if (t >= total) return;
+    const uint32_t w = t / spw, sidx = t - w * spw;
+    const uint32_t a = sidx * seg;
+    const uint8_t* B = buckets + XYZZ_BYTES * ((size_t)w * NB + a);
+    G1XYZZ running = G1XYZZ::identity(), acc = G1XYZZ::identity();
+#pragma unroll 1
+    for (int j = (int)seg - 1; j >= 0; --j) {
+        running = xyzz_add_par4(running, xyzz_load(B + XYZZ_BYTES * (size_t)j));
+        acc = xyzz_add_par4(acc, running);
+    }
+    if (a != 0 && !running.is_identity()) acc = xyzz_add_par4(acc, xyzz_mul_small_par4(running, a));
+    if ((threadIdx.x & 3) == 0) xyzz_store(segsum + XYZZ_BYTES * (size_t)t, acc);
+}
+constexpr int PAR4_GROUPS = 128, PAR4_THREADS = 4 * PAR4_GROUPS;
+// sum of one (replicated) point per group over a PAR4_THREADS workgroup; the result is replicated in group 0
+__device__ __noinline__ G1XYZZ block_sum_xyzz_par4(G1XYZZ v, uint32_t* lds) {
+    const int g = threadIdx.x >> 2, l = threadIdx.x & 3;
+    if (l == 0) lds_put_xyzz(lds, g, v);
+    __syncthreads();
+#pragma unroll 1
+    for (int s = PAR4_GROUPS / 2; s >= 1; s >>= 1) {
+        if (g < s) {
+            v = xyzz_add_par4(v, lds_get_xyzz(lds, g + s));
+            if (l == 0) lds_put_xyzz(lds, g, v);
+        }
+        __syncthreads();
+    }
+    return v;
+}
+__global__ void __launch_bounds__(PAR4_THREADS) k_msm_window_sum_par4(const uint8_t* __restrict__ segsum, uint32_t spw,
+                                                                      uint8_t* __restrict__ wsum) {
+    __shared__ uint32_t lds[XYZZ_WORDS * BLOCK];
+    const uint32_t w = blockIdx.x;
+    G1XYZZ acc = G1XYZZ::identity();
+#pragma unroll 1
+    for (uint32_t s = threadIdx.x >> 2; s < spw; s += PAR4_GROUPS)
+        acc = xyzz_add_par4(acc, xyzz_load(segsum + XYZZ_BYTES * ((size_t)w * spw + s)));
+    G1XYZZ tot = block_sum_xyzz_par4(acc, lds);
+    if (threadIdx.x == 0) xyzz_store(wsum + XYZZ_BYTES * (size_t)w, tot);
 }
 
 // result = sum_w 2^(c*w) * wsum[w]  (Horner, top window first).  Writes the XYZZ value (Montgomery, for
@@ -255,13 +365,12 @@ __global__ void __launch_bounds__(64) k_msm_final(const uint8_t* __restrict__ ws
     // this wave carries the whole latency chain: let it win issue arbitration against the bulk kernels of the
     // next MSM that share its SIMD in overlap mode
     __builtin_amdgcn_s_setprio(3);
-    const int lane = threadIdx.x & 3;
     G1XYZZ acc = xyzz_load(wsum + XYZZ_BYTES * (size_t)(W - 1));
 #pragma unroll 1
     for (int w = W - 2; w >= 0; --w) {
 #pragma unroll 1
-        for (int k = 0; k < c; ++k) acc = xyzz_double_par4(acc, lane);
-        acc = xyzz_add(acc, xyzz_load(wsum + XYZZ_BYTES * (size_t)w));
+        for (int k = 0; k < c; ++k) acc = xyzz_double_par4(acc);
+        acc = xyzz_add_par4(acc, xyzz_load(wsum + XYZZ_BYTES * (size_t)w));
     }
     if (threadIdx.x == 0) {
         if (out_xyzz) xyzz_store(out_xyzz, acc);

@@ -113,22 +113,154 @@ __global__ void __launch_bounds__(BLOCK) k_tape_gather(const uint32_t* __restric
 }
 
 // ------------------------------------------------------------------ host side: AST + symbolic evaluation
+// The tape is a DAG of Fr operations; its run time on the device is (number of dependency levels) x (one barrier +
+// one multiplication latency), so the recorder keeps it SHALLOW.  Field arithmetic is exact, hence any association
+// of the same products / sums yields the identical canonical result; the recorder uses that freedom twice:
+//   * multiplicative chains  s_k = s_(k-1) * v  (the scalar pushed down a Horner chain v*acc + q, multiopen.rs:56-60,
+//     is v^k after k levels) are recorded as  root * pow(v, k)  with pow() built by halving: depth log2 k, not k;
+//   * additive chains  e = e + t_k  (every evaluation merges into the "" entry, evaluation.rs:251-262) stay LAZY
+//     (a linked list of terms) until something consumes the sum, then become a balanced tree: depth log2 n, not n.
+// Constants are interned by value so that the thousands of `scalar!(v)` leaves share one register.
 struct Tape {
-    std::vector<uint8_t> consts;   // 32 B each; register i < nconsts is constant i
-    std::vector<TapeOp> ops;       // op k writes register nconsts_final + k (fixed up at finalisation)
-    std::vector<uint32_t> level;   // per register
+    static constexpr uint32_t OPBIT = 0x80000000u;    // provisional id of an operation result (resolved at run time)
+    static constexpr uint32_t LAZYBIT = 0x40000000u;  // id of a not-yet-materialised sum
+    static constexpr uint32_t NONE = 0xffffffffu;
+    std::vector<uint8_t> consts;   // 32 B each; register i < nconst is constant i
+    std::vector<TapeOp> ops;       // op k writes register nconst_final + k
     uint32_t nconst = 0;
-    // registers are numbered: constants first (ids 0..nconst-1 while recording are provisional: we
-    // record with a tag bit and resolve when the constant count is known)
-    static constexpr uint32_t OPBIT = 0x80000000u;
+
+    struct Key32 {
+        uint64_t w[4];
+        bool operator==(const Key32& o) const { return w[0] == o.w[0] && w[1] == o.w[1] && w[2] == o.w[2] && w[3] == o.w[3]; }
+    };
+    struct Key32Hash {
+        size_t operator()(const Key32& k) const {
+            uint64_t h = k.w[0] * 0x9E3779B97F4A7C15ull;
+            h = (h ^ (h >> 29)) + k.w[1] * 0xC2B2AE3D27D4EB4Full;
+            h = (h ^ (h >> 31)) + k.w[2] * 0x165667B19E3779F9ull;
+            h = (h ^ (h >> 30)) + k.w[3] * 0xD6E8FEB86659FD93ull;
+            return (size_t)(h ^ (h >> 32));
+        }
+    };
+    std::unordered_map<Key32, uint32_t, Key32Hash> const_ids;
+    struct Chain {
+        uint32_t root, c, e;  // register = root * c^e   (root == NONE: just c^e)
+    };
+    std::unordered_map<uint32_t, Chain> chain_of;
+    std::unordered_map<uint64_t, uint32_t> pow_memo;  // (c << 32 | e) -> register
+    struct Lazy {
+        uint32_t parent;  // LAZYBIT id of the sum this one extends, or NONE
+        uint32_t head;    // first term when parent == NONE
+        uint32_t term;    // the term added here
+        uint32_t reg;     // materialised register, or NONE
+    };
+    std::vector<Lazy> lazies;
+
     uint32_t add_const(const uint8_t v[32]) {
+        Key32 k;
+        memcpy(k.w, v, 32);
+        auto it = const_ids.find(k);
+        if (it != const_ids.end()) return it->second;
         consts.insert(consts.end(), v, v + 32);
+        const_ids.emplace(k, nconst);
         return nconst++;
     }
+    static bool is_const(uint32_t r) { return !(r & (OPBIT | LAZYBIT)); }
     uint32_t record(uint32_t opcode, uint32_t a, uint32_t b) {
+        a = materialize(a);
+        b = materialize(b);
         TapeOp o{(uint32_t)ops.size() | OPBIT, a, b, opcode};
         ops.push_back(o);
         return o.dst;
+    }
+    // a * b where one side is (typically) a `scalar!` leaf: keeps multiplicative chains shallow
+    uint32_t mul(uint32_t a, uint32_t b) {
+        a = materialize(a);
+        b = materialize(b);
+        if (is_const(a) && !is_const(b)) std::swap(a, b);  // constant on the right
+        if (is_const(b)) {
+            if (is_const(a)) {
+                if (a == b) return chain(NONE, b, 2);
+            } else {
+                auto it = chain_of.find(a);
+                if (it != chain_of.end() && it->second.c == b) {
+                    const Chain ch = it->second;
+                    return chain(ch.root, b, ch.e + 1);
+                }
+            }
+            const uint32_t r = record(TAPE_MUL, a, b);
+            chain_of.emplace(r, Chain{a, b, 1});
+            return r;
+        }
+        return record(TAPE_MUL, a, b);
+    }
+    uint32_t pow(uint32_t c, uint32_t e) {
+        if (e == 1) return c;
+        const uint64_t key = ((uint64_t)c << 32) | e;
+        auto it = pow_memo.find(key);
+        if (it != pow_memo.end()) return it->second;
+        const uint32_t lo = pow(c, e / 2), hi = pow(c, e - e / 2);
+        const uint32_t r = record(TAPE_MUL, lo, hi);
+        pow_memo.emplace(key, r);
+        chain_of.emplace(r, Chain{NONE, c, e});
+        return r;
+    }
+    uint32_t chain(uint32_t root, uint32_t c, uint32_t e) {
+        const uint32_t p = pow(c, e);
+        if (root == NONE) return p;
+        const uint32_t r = record(TAPE_MUL, root, p);
+        chain_of.emplace(r, Chain{root, c, e});
+        return r;
+    }
+    // a + b, deferred
+    uint32_t add(uint32_t a, uint32_t b) {
+        const bool la = (a & LAZYBIT) && lazies[a & ~LAZYBIT].reg == NONE;
+        const bool lb = (b & LAZYBIT) && lazies[b & ~LAZYBIT].reg == NONE;
+        Lazy z;
+        z.reg = NONE;
+        if (la) {
+            z.parent = a, z.head = NONE, z.term = materialize(b);
+        } else if (lb) {
+            z.parent = b, z.head = NONE, z.term = materialize(a);
+        } else {
+            z.parent = NONE, z.head = materialize(a), z.term = materialize(b);
+        }
+        lazies.push_back(z);
+        return (uint32_t)(lazies.size() - 1) | LAZYBIT;
+    }
+    uint32_t materialize(uint32_t r) {
+        if (!(r & LAZYBIT) || r == NONE) return r;
+        Lazy& top = lazies[r & ~LAZYBIT];
+        if (top.reg != NONE) return top.reg;
+        std::vector<uint32_t> terms;
+        uint32_t cur = r;
+        for (;;) {
+            const Lazy& z = lazies[cur & ~LAZYBIT];
+            if (z.reg != NONE) {  // an already materialised prefix of the sum
+                terms.push_back(z.reg);
+                break;
+            }
+            terms.push_back(z.term);
+            if (z.parent == NONE) {
+                terms.push_back(z.head);
+                break;
+            }
+            cur = z.parent;
+        }
+        // oldest term first, then a balanced pairwise tree
+        std::vector<uint32_t> lvl(terms.rbegin(), terms.rend());
+        while (lvl.size() > 1) {
+            size_t o = 0;
+            for (size_t i = 0; i + 1 < lvl.size(); i += 2) {
+                TapeOp op{(uint32_t)ops.size() | OPBIT, lvl[i], lvl[i + 1], TAPE_ADD};
+                ops.push_back(op);
+                lvl[o++] = op.dst;
+            }
+            if (lvl.size() & 1) lvl[o++] = lvl.back();
+            lvl.resize(o);
+        }
+        lazies[r & ~LAZYBIT].reg = lvl[0];
+        return lvl[0];
     }
     uint32_t resolve(uint32_t r) const { return (r & OPBIT) ? nconst + (r & ~OPBIT) : r; }
 };
@@ -139,17 +271,17 @@ struct SchemaNode {
     uint32_t l = 0, r = 0; // children (ADD / MUL)
     int32_t point = -1;    // COMMITMENT: index into Schema::points
     uint32_t reg = 0;      // EVAL / SCALAR: tape constant
-    std::string key;       // COMMITMENT
+    uint32_t key = 0;      // COMMITMENT: interned key (0 = "")
 };
 
 struct PreparedEntry {
-    std::string key;
+    uint32_t key;    // interned; 0 = ""
     int32_t point;   // -1 = None
-    int64_t scalar;  // -1 = None, otherwise a tape register (possibly OPBIT-tagged)
+    int64_t scalar;  // -1 = None, otherwise a tape register id (possibly OPBIT / LAZYBIT tagged)
 };
 struct Prepared {
     std::vector<PreparedEntry> v;
-    std::unordered_map<std::string, uint32_t> index;  // key -> position of its first entry
+    std::unordered_map<uint32_t, uint32_t> index;  // key -> position of its first entry
     bool indexed = false;
     void build_index() {
         if (indexed) return;
@@ -166,11 +298,24 @@ struct Schema {
     uint32_t one_reg = 0;
     bool has_one = false;
     std::string err;
+    std::vector<std::string> key_names{std::string()};                 // interned keys, id 0 = ""
+    std::unordered_map<std::string, uint32_t> key_ids{{std::string(), 0u}};
 
-    // results of the last eval (names: evaluation.rs:183)
-    std::vector<std::string> names;
+    // results of the last eval (names: evaluation.rs:183), as interned key ids
+    std::vector<uint32_t> names;
     size_t point_list_len = 0;     // what MockChipCtx::point_list.len() would be after multi_exp
 
+    uint32_t intern(const char* key) {
+        auto it = key_ids.find(key);
+        if (it != key_ids.end()) return it->second;
+        const uint32_t id = (uint32_t)key_names.size();
+        key_names.emplace_back(key);
+        key_ids.emplace(key_names.back(), id);
+        return id;
+    }
+    void grow_nodes(size_t extra) {
+        if (nodes.size() + extra > nodes.capacity()) nodes.reserve(2 * nodes.capacity() + extra);
+    }
     uint32_t one() {
         if (!has_one) {
             uint8_t v[32] = {1};
@@ -179,22 +324,23 @@ struct Schema {
         }
         return one_reg;
     }
-    uint32_t add_commitment(const char* key, const uint8_t p[64]) {
+    uint32_t add_commitment_id(uint32_t key, const uint8_t p[64]) {
         SchemaNode n;
         n.kind = SchemaNode::COMMITMENT;
         n.has_commitment = true;
         n.key = key;
         n.point = (int32_t)(points.size() / 64);
         points.insert(points.end(), p, p + 64);
-        nodes.push_back(std::move(n));
+        nodes.push_back(n);
         return (uint32_t)nodes.size() - 1;
     }
+    uint32_t add_commitment(const char* key, const uint8_t p[64]) { return add_commitment_id(intern(key), p); }
     uint32_t add_leaf_scalar(SchemaNode::Kind k, const uint8_t s[32]) {
         SchemaNode n;
         n.kind = k;
         n.has_commitment = false;
         n.reg = tape.add_const(s);
-        nodes.push_back(std::move(n));
+        nodes.push_back(n);
         return (uint32_t)nodes.size() - 1;
     }
     bool valid(uint32_t id) const { return id < nodes.size(); }
@@ -204,7 +350,7 @@ struct Schema {
         n.l = l;
         n.r = r;
         n.has_commitment = nodes[l].has_commitment || nodes[r].has_commitment;  // evaluation.rs:35-36
-        nodes.push_back(std::move(n));
+        nodes.push_back(n);
         return (uint32_t)nodes.size() - 1;
     }
 
@@ -243,6 +389,7 @@ struct Schema {
             err = "assert_eq!(self.w.len(), points.len()) failed (multiopen.rs:48)";
             return false;
         }
+        grow_nodes(3 * nq + 12 * groups.size());
         std::vector<uint32_t> s_of(groups.size());
         for (size_t g = 0; g < groups.size(); ++g) {                          // :56-60  rev().reduce(v*acc + q)
             const std::vector<uint32_t>& sc = groups[g].schemas;
@@ -257,9 +404,10 @@ struct Schema {
         uint32_t w_x = 0, w_g = 0;
         for (size_t gi = groups.size(); gi-- > 0;) {                          // :82-96  enumerate().rev()
             const std::string wkey = std::string(key) + "_w" + std::to_string(gi);
-            const uint32_t cw = add_commitment(wkey.c_str(), w + 64 * gi);
+            const uint32_t wid = intern(wkey.c_str());
+            const uint32_t cw = add_commitment_id(wid, w + 64 * gi);
             const uint32_t zc = add_binary(SchemaNode::MUL, add_leaf_scalar(SchemaNode::SCALAR, groups[gi].point),
-                                           add_commitment(wkey.c_str(), w + 64 * gi));
+                                           add_commitment_id(wid, w + 64 * gi));
             if (!have) {
                 w_x = cw;
                 w_g = add_binary(SchemaNode::ADD, zc, s_of[gi]);
@@ -301,23 +449,23 @@ struct Schema {
     // eval_prepare (evaluation.rs:205-293); `scalar` = -1 for None.  Returns false on the reference's
     // assertion failures (err is set).
     bool eval_prepare(uint32_t id, int64_t scalar, Prepared& out) {
-        const SchemaNode& n = nodes[id];
+        const SchemaNode n = nodes[id];
         switch (n.kind) {
         case SchemaNode::COMMITMENT:                                         // :216-218
             out.v.push_back({n.key, n.point, scalar});
             return true;
         case SchemaNode::EVAL: {                                             // :219-225
             int64_t e = scalar >= 0 ? (int64_t)tape.record(TAPE_MUL, (uint32_t)scalar, n.reg) : (int64_t)n.reg;
-            out.v.push_back({std::string(), -1, e});
+            out.v.push_back({0u, -1, e});
             return true;
         }
         case SchemaNode::SCALAR: {                                           // :226-232
-            int64_t s = scalar >= 0 ? (int64_t)tape.record(TAPE_MUL, n.reg, (uint32_t)scalar) : (int64_t)n.reg;
-            out.v.push_back({std::string(), -1, s});
+            int64_t s = scalar >= 0 ? (int64_t)tape.mul(n.reg, (uint32_t)scalar) : (int64_t)n.reg;
+            out.v.push_back({0u, -1, s});
             return true;
         }
         case SchemaNode::ADD: {
-            const uint32_t l = n.l, r = n.r;  // copy: `nodes` is not modified below, but keep it simple
+            const uint32_t l = n.l, r = n.r;
             if (!nodes[l].has_commitment && !nodes[r].has_commitment) {      // :234-244
                 Prepared pl, pr;
                 if (!eval_prepare(l, -1, pl) || !eval_prepare(r, -1, pr)) return false;
@@ -325,9 +473,9 @@ struct Schema {
                     err = "assert!(l.len() == 1 && r.len() == 1) failed (evaluation.rs:237-238)";
                     return false;
                 }
-                int64_t sum = tape.record(TAPE_ADD, (uint32_t)pl.v[0].scalar, (uint32_t)pr.v[0].scalar);
+                int64_t sum = tape.add((uint32_t)pl.v[0].scalar, (uint32_t)pr.v[0].scalar);
                 if (scalar >= 0) sum = tape.record(TAPE_MUL, (uint32_t)scalar, (uint32_t)sum);
-                out.v.push_back({std::string(), -1, sum});
+                out.v.push_back({0u, -1, sum});
                 return true;
             }
             // :245-268  merge entries with equal key by adding their scalars (None == one).
@@ -346,10 +494,10 @@ struct Schema {
                     PreparedEntry& p = res.v[it->second];
                     const uint32_t a = p.scalar >= 0 ? (uint32_t)p.scalar : one();
                     const uint32_t b = ev.scalar >= 0 ? (uint32_t)ev.scalar : one();
-                    p.scalar = tape.record(TAPE_ADD, a, b);
+                    p.scalar = tape.add(a, b);
                 } else {
                     res.index.emplace(ev.key, (uint32_t)res.v.size());
-                    res.v.push_back(std::move(ev));
+                    res.v.push_back(ev);
                 }
             }
             out = std::move(res);
@@ -371,7 +519,7 @@ struct Schema {
                 return false;
             }
             int64_t sv = s.v[0].scalar;
-            if (scalar >= 0) sv = tape.record(TAPE_MUL, (uint32_t)scalar, (uint32_t)sv);
+            if (scalar >= 0) sv = tape.mul((uint32_t)scalar, (uint32_t)sv);
             return eval_prepare(rem, sv, out);
         }
         }

@@ -182,6 +182,8 @@ int h2agg_evaluate_multiopen_proof(h2agg_schema* s, uint32_t w_x, uint32_t w_g, 
  * length MockChipCtx::point_list would have after the last multi_exp (mock/arith/ecc.rs:112-116). */
 size_t h2agg_schema_name_count(h2agg_schema* s);
 const char* h2agg_schema_name(h2agg_schema* s, size_t i);
+/* all names in one call, each followed by '\n'; returns the byte count needed (nothing is written if cap is smaller) */
+size_t h2agg_schema_names_joined(h2agg_schema* s, char* out, size_t cap);
 size_t h2agg_schema_point_list_len(h2agg_schema* s);
 
 /* ---- tuning / measurement -------------------------------------------------------------------------
@@ -205,7 +207,8 @@ int h2agg_msm_configure_sort(h2agg_ctx* ctx, int sub_bits, int tile);
  * the context), not merely after the caller's stream has drained.  Default: off. */
 int h2agg_msm_set_tail_overlap(h2agg_ctx* ctx, int enable);
 /* When enabled, every MSM stage is bracketed by HIP events on the context's stream and per-stage times
- * are accumulated (this makes the async entry point synchronise at the end of each call). */
+ * are accumulated.  enable: 0 = off, 1 = every stage, 2 + s = only stage s (one event pair per MSM: the event
+ * packets between kernels cost ~5 us each, which is 5-8 % of a 2^20 MSM when all nine stages are bracketed). */
 int h2agg_profile_enable(h2agg_ctx* ctx, int enable);
 int h2agg_profile_reset(h2agg_ctx* ctx);
 /* Number of stages; name of stage i; accumulated milliseconds and launch count of stage i. */
