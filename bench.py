@@ -70,7 +70,7 @@ def measured_traffic(stage_name: str, log2n: int):
     return None
 
 
-def aggregation_leg(pkg, eng, args, rank, world, dist, devs):
+def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
     """Secondary figure (BASELINE.json metric, second half): aggregated proofs/s through the full
     EvaluationQuerySchema::eval path.  `agg_proofs` synthetic proofs per GPU (shape: `agg_commitments`
     advice columns, 3 rotation groups), sharded round-robin, one all-gather of the partial (W_x, W_g)."""
@@ -103,6 +103,23 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs):
         spec = [(rot, key, z, pts[(i * 131 + k) % pool_n], fr()) for k, (rot, key, z) in enumerate(qs)]
         specs.append((spec, [pts[(i + 1) % pool_n], pts[(i + 2) % pool_n], pts[(i + 3) % pool_n]], fr(), fr()))
 
+    # assign_instance_commitment (verify.rs:574-649): every proof's instance column is committed against the fixed
+    # g_lagrange table with an MSM of 2^k - (blinding_factors + 1) scalars (k = 17, l = 6).
+    # Instance scalars are resident in HBM (seeded per global proof id); the first 2^k entries of `g_table` stand in
+    # for g_lagrange.
+    n_inst = ((1 << args.agg_instance_log2) - 6) if args.agg_instance_log2 else 0
+    d_inst = d_inst_out = None
+    my_idx = agg.shard_indices(n_total, world, rank)
+    if n_inst and my_idx:
+        rows = []
+        for i in my_idx:                                       # seeded per GLOBAL proof id: sharding-independent
+            gen = torch.Generator(device="cpu").manual_seed(0x1A57 + i)
+            rows.append(torch.randint(0, 256, (n_inst, 32), dtype=torch.uint8, generator=gen))
+        inst = torch.stack(rows)
+        inst[:, :, 31] &= 0x1F                                 # < 2^253 < r: canonical
+        d_inst = inst.to(dev)                                  # this rank's proofs, contiguous: [local][n_inst][32]
+        d_inst_out = torch.zeros((len(my_idx), 96), dtype=torch.uint8, device=dev)
+
     packed = []
     for spec, w, v, u in specs:      # byte-level packing of the proof data (what a transcript reader hands over)
         packed.append(([k for _r, k, _z, _c, _e in spec], b"".join(c for *_x, c, _e in spec),
@@ -112,11 +129,21 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs):
     def build(b, idx):
         """per proof: n x EvaluationQuery::new + batch_multi_open_proofs, both in the C++ host layer"""
         out = []
+        if n_inst and idx:   # queue the instance-column MSMs first; the host builds the schemas underneath them
+            assert list(idx) == my_idx
+            # ONE batched MSM: all of this rank's instance columns against the shared g_lagrange table
+            eng.g1_msm_device_batch_async(g_table, d_inst.data_ptr(), n_inst, len(idx), d_inst_out.data_ptr())
+        first = []
         for i in idx:
             keys, commitments, evals, rots, zs, wbytes, v, u = packed[i]
             qnodes = b.evaluation_queries(keys, commitments, evals, wrap=False)
+            first.append(qnodes[0])
             w_x, w_g = b.batch_multi_open("p%d" % i, rots, zs, qnodes, wbytes, v, u)
             out.append(mo.MultiOpenProof(w_x, w_g))
+        if n_inst and idx:
+            aff = eng.g1_batch_to_affine_device(d_inst_out.data_ptr(), len(idx))
+            for j, q in enumerate(first):
+                b.query_set_commitment(q, aff[64 * j:64 * j + 64])
         return out
 
     agg.aggregate_sharded(backend, build, n_total, lam, dist=dist, device=coll_dev)     # warm-up
@@ -140,9 +167,12 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs):
         "proofs": n_total,
         "seconds_per_aggregation": dt,
         "commitments_per_proof": len(specs[0][0]),
+        "instance_msm_points_per_proof": n_inst,
         "final_pair_sha": __import__("hashlib").sha256(pair[0] + pair[1]).hexdigest()[:16],
-        "note": "synthetic shape-faithful schemas; includes host-side schema construction (Python + C++), "
-                "device Fr tape, MSM, +/- e*G, to_affine, and the all-gather + fold of the partial (W_x, W_g)",
+        "note": "synthetic shape-faithful schemas; per proof: the instance-column commitment MSM against the fixed "
+                "g_lagrange table (instance scalars resident in HBM), host-side schema construction (Python + C++) "
+                "underneath it; then the device Fr tape, the two multi_exps, +/- e*G, to_affine, and the all-gather + "
+                "fold of the partial (W_x, W_g)",
     }
 
 
@@ -164,6 +194,8 @@ def main():
     ap.add_argument("--overlap-level", type=int, default=2, help="1: only the Horner tail overlaps; 2: + bucket reduction")
     ap.add_argument("--agg-proofs", type=int, default=4, help="proofs per GPU in the aggregation leg (0 = skip)")
     ap.add_argument("--agg-commitments", type=int, default=300, help="advice commitments per synthetic proof")
+    ap.add_argument("--agg-instance-log2", type=int, default=17,
+                    help="k of the per-proof instance-column commitment MSM (2^k - 6 scalars); 0 = leave it out")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -285,10 +317,17 @@ def main():
 
     agg_info = None
     if args.agg_proofs > 0:
-        agg_info = aggregation_leg(pkg, eng, args, rank, world, dist, (dev, coll_dev))  # configs[2]/[3]: 4 proofs per GPU
+        g_table = None
+        if args.agg_instance_log2:     # stands in for ParamsKZG.g_lagrange: the SAME table on every rank
+            gen = torch.Generator(device="cpu").manual_seed(0x6C61)
+            gk = torch.randint(0, 256, (1 << args.agg_instance_log2, 32), dtype=torch.uint8, generator=gen)
+            gk[:, 31] &= 0x1F
+            gk = gk.to(dev)
+            g_table = eng.bases_generate(gk.data_ptr(), 1 << args.agg_instance_log2)
+        agg_info = aggregation_leg(pkg, eng, args, rank, world, dist, (dev, coll_dev), g_table)  # configs[2]/[3]: 4 proofs per GPU
         big = argparse.Namespace(**vars(args))
         big.agg_proofs = 4 * args.agg_proofs                                       # configs[4]: 16 proofs per GPU
-        more = aggregation_leg(pkg, eng, big, rank, world, dist, (dev, coll_dev))
+        more = aggregation_leg(pkg, eng, big, rank, world, dist, (dev, coll_dev), g_table)
         if agg_info is not None and more is not None:
             agg_info["at_%d_proofs_per_gpu" % big.agg_proofs] = {
                 k: more[k] for k in ("proofs_per_sec", "proofs", "seconds_per_aggregation")}

@@ -93,6 +93,9 @@ def load_library():
         "h2agg_evaluate_multiopen_proof": (i32, [C.c_void_p, C.c_uint32, C.c_uint32, vp, vp]),
         "h2agg_schema_name_count": (C.c_size_t, [C.c_void_p]),
         "h2agg_schema_name": (C.c_char_p, [C.c_void_p, C.c_size_t]),
+        "h2agg_g1_msm_device_batch_async": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
+        "h2agg_schema_query_set_commitment": (C.c_int, [C.c_void_p, C.c_uint32, C.c_char_p]),
+        "h2agg_g1_batch_to_affine_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p]),
         "h2agg_schema_names_joined": (C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t]),
         "h2agg_schema_point_list_len": (C.c_size_t, [C.c_void_p]),
         "h2agg_msm_configure": (i32, [ctxp, i32, i32, i32]),
@@ -210,6 +213,11 @@ class H2Agg:
         self._check(self._lib.h2agg_g1_batch_to_affine(self._ctx, jac, n, out))
         return out.raw[:64 * n]
 
+    def g1_batch_to_affine_device(self, d_jac_ptr: int, n: int) -> bytes:
+        out = C.create_string_buffer(64 * n)
+        self._check(self._lib.h2agg_g1_batch_to_affine_device(self._ctx, C.c_void_p(d_jac_ptr), n, out))
+        return out.raw
+
     def g1_sum(self, jac: bytes) -> bytes:
         out = C.create_string_buffer(96)
         self._check(self._lib.h2agg_g1_sum(self._ctx, jac, len(jac) // 96, out))
@@ -264,6 +272,10 @@ class H2Agg:
         self._check(self._lib.h2agg_g1_msm_device_async(self._ctx, handle, d_scalars_ptr, n, d_out_ptr))
 
     # ------------------------------------------------------------------ tuning / measurement
+    def g1_msm_device_batch_async(self, handle: int, d_scalars_ptr: int, n: int, batch: int, d_out_ptr: int):
+        self._check(self._lib.h2agg_g1_msm_device_batch_async(self._ctx, handle, C.c_void_p(d_scalars_ptr), n, batch,
+                                                              C.c_void_p(d_out_ptr)))
+
     def msm_configure(self, window_bits: int = 0, reduce_segment: int = 0, big_bucket_threshold: int = 0):
         self._check(self._lib.h2agg_msm_configure(self._ctx, window_bits, reduce_segment, big_bucket_threshold))
 
@@ -352,6 +364,10 @@ class SchemaBuilder:
         if not wrap:
             return out
         return [EvaluationQuerySchema(self, out[i]) for i in range(n)]
+
+    def query_set_commitment(self, query_node, point_aff: bytes):
+        node = query_node.node if isinstance(query_node, EvaluationQuerySchema) else int(query_node)
+        self.eng._check(self._lib.h2agg_schema_query_set_commitment(self._s, node, point_aff))
 
     def batch_multi_open(self, key: str, rotations: Sequence[int], points: bytes, query_nodes, w: bytes,
                          v: bytes, u: bytes):

@@ -177,7 +177,7 @@ int choose_window(size_t n, bool glv) {
     return n <= ((size_t)1 << 12) ? 8 : n < ((size_t)1 << 19) ? 15 : 16;
 }
 
-MsmPlan make_plan(const h2agg_ctx* c, size_t n) {
+MsmPlan make_plan(const h2agg_ctx* c, size_t n, uint32_t batch = 1) {
     MsmPlan p;
     // GLV halves the latency-shaped stages (reduction, Horner tail) at the price of ~5 % more work in the
     // accumulation (beta multiplications): a win whenever those stages are exposed — single-MSM latency mode, or
@@ -187,7 +187,7 @@ MsmPlan make_plan(const h2agg_ctx* c, size_t n) {
     p.c = c->cfg_c ? c->cfg_c : choose_window(n, p.glv);
     p.W = window_count(p.c, p.glv);
     p.NB = 1u << (p.c - 1);
-    p.NBT = (uint32_t)p.W * p.NB;
+    p.NBT = (uint32_t)p.W * batch * p.NB;   // a batch of MSMs over one table is one MSM with batch x W windows
     // segment length of the bucket reduction: ~1024 waves of running sums (profiles/r01_sweeps.txt)
     uint32_t seg = c->cfg_seg ? (uint32_t)c->cfg_seg : (p.NBT >= (1u << 18) ? 8u : (p.NBT >= (1u << 15) ? 4u : 2u));
     if (seg > p.NB) seg = p.NB;
@@ -256,10 +256,17 @@ int join_tails(h2agg_ctx* c) {
 
 // The MSM proper.  d_bases: Montgomery affine table; d_scalars: canonical 32-B scalars (device).
 // Result: c->d_res_xyzz (Montgomery XYZZ) and, if d_out_jac != nullptr, canonical Jacobian there.
-int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size_t n, uint8_t* d_out_jac) {
+// batch > 1: `batch` MSMs over the SAME n bases, scalars laid out [batch][n]; results: canonical Jacobian at
+// d_out_jac[96 * q] (c->d_res_xyzz then only holds MSM 0's XYZZ).  One set of launches does all of them: every
+// scalar's windows are numbered q * W + w, and the stages after the sort only see batch * W windows.
+int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size_t n_base, uint8_t* d_out_jac,
+            uint32_t batch = 1) {
+    const size_t n = n_base * batch;   // scalars
     if (n >= ((size_t)1 << 30)) return fail(c, H2AGG_ERR_INVALID, "n must be < 2^30");
-    MsmPlan p = make_plan(c, n);
-    const size_t nent = n * (size_t)p.W * (p.glv ? 2 : 1);   // bucket insertions
+    MsmPlan p = make_plan(c, n_base, batch);
+    const int W1 = p.W;                       // windows per MSM
+    const uint32_t WT = (uint32_t)W1 * batch;  // windows in total
+    const size_t nent = n * (size_t)W1 * (p.glv ? 2 : 1);   // bucket insertions
     if (!c->cfg_big) {
         // a lane walks a bucket alone up to `big` entries: 8x the mean keeps a denser top window (up to 4x the mean
         // when it holds c-2 bits) out of the workgroup-per-chunk path, whose LDS tree only pays for real outliers
@@ -270,23 +277,27 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     SortPlan sp;
     const int want_sub = c->cfg_sub_bits ? c->cfg_sub_bits : SORT_SUB_BITS;
     sp.sub_bits = (p.c - 1 < want_sub) ? p.c - 1 : want_sub;
-    while (((uint32_t)p.W * (p.NB >> sp.sub_bits)) > (uint32_t)SORT_MAX_PW && sp.sub_bits < p.c - 1 &&
+    while ((WT * (p.NB >> sp.sub_bits)) > (uint32_t)SORT_MAX_PW && sp.sub_bits < p.c - 1 &&
            sp.sub_bits < SORT_MAX_SUB_BITS)
         ++sp.sub_bits;  // keep the level-1 partition count within its LDS counters
     sp.SB = 1u << sp.sub_bits;
     sp.ppw = p.NB >> sp.sub_bits;
-    sp.PW = (uint32_t)p.W * sp.ppw;
+    sp.PW = WT * sp.ppw;
+    if (batch > 1) {
+        sp.n_base = (uint32_t)n_base;
+        sp.W1 = (uint32_t)W1;
+    }
     sp.tile = c->cfg_tile ? (uint32_t)c->cfg_tile : 2048u;
     // packed-item staged path: index field of 31 - sub_bits bits, a tile's keys must fit the LDS stage
     sp.glv = p.glv;
     const int idx_bits = (p.glv ? 30 : 31) - sp.sub_bits;   // packed item: sub | neg | (endo) | idx
-    bool staged = !c->cfg_no_stage && n <= ((size_t)1 << idx_bits);
-    const size_t keys_per_scalar = (size_t)p.W * (p.glv ? 2 : 1);
+    bool staged = !c->cfg_no_stage && n_base <= ((size_t)1 << idx_bits);   // items carry the BASE index
+    const size_t keys_per_scalar = (size_t)W1 * (p.glv ? 2 : 1);
     if (staged && c->cfg_stage_l1 && (size_t)sp.tile * keys_per_scalar > (size_t)STAGE_ITEMS)
         sp.tile = (uint32_t)(STAGE_ITEMS / keys_per_scalar);
     if (staged && sp.tile < (uint32_t)BLOCK) staged = false;
     if (sp.PW > (uint32_t)SORT_MAX_PW) return fail(c, H2AGG_ERR_INVALID, "too many sort partitions");
-    const uint32_t nseg_total = (uint32_t)p.W * p.spw;
+    const uint32_t nseg_total = WT * p.spw;
     // 4 lanes per chain in the bucket reduction / window sums (latency) or 1 (least work): see msm_kernels.cuh
     static const int par4_env = getenv("H2AGG_PAR4") ? atoi(getenv("H2AGG_PAR4")) : 0;
     const bool par4 = par4_env ? par4_env > 0 : nseg_total <= 16384;   // measured: wins up to c = 13, loses (extra work) above
@@ -303,7 +314,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     // runs while MSM k+1 fills the other set
     TRY(ensure(c, c->buckets, h2agg_ctx::TAIL_SLOTS * (size_t)p.NBT * XYZZ_BYTES));
     TRY(ensure(c, c->segsum, h2agg_ctx::TAIL_SLOTS * (size_t)nseg_total * XYZZ_BYTES));
-    TRY(ensure(c, c->wsum, h2agg_ctx::TAIL_SLOTS * (size_t)p.W * XYZZ_BYTES));
+    TRY(ensure(c, c->wsum, h2agg_ctx::TAIL_SLOTS * (size_t)WT * XYZZ_BYTES));
     const size_t max_slots = nent / BIG_CHUNK + nent / ((size_t)p.big + 1) + 2;   // chunks of over-long buckets
     const size_t max_keys = nent / ((size_t)p.big + 1) + 2;
     TRY(ensure(c, c->big_list, max_slots * 12));
@@ -322,7 +333,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     c->d_res_xyzz = (uint8_t*)c->small.p + 1024 + 144 * par;   // each tail slot has its own XYZZ result
     uint8_t* buckets = (uint8_t*)c->buckets.p + (size_t)par * p.NBT * XYZZ_BYTES;
     uint8_t* segsum = (uint8_t*)c->segsum.p + (size_t)par * nseg_total * XYZZ_BYTES;
-    uint8_t* wsum = (uint8_t*)c->wsum.p + (size_t)par * p.W * XYZZ_BYTES;
+    uint8_t* wsum = (uint8_t*)c->wsum.p + (size_t)par * WT * XYZZ_BYTES;
     uint32_t* big_list = (uint32_t*)c->big_list.p;
     uint32_t* big_keys = (uint32_t*)c->big_keys.p;
     uint8_t* big_part = (uint8_t*)c->big_part.p;
@@ -342,7 +353,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         StageTimer t(c, ST_PART_COUNT);
         HIP_TRY(c, hipMemsetAsync(meta, 0, 12288 * 4, st));
         HIP_TRY(c, hipMemsetAsync(big_count, 0, 8, st));
-        hipLaunchKernelGGL(k_part_count, dim3(ntiles), dim3(BLOCK), 0, st, d_scalars, n, p.c, p.W, sp, pcount,
+        hipLaunchKernelGGL(k_part_count, dim3(ntiles), dim3(BLOCK), 0, st, d_scalars, n, p.c, W1, sp, pcount,
                            c->d_flags);
         hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(BLOCK), 0, st, pcount, sp.PW, pstart, pcursor);
     }
@@ -360,10 +371,10 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         {
             StageTimer t(c, ST_PART_SCATTER);
             if (c->cfg_stage_l1)
-                hipLaunchKernelGGL(k_part_scatter_staged, dim3(ntiles), dim3(BLOCK), lds1, st, d_scalars, n, p.c, p.W,
+                hipLaunchKernelGGL(k_part_scatter_staged, dim3(ntiles), dim3(BLOCK), lds1, st, d_scalars, n, p.c, W1,
                                    sp, idx_bits, pcursor, item_idx);
             else
-                hipLaunchKernelGGL(k_part_scatter_packed, dim3(ntiles), dim3(BLOCK), 0, st, d_scalars, n, p.c, p.W, sp,
+                hipLaunchKernelGGL(k_part_scatter_packed, dim3(ntiles), dim3(BLOCK), 0, st, d_scalars, n, p.c, W1, sp,
                                    idx_bits, pcursor, item_idx);
         }
         {
@@ -374,7 +385,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     } else {
         {
             StageTimer t(c, ST_PART_SCATTER);
-            hipLaunchKernelGGL(k_part_scatter, dim3(ntiles), dim3(BLOCK), 0, st, d_scalars, n, p.c, p.W, sp, pcursor,
+            hipLaunchKernelGGL(k_part_scatter, dim3(ntiles), dim3(BLOCK), 0, st, d_scalars, n, p.c, W1, sp, pcursor,
                                item_idx, item_sub);
         }
         {
@@ -449,9 +460,9 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     {
         StageTimer t(c, ST_WINDOW_SUM, ts);
         if (par4)
-            hipLaunchKernelGGL(k_msm_window_sum_par4, dim3(p.W), dim3(PAR4_THREADS), 0, ts, segsum, p.spw, wsum);
+            hipLaunchKernelGGL(k_msm_window_sum_par4, dim3(WT), dim3(PAR4_THREADS), 0, ts, segsum, p.spw, wsum);
         else
-            hipLaunchKernelGGL(k_msm_window_sum, dim3(p.W), dim3(BLOCK), 0, ts, segsum, p.spw, wsum);
+            hipLaunchKernelGGL(k_msm_window_sum, dim3(WT), dim3(BLOCK), 0, ts, segsum, p.spw, wsum);
     }
     if (c->tail_overlap && c->overlap_level < 2) {
         HIP_TRY(c, hipEventRecord(c->ev_bulk[par], st));
@@ -460,7 +471,8 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     }
     {
         StageTimer t(c, ST_FINAL, ts);
-        hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, ts, wsum, p.c, p.W, c->d_res_xyzz, d_out_jac);
+        hipLaunchKernelGGL(k_msm_final, dim3(batch), dim3(64), 0, ts, wsum, p.c, W1, batch > 1 ? (uint8_t*)nullptr : c->d_res_xyzz,
+                           d_out_jac);
     }
     if (c->tail_overlap) {
         HIP_TRY(c, hipEventRecord(c->ev_tail[par], c->tail_streams[par]));
@@ -689,6 +701,19 @@ int h2agg_g1_batch_to_affine(h2agg_ctx* c, const uint8_t* in, size_t n, uint8_t*
     return finish(c);
 }
 
+int h2agg_g1_batch_to_affine_device(h2agg_ctx* c, const uint8_t* d_in_jac, size_t n, uint8_t* out) {
+    TRY(bind(c));
+    if (n == 0) return H2AGG_OK;
+    if (!d_in_jac || !out) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    TRY(join_tails(c));   // the inputs are typically results of h2agg_g1_msm_device_async
+    TRY(ensure(c, c->out, 64 * n));
+    TRY(clear_flags(c));
+    hipLaunchKernelGGL(k_g1_batch_to_affine, dim3(grid_for(c, n)), dim3(BLOCK), 0, c->stream, d_in_jac, n,
+                       (uint8_t*)c->out.p, c->d_flags);
+    HIP_TRY(c, hipMemcpyAsync(out, c->out.p, 64 * n, hipMemcpyDeviceToHost, c->stream));
+    return finish(c);
+}
+
 int h2agg_g1_sum(h2agg_ctx* c, const uint8_t* in, size_t n, uint8_t out[96]) {
     TRY(bind(c));
     if (!out || (n && !in)) return fail(c, H2AGG_ERR_INVALID, "null buffer");
@@ -784,6 +809,32 @@ int h2agg_g1_msm_device_async(h2agg_ctx* c, uint64_t handle, const void* d_scala
     if (n == 0) return fail(c, H2AGG_ERR_EMPTY, "multi_exp of zero pairs (reference panics: mock/arith/ecc.rs:128)");
     if (n > it->second.n) return fail(c, H2AGG_ERR_INVALID, "more scalars than bases in the table");
     return msm_run(c, it->second.d, (const uint8_t*)d_scalars, n, (uint8_t*)d_out_jac);
+}
+
+int h2agg_g1_msm_device_batch_async(h2agg_ctx* c, uint64_t handle, const void* d_scalars, size_t n, size_t batch,
+                                    void* d_out_jac) {
+    TRY(bind(c));
+    auto it = c->tables.find(handle);
+    if (it == c->tables.end()) return fail(c, H2AGG_ERR_INVALID, "unknown base-table handle");
+    if (!d_scalars || !d_out_jac) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    if (n == 0 || batch == 0)
+        return fail(c, H2AGG_ERR_EMPTY, "multi_exp of zero pairs (reference panics: mock/arith/ecc.rs:128)");
+    if (n > it->second.n) return fail(c, H2AGG_ERR_INVALID, "more scalars than bases in the table");
+    // MSMs per set of launches: the level-1 sort partitions (batch * W * NB >> sub_bits, sub_bits <= 11) must fit its
+    // LDS counters, and the entry count its 32-bit offsets
+    const MsmPlan p1 = make_plan(c, n, 1);
+    uint32_t ppw_min = p1.NB >> 11;
+    if (ppw_min < 1) ppw_min = 1;
+    size_t per = (size_t)SORT_MAX_PW / ((size_t)p1.W * ppw_min);
+    const size_t ent1 = n * (size_t)p1.W * (p1.glv ? 2 : 1);
+    if (per * ent1 >= ((size_t)1 << 31)) per = (((size_t)1 << 31) - 1) / ent1;
+    if (per * n >= ((size_t)1 << 29)) per = (((size_t)1 << 29) - 1) / n;
+    if (per < 1) per = 1;
+    for (size_t q = 0; q < batch; q += per) {
+        const size_t b = batch - q < per ? batch - q : per;
+        TRY(msm_run(c, it->second.d, (const uint8_t*)d_scalars + 32 * n * q, n, (uint8_t*)d_out_jac + 96 * q, (uint32_t)b));
+    }
+    return H2AGG_OK;
 }
 
 int h2agg_g1_msm_device(h2agg_ctx* c, uint64_t handle, const void* d_scalars, size_t n, uint8_t out[96]) {

@@ -361,7 +361,10 @@ __global__ void __launch_bounds__(PAR4_THREADS) k_msm_window_sum_par4(const uint
 // One wave; the point is replicated across lanes, lanes cooperate in groups of 4 on every doubling.
 __global__ void __launch_bounds__(64) k_msm_final(const uint8_t* __restrict__ wsum, int c, int W,
                                                   uint8_t* __restrict__ out_xyzz, uint8_t* __restrict__ out_jac) {
-    if (blockIdx.x != 0) return;
+    // one workgroup (one wave) per MSM of a batch: its W windows start at wsum[blockIdx.x * W]
+    wsum += XYZZ_BYTES * (size_t)blockIdx.x * W;
+    if (out_xyzz) out_xyzz += XYZZ_BYTES * (size_t)blockIdx.x;
+    if (out_jac) out_jac += 96 * (size_t)blockIdx.x;
     // this wave carries the whole latency chain: let it win issue arbitration against the bulk kernels of the
     // next MSM that share its SIMD in overlap mode
     __builtin_amdgcn_s_setprio(3);

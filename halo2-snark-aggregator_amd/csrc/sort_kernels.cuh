@@ -33,6 +33,10 @@ struct SortPlan {
     uint32_t PW;       // partitions = W * ppw (<= SORT_MAX_PW)
     uint32_t tile;     // scalars per level-1 workgroup
     bool glv;          // `scalars` are glv_decompose() words
+    // batched MSMs over ONE base table: scalar j belongs to MSM q = j / n_base, refers to base j - q * n_base and
+    // its windows are numbered q * W1 + w (so every stage downstream just sees more windows).  n_base = 0: no batch.
+    uint32_t n_base = 0;
+    uint32_t W1 = 0;
 };
 
 // ------------------------------------------------------------------ GLV (endomorphism) decomposition
@@ -230,6 +234,9 @@ constexpr uint32_t ENT_IDX = 0x3fffffffu;
         if (live_) nxt_ = u256_load(scalars + 32 * i);                                 \
         while (live_) {                                                                \
             U256 s = nxt_;                                                             \
+            const uint32_t q_ = sp.n_base ? (uint32_t)i / sp.n_base : 0u;              \
+            const uint32_t wofs = q_ * sp.W1;            /* window offset of MSM q */   \
+            const uint32_t bi = (uint32_t)i - q_ * sp.n_base;   /* base index */        \
             const uint32_t kn_ = k_ + BLOCK;                                           \
             const size_t in_ = base + kn_;                                             \
             const bool more_ = kn_ < sp.tile && in_ < n;                               \
@@ -252,7 +259,7 @@ __global__ void __launch_bounds__(BLOCK) k_part_count(const uint8_t* __restrict_
     TILE_SCALARS_BEGIN(threadIdx.x)
         if (!sp.glv) bad |= !u256_is_canonical_fr(s);  // (GLV words were range-checked by k_glv_decompose)
         msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool, bool) {
-            atomicAdd(&cnt[(uint32_t)w * sp.ppw + (b >> sp.sub_bits)], 1u);
+            atomicAdd(&cnt[((uint32_t)w + wofs) * sp.ppw + (b >> sp.sub_bits)], 1u);
         });
     TILE_SCALARS_END
     if (bad) atomicOr(flags, FLAG_NONCANONICAL);
@@ -309,7 +316,7 @@ __global__ void __launch_bounds__(BLOCK) k_part_scatter(const uint8_t* __restric
     const size_t base = (size_t)blockIdx.x * sp.tile;
     TILE_SCALARS_BEGIN(threadIdx.x)
         msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool, bool) {
-            atomicAdd(&cnt[(uint32_t)w * sp.ppw + (b >> sp.sub_bits)], 1u);
+            atomicAdd(&cnt[((uint32_t)w + wofs) * sp.ppw + (b >> sp.sub_bits)], 1u);
         });
     TILE_SCALARS_END
     __syncthreads();
@@ -322,9 +329,9 @@ __global__ void __launch_bounds__(BLOCK) k_part_scatter(const uint8_t* __restric
     const uint32_t submask = sp.SB - 1u;
     TILE_SCALARS_BEGIN(threadIdx.x)
         msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool neg, bool endo) {
-            const uint32_t p = (uint32_t)w * sp.ppw + (b >> sp.sub_bits);
+            const uint32_t p = ((uint32_t)w + wofs) * sp.ppw + (b >> sp.sub_bits);
             const uint32_t pos = basep[p] + atomicAdd(&cnt[p], 1u);
-            item_idx[pos] = (uint32_t)i | (neg ? ENT_NEG : 0u) | (endo ? ENT_ENDO : 0u);
+            item_idx[pos] = bi | (neg ? ENT_NEG : 0u) | (endo ? ENT_ENDO : 0u);
             item_sub[pos] = (uint16_t)(b & submask);
         });
     TILE_SCALARS_END
@@ -423,7 +430,7 @@ __global__ void __launch_bounds__(BLOCK) k_part_scatter_staged(const uint8_t* __
     const size_t base = (size_t)blockIdx.x * sp.tile;
     TILE_SCALARS_BEGIN(tid)
         msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool, bool) {
-            atomicAdd(&len[(uint32_t)w * sp.ppw + (b >> sp.sub_bits)], 1u);
+            atomicAdd(&len[((uint32_t)w + wofs) * sp.ppw + (b >> sp.sub_bits)], 1u);
         });
     TILE_SCALARS_END
     __syncthreads();
@@ -462,9 +469,9 @@ __global__ void __launch_bounds__(BLOCK) k_part_scatter_staged(const uint8_t* __
     const uint32_t submask = sp.SB - 1u;
     TILE_SCALARS_BEGIN(tid)
         msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool neg, bool endo) {
-            const uint32_t p = (uint32_t)w * sp.ppw + (b >> sp.sub_bits);
+            const uint32_t p = ((uint32_t)w + wofs) * sp.ppw + (b >> sp.sub_bits);
             const uint32_t r = atomicAdd(&cur[p], 1u);
-            stage[lbase[p] + r] = pack_item(b & submask, neg, endo, (uint32_t)i, idx_bits, sp.glv);
+            stage[lbase[p] + r] = pack_item(b & submask, neg, endo, bi, idx_bits, sp.glv);
         });
     TILE_SCALARS_END
     __syncthreads();
@@ -489,7 +496,7 @@ __global__ void __launch_bounds__(BLOCK) k_part_scatter_packed(const uint8_t* __
     const size_t base = (size_t)blockIdx.x * sp.tile;
     TILE_SCALARS_BEGIN(threadIdx.x)
         msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool, bool) {
-            atomicAdd(&cnt[(uint32_t)w * sp.ppw + (b >> sp.sub_bits)], 1u);
+            atomicAdd(&cnt[((uint32_t)w + wofs) * sp.ppw + (b >> sp.sub_bits)], 1u);
         });
     TILE_SCALARS_END
     __syncthreads();
@@ -502,9 +509,9 @@ __global__ void __launch_bounds__(BLOCK) k_part_scatter_packed(const uint8_t* __
     const uint32_t submask = sp.SB - 1u;
     TILE_SCALARS_BEGIN(threadIdx.x)
         msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool neg, bool endo) {
-            const uint32_t p = (uint32_t)w * sp.ppw + (b >> sp.sub_bits);
+            const uint32_t p = ((uint32_t)w + wofs) * sp.ppw + (b >> sp.sub_bits);
             const uint32_t pos = basep[p] + atomicAdd(&cnt[p], 1u);
-            items[pos] = pack_item(b & submask, neg, endo, (uint32_t)i, idx_bits, sp.glv);
+            items[pos] = pack_item(b & submask, neg, endo, bi, idx_bits, sp.glv);
         });
     TILE_SCALARS_END
 }

@@ -92,6 +92,9 @@ int h2agg_g1_batch_scalar_mul(h2agg_ctx* ctx, const uint8_t* bases_aff, const ui
 /* replaces: MockEccChip::to_value = `to_affine` (halo2-snark-aggregator-api/src/mock/arith/ecc.rs:64-66). */
 int h2agg_g1_batch_to_affine(h2agg_ctx* ctx, const uint8_t* in_jac, size_t n, uint8_t* out_aff);
 
+/* h2agg_g1_batch_to_affine for Jacobian points already in device memory (e.g. the outputs of
+ * h2agg_g1_msm_device_async: N instance-column commitments become affine with one launch and one download). */
+int h2agg_g1_batch_to_affine_device(h2agg_ctx* ctx, const uint8_t* d_in_jac, size_t n, uint8_t* out_aff);
 /* Sum of n Jacobian points (the local fold after the multi-GPU all-gather of partial (W_x, W_g),
  * SURVEY.md §8e; arithmetic = MockEccChip::add, mock/arith/ecc.rs:30-37).  n == 0 -> identity. */
 int h2agg_g1_sum(h2agg_ctx* ctx, const uint8_t* in_jac, size_t n, uint8_t out_jac[96]);
@@ -139,6 +142,12 @@ int h2agg_g1_msm_device(h2agg_ctx* ctx, uint64_t bases_handle, const void* d_sca
  * to DEVICE memory at d_out_jac; nothing is copied to the host and the call does not synchronise. */
 int h2agg_g1_msm_device_async(h2agg_ctx* ctx, uint64_t bases_handle, const void* d_scalars, size_t n,
                               void* d_out_jac);
+/* `batch` MSMs over the SAME first n bases of the table, scalars laid out [batch][n] in device memory, results
+ * d_out_jac[96 * q].  One set of launches computes all of them (the MSMs become extra windows of one bucket sort), so
+ * many medium-sized MSMs fill the chip like one large one: the N instance-column commitments of N proofs against
+ * ParamsKZG.g_lagrange (assign_instance_commitment, verify.rs:574-649) are this shape. */
+int h2agg_g1_msm_device_batch_async(h2agg_ctx* ctx, uint64_t bases_handle, const void* d_scalars, size_t n, size_t batch,
+                                    void* d_out_jac);
 
 /* ---- EvaluationQuerySchema (the entry point of the hot path) ---------------------------------------
  * replaces: the AST of halo2-snark-aggregator-api/src/systems/halo2/evaluation.rs:15-27 and its
@@ -159,6 +168,10 @@ int h2agg_schema_estimate(h2agg_schema* s, uint32_t node, size_t* out);         
 /* n x EvaluationQuery::new (evaluation.rs:100-118): nodes_out[i] = commit!(cq_i) + eval!(cq_i). */
 int h2agg_schema_evaluation_queries(h2agg_schema* s, size_t n, const char* const* keys, const uint8_t* commitments,
                                     const uint8_t* evals, uint32_t* nodes_out);
+/* Replace the commitment of an EvaluationQuery node created by h2agg_schema_evaluation_queries.  Lets the host build
+ * the schema while the device is still computing that commitment (assign_instance_commitment's MSM,
+ * verify.rs:574-649, whose result is the first query of every proof). */
+int h2agg_schema_query_set_commitment(h2agg_schema* s, uint32_t query_node, const uint8_t point_aff[64]);
 /* replaces: VerifierParams::get_point_schemas + batch_multi_open_proofs
  * (halo2-snark-aggregator-api/src/systems/halo2/multiopen.rs:23-102): queries (rotation, evaluation point,
  * schema node) in VerifierParams::queries order are grouped by rotation in first-seen order, Horner-folded

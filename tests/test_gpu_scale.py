@@ -176,3 +176,35 @@ def test_msm_2p20_against_cpu_pippenger(eng):
         assert got == cref.msm_pippenger(bases, bytes(s_np.tobytes()), n, 16, 16)
     finally:
         eng.bases_free(table)
+
+
+@pytest.mark.parametrize("n,batch,glv", [(3000, 5, 0), (1 << 15, 3, 0), (1 << 15, 3, -1), (77, 20, 0), (1 << 17, 6, 0)])
+def test_msm_batch_over_one_table(eng, n, batch, glv):
+    """h2agg_g1_msm_device_batch_async: `batch` MSMs over the same bases in one set of launches must each equal
+    the single MSM (and (sum k_i s_i) * G); covers chunking (6 x 2^17 is split) and both scalar recodings."""
+    dev = torch.device("cuda", 0)
+    ks, k_np = _workload(n, 11)
+    d_k = torch.from_numpy(k_np.copy()).to(dev)
+    table = eng.bases_generate(d_k.data_ptr(), n)
+    eng.msm_configure_glv(glv)
+    try:
+        rows, arrs = [], []
+        for q in range(batch):
+            v, a = _workload(n, 100 + q)
+            if q == 1:                       # an all-zero scalar vector inside the batch: identity result
+                v, a = [0] * n, np.zeros((n, 32), dtype=np.uint8)
+            rows.append(v)
+            arrs.append(a)
+        d_s = torch.from_numpy(np.stack(arrs).copy()).to(dev)
+        d_out = torch.zeros((batch, 96), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        eng.g1_msm_device_batch_async(table, d_s.data_ptr(), n, batch, d_out.data_ptr())
+        got = eng.g1_batch_to_affine_device(d_out.data_ptr(), batch)
+        for q in range(batch):
+            single = eng.g1_batch_to_affine(eng.g1_msm_device(table, d_s[q].data_ptr(), n))
+            assert got[64 * q:64 * q + 64] == single, q
+            t = sum(k * s for k, s in zip(ks, rows[q])) % O.R
+            assert single == O.aff_to_bytes(O.scalar_mul(t, O.G1)), q
+    finally:
+        eng.msm_configure_glv(0)
+        eng.bases_free(table)
