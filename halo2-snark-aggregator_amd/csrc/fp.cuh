@@ -389,21 +389,126 @@ FP_INLINE Fp<P> fp_from_mont(const Fp<P>& a) {
     return fp_cond_sub<P>(fp_mul<P>(a, one));
 }
 
-// a^(m-2) (Fermat), Montgomery in / out (< 2m).  inv(0) = 0; callers mirroring `invert().unwrap()` test first.
-template <class P>
-__device__ __noinline__ Fp<P> fp_inv(const Fp<P>& a) {
-    // exponent m - 2 as 8 x 32-bit words, recomposed from the 29-bit limbs at compile time
-    Fp<P> acc = Fp<P>::one();
+// ---- modular inverse: safegcd (Bernstein-Yang divsteps, "half-delta" variant) on signed 29-bit limbs -----------
+// 21 rounds of 29 division steps (609 >= the 590 that 256-bit inputs need), each round: a 2x2 transition matrix from
+// the low limbs of (f, g) with branch-free integer ops, then (f, g) <- M (f, g) / 2^29 exactly and
+// (d, e) <- M (d, e) / 2^29 mod m.  ~13 k instructions against ~85 k for the Fermat ladder (254 squarings + ~127
+// multiplications) it replaces: a to_affine is one inversion of pure dependent latency on its lane, 0.2 ms before.
+// Invariants: d * x = f, e * x = g (mod m, up to the powers of two divided out); f ends as +-1 with g = 0.
+struct Trans2x2 {
+    int32_t u, v, q, r;
+};
+FP_INLINE int32_t fp_divsteps29(int32_t zeta, uint32_t f0, uint32_t g0, Trans2x2& t) {
+    uint32_t u = 1, v = 0, q = 0, r = 1, f = f0, g = g0;
 #pragma unroll 1
-    for (int bit = 253; bit >= 0; --bit) {
-        acc = fp_sqr<P>(acc);
-        const int limb = bit / 29, off = bit % 29;
-        uint32_t w = 0;
-#pragma unroll
-        for (int i = 0; i < NL; ++i) w = (limb == i) ? (P::MOD[i] - (i == 0 ? 2u : 0u)) : w;  // low limb >= 2
-        if ((w >> off) & 1u) acc = fp_mul<P>(acc, a);
+    for (int i = 0; i < 29; ++i) {
+        uint32_t m1 = (uint32_t)(zeta >> 31);            // zeta < 0  (delta > 0)
+        const uint32_t m2 = 0u - (g & 1u);               // g odd
+        const uint32_t x = (f ^ m1) - m1, y = (u ^ m1) - m1, z = (v ^ m1) - m1;   // -f, -u, -v when zeta < 0
+        g += x & m2;
+        q += y & m2;
+        r += z & m2;
+        m1 &= m2;
+        zeta = (int32_t)(((uint32_t)zeta ^ m1) - 1u);     // -zeta - 2 on a swap, zeta - 1 otherwise
+        f += g & m1;
+        u += q & m1;
+        v += r & m1;
+        g >>= 1;
+        u <<= 1;
+        v <<= 1;
     }
-    return acc;
+    t.u = (int32_t)u;
+    t.v = (int32_t)v;
+    t.q = (int32_t)q;
+    t.r = (int32_t)r;
+    return zeta;
+}
+// x^-1 mod m for a canonical integer x (tight limbs, < m); canonical out; 0 -> 0
+template <class P>
+__device__ __noinline__ Fp<P> fp_inv_int(const Fp<P>& x) {
+    constexpr int32_t MASK = (int32_t)M29;
+    constexpr uint32_t MINV = ((1u << 29) - P::NINV) & M29;   // m^-1 mod 2^29
+    int32_t f[NL], g[NL], d[NL], e[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        f[i] = (int32_t)P::MOD[i];
+        g[i] = (int32_t)x.l[i];
+        d[i] = 0;
+        e[i] = (i == 0);
+    }
+    int32_t zeta = -1;
+#pragma unroll 1
+    for (int it = 0; it < 21; ++it) {
+        Trans2x2 t;
+        zeta = fp_divsteps29(zeta, (uint32_t)f[0] | ((uint32_t)f[1] << 29), (uint32_t)g[0] | ((uint32_t)g[1] << 29), t);
+        {   // (d, e) <- t * (d, e) / 2^29 mod m, both kept in (-2m, m)
+            const int32_t sd = d[NL - 1] >> 31, se = e[NL - 1] >> 31;
+            int32_t md = (t.u & sd) + (t.v & se), me = (t.q & sd) + (t.r & se);
+            int64_t cd = (int64_t)t.u * d[0] + (int64_t)t.v * e[0], ce = (int64_t)t.q * d[0] + (int64_t)t.r * e[0];
+            md -= (int32_t)((MINV * (uint32_t)cd + (uint32_t)md) & M29);   // make the low 29 bits of cd + m * md vanish
+            me -= (int32_t)((MINV * (uint32_t)ce + (uint32_t)me) & M29);
+            cd += (int64_t)(int32_t)P::MOD[0] * md;
+            ce += (int64_t)(int32_t)P::MOD[0] * me;
+            cd >>= 29;
+            ce >>= 29;
+#pragma unroll
+            for (int i = 1; i < NL; ++i) {
+                cd += (int64_t)t.u * d[i] + (int64_t)t.v * e[i] + (int64_t)(int32_t)P::MOD[i] * md;
+                ce += (int64_t)t.q * d[i] + (int64_t)t.r * e[i] + (int64_t)(int32_t)P::MOD[i] * me;
+                d[i - 1] = (int32_t)cd & MASK;
+                e[i - 1] = (int32_t)ce & MASK;
+                cd >>= 29;
+                ce >>= 29;
+            }
+            d[NL - 1] = (int32_t)cd;
+            e[NL - 1] = (int32_t)ce;
+        }
+        {   // (f, g) <- t * (f, g) / 2^29, exact
+            int64_t cf = (int64_t)t.u * f[0] + (int64_t)t.v * g[0], cg = (int64_t)t.q * f[0] + (int64_t)t.r * g[0];
+            cf >>= 29;
+            cg >>= 29;
+#pragma unroll
+            for (int i = 1; i < NL; ++i) {
+                cf += (int64_t)t.u * f[i] + (int64_t)t.v * g[i];
+                cg += (int64_t)t.q * f[i] + (int64_t)t.r * g[i];
+                f[i - 1] = (int32_t)cf & MASK;
+                g[i - 1] = (int32_t)cg & MASK;
+                cf >>= 29;
+                cg >>= 29;
+            }
+            f[NL - 1] = (int32_t)cf;
+            g[NL - 1] = (int32_t)cg;
+        }
+    }
+    // d is in (-2m, m) and f = +-1: add m if negative, negate if f = -1, add m again if still negative
+    int32_t ca = d[NL - 1] >> 31;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) d[i] += (int32_t)P::MOD[i] & ca;
+    const int32_t cn = f[NL - 1] >> 31;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) d[i] = (d[i] ^ cn) - cn;
+#pragma unroll
+    for (int i = 0; i < NL - 1; ++i) {
+        d[i + 1] += d[i] >> 29;
+        d[i] &= MASK;
+    }
+    ca = d[NL - 1] >> 31;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) d[i] += (int32_t)P::MOD[i] & ca;
+#pragma unroll
+    for (int i = 0; i < NL - 1; ++i) {
+        d[i + 1] += d[i] >> 29;
+        d[i] &= MASK;
+    }
+    Fp<P> r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = (uint32_t)d[i];
+    return r;
+}
+// Montgomery in (any bound) / out (< 2m).  inv(0) = 0; callers mirroring `invert().unwrap()` test first.
+template <class P>
+FP_INLINE Fp<P> fp_inv(const Fp<P>& a) {
+    return fp_to_mont<P>(fp_inv_int<P>(fp_from_mont<P>(a)));   // (x R) -> x -> x^-1 -> x^-1 R
 }
 
 // ---- 32-byte packed form (8 x 32-bit words, value < 2^256) <-> limbs -------------------------------

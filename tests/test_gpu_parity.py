@@ -127,6 +127,27 @@ def test_g1_batch_to_affine(eng):
     assert eng.g1_batch_to_affine(jac) == bytes(aff)
 
 
+def test_inversion_edges_and_shapes(eng):
+    """The device inverse is a safegcd (divsteps) implementation on signed 29-bit limbs (csrc/fp.cuh): exercise limb
+    boundaries, near-modulus values and short / long operands in both fields against exact big-int inverses."""
+    rng = O.SplitMix64(77)
+    for mod, is_fr in ((O.R, True), (O.P, False)):
+        xs = [1, 2, 3, mod - 1, mod - 2, (mod + 1) // 2, (mod - 1) // 2, mod >> 1, (1 << 29) - 1, 1 << 29, (1 << 29) + 1,
+              (1 << 58) - 1, 1 << 58, (1 << 232) + 1, (1 << 253) + 1, 1 << 128, (1 << 128) - 1]
+        xs += [(rng.fr() * rng.fr()) % (1 << k) or 1 for k in range(1, 254, 2)]
+        xs += [mod - ((rng.fr() % (1 << k)) or 1) for k in range(1, 250, 3)]
+        xs += [rng.fr() % mod or 1 for _ in range(3000)]
+        if is_fr:
+            got = eng.fr_batch_op(4, fr_bytes(xs), None)
+            want = b"".join(pow(x, -1, mod).to_bytes(32, "little") for x in xs)
+            assert got == want
+        else:   # Fq inverses are reached through to_affine: (X, Y, Z) = (x z^2, y z^3, z) must come back as (x, y)
+            n = len(xs)
+            aff = points_from_scalars(rand_frs(rng, 8)) * (n // 8 + 1)
+            aff = aff[:64 * n]
+            assert eng.g1_batch_to_affine(to_jac_bytes(aff, xs)) == aff
+
+
 @pytest.mark.parametrize("n", [0, 1, 2, 8, 300])
 def test_g1_sum(eng, n):
     rng = O.SplitMix64(16 + n)
