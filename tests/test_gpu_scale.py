@@ -208,3 +208,23 @@ def test_msm_batch_over_one_table(eng, n, batch, glv):
     finally:
         eng.msm_configure_glv(0)
         eng.bases_free(table)
+
+
+def test_msm_2p22_identity(eng):
+    """BASELINE.json configs[4] size (2^22 points per MSM): MSM([k_i G], [s_i]) = (sum k_i s_i) G, both recodings."""
+    n = 1 << 22
+    dev = torch.device("cuda", 0)
+    ks, k_np = _workload(n, 21)
+    ss, s_np = _workload(n, 22)
+    d_k = torch.from_numpy(k_np.copy()).to(dev)
+    d_s = torch.from_numpy(s_np.copy()).to(dev)
+    table = eng.bases_generate(d_k.data_ptr(), n)
+    try:
+        t = sum(k * s for k, s in zip(ks, ss)) % O.R
+        want = eng.g1_batch_to_affine(eng.g1_batch_scalar_mul(O.aff_to_bytes(O.G1), O.fe_to_bytes(t)))
+        for glv in (-1, 1):
+            eng.msm_configure_glv(glv)
+            assert eng.g1_batch_to_affine(eng.g1_msm_device(table, d_s.data_ptr(), n)) == want
+    finally:
+        eng.msm_configure_glv(0)
+        eng.bases_free(table)

@@ -137,3 +137,65 @@ def test_cpp_batch_builders_match_oracle(eng, pkg):
         b.batch_multi_open(key, [r for r, *_x in spec], b"".join(O.fe_to_bytes(z) for _r, _k, z, _c, _e in spec),
                            qn, b"".join(O.aff_to_bytes(p) for p in w[:2]), O.fe_to_bytes(v), O.fe_to_bytes(u))
     b.close()
+
+
+def _rand_scalar_tree(rng, depth, consts):
+    """commitment-free subtree: always prepares to exactly one entry"""
+    r = rng.next() % 8
+    if depth <= 0 or r < 3:
+        v = consts[rng.next() % len(consts)]
+        if rng.next() & 1:
+            return S.scalar(v)
+        return S.evalq(S.CommitQuery("", None, v))
+    l, rr = _rand_scalar_tree(rng, depth - 1, consts), _rand_scalar_tree(rng, depth - 1, consts)
+    return l + rr if r < 6 else l * rr
+
+
+def _rand_tree(rng, depth, keys, consts):
+    """subtree with at least one commitment; Mul never has commitments on both sides (evaluation.rs:282)"""
+    r = rng.next() % 10
+    if depth <= 0 or r < 2:
+        k, p = keys[rng.next() % len(keys)]
+        return S.commit(S.CommitQuery(k, p, None))
+    if r < 5:
+        return _rand_tree(rng, depth - 1, keys, consts) + _rand_tree(rng, depth - 1, keys, consts)
+    if r < 6:
+        return _rand_tree(rng, depth - 1, keys, consts) + _rand_scalar_tree(rng, 2, consts)
+    if r < 7:
+        return _rand_scalar_tree(rng, 2, consts) + _rand_tree(rng, depth - 1, keys, consts)
+    if r < 9:
+        return _rand_scalar_tree(rng, 2, consts) * _rand_tree(rng, depth - 1, keys, consts)
+    return _rand_tree(rng, depth - 1, keys, consts) * _rand_scalar_tree(rng, 2, consts)
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_schema_trees_vs_oracle(eng, pkg, seed):
+    """Differential test of the tape recorder (interned constants, power chains, deferred sums: csrc/schema.cuh)
+    on random ASTs: repeated keys (merging), repeated constants, scalar-only subtrees on either side of Add / Mul,
+    and a long Horner chain in one repeated scalar on top."""
+    rng = O.SplitMix64(0x5EED00 + seed)
+    keys = [("k%d" % i, O.scalar_mul(rng.fr(), O.G1)) for i in range(1 + seed % 7)]
+    consts = [rng.fr() for _ in range(1 + seed % 4)] + [1, 0, O.R - 1][:seed % 4]
+    tree = _rand_tree(rng, 2 + seed % 5, keys, consts)
+    v = consts[0]
+    for j in range(5 * (seed % 6)):                   # v*(v*(...) + q) + q: multiopen.rs:56-60 shape
+        k, p = keys[rng.next() % len(keys)]
+        q = S.commit(S.CommitQuery(k, p, None)) + S.evalq(S.CommitQuery("", None, rng.fr()))
+        tree = S.scalar(v) * tree + q
+    ctx, sc, pc = S.OracleCtx(), S.OracleFieldChip(), S.OracleEccChip()
+    b = pkg.SchemaBuilder(eng)
+    g = mirror(pkg, b, tree)
+    assert g.estimate() == tree.estimate()
+    try:
+        want_p, want_e, want_names = tree.eval(ctx, sc, pc, sc.assign_one(ctx))
+    except Exception:
+        with pytest.raises(pkg.H2AggError):
+            g.eval()
+        b.close()
+        return
+    jac, e, names = g.eval()
+    assert names == want_names
+    assert e == (None if want_e is None else O.fe_to_bytes(want_e))
+    assert eng.g1_batch_to_affine(jac) == O.aff_to_bytes(want_p)
+    assert b.point_list_len() == len(ctx.point_list)
+    b.close()
