@@ -34,7 +34,8 @@ const char* const STAGE_NAMES[ST_N] = {"msm_part_count", "msm_part_scatter",   "
                                        "msm_reduce",     "msm_window_sum",     "msm_final"};
 
 struct Table {
-    uint8_t* d = nullptr;  // Montgomery affine, 64 B / point
+    uint8_t* d = nullptr;       // Montgomery affine, 64 B / point
+    uint8_t* endo_x = nullptr;  // beta * x, 32 B / point (made on the first GLV MSM over this table)
     size_t n = 0;
 };
 
@@ -51,7 +52,7 @@ struct h2agg_ctx {
     // grow-only device workspace
     DevBuf in_a, in_b, in_c, out, tmp_bases;                      // host-buffer entry points
     DevBuf hist, offs, pmeta, item_idx, item_sub, order, entries, buckets, segsum, wsum, big_list, big_keys, big_part,
-        glv_buf, parts, small;  // MSM
+        glv_buf, parts, small, endo_buf;  // MSM
     uint32_t* d_flags = nullptr;      // in `small`: [0] status flags, [1] big_count
     uint8_t* d_res_xyzz = nullptr;    // in `small` + 1024 + 144 * slot of the LAST msm_run (see msm_run)
     uint8_t* d_res_jac = nullptr;     // in `small` + 256
@@ -259,8 +260,9 @@ int join_tails(h2agg_ctx* c) {
 // batch > 1: `batch` MSMs over the SAME n bases, scalars laid out [batch][n]; results: canonical Jacobian at
 // d_out_jac[96 * q] (c->d_res_xyzz then only holds MSM 0's XYZZ).  One set of launches does all of them: every
 // scalar's windows are numbered q * W + w, and the stages after the sort only see batch * W windows.
+// d_endo_x: beta * x per base (Table::endo_x) or nullptr = compute it here when the plan uses GLV.
 int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size_t n_base, uint8_t* d_out_jac,
-            uint32_t batch = 1) {
+            uint32_t batch = 1, const uint8_t* d_endo_x = nullptr) {
     const size_t n = n_base * batch;   // scalars
     if (n >= ((size_t)1 << 30)) return fail(c, H2AGG_ERR_INVALID, "n must be < 2^30");
     MsmPlan p = make_plan(c, n_base, batch);
@@ -342,6 +344,12 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     const unsigned ntiles = (unsigned)((n + sp.tile - 1) / sp.tile);
     profile_begin_call(c);
 
+    if (p.glv && !d_endo_x) {
+        TRY(ensure(c, c->endo_buf, n_base * 32));
+        hipLaunchKernelGGL(k_bases_endo_x, dim3(grid_for(c, n_base)), dim3(BLOCK), 0, st, d_bases, n_base,
+                           (uint8_t*)c->endo_buf.p);
+        d_endo_x = (const uint8_t*)c->endo_buf.p;
+    }
     if (p.glv) {  // k = k1 + lambda*k2: the sort below reads the decomposed words instead of the scalars
         TRY(ensure(c, c->glv_buf, n * 32));
         StageTimer t(c, ST_PART_COUNT);
@@ -422,7 +430,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     {
         StageTimer t(c, ST_ACCUM);
         hipLaunchKernelGGL(k_msm_accumulate, dim3((unsigned)(((size_t)p.NBT * lpb + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0,
-                           st, d_bases, entries, offs, hist, order, p.NBT, p.big, lpb, acc_out, big_list, big_keys,
+                           st, d_bases, d_endo_x, entries, offs, hist, order, p.NBT, p.big, lpb, acc_out, big_list, big_keys,
                            big_count);
     }
     {
@@ -430,7 +438,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         size_t grid = max_slots;
         const size_t cap = (size_t)c->cu_count * 4;
         if (grid > cap) grid = cap;
-        hipLaunchKernelGGL(k_msm_accumulate_big, dim3((unsigned)grid), dim3(BLOCK), 0, st, d_bases, entries, offs, hist,
+        hipLaunchKernelGGL(k_msm_accumulate_big, dim3((unsigned)grid), dim3(BLOCK), 0, st, d_bases, d_endo_x, entries, offs, hist,
                            acc_out, lpb, big_part, big_list, big_count);
         size_t gk = max_keys < cap ? max_keys : cap;
         hipLaunchKernelGGL(k_msm_big_combine, dim3((unsigned)gk), dim3(BLOCK), 0, st, big_part, big_keys, big_count,
@@ -559,12 +567,14 @@ void h2agg_destroy(h2agg_ctx* c) {
         if (c->tail_streams[k]) hipStreamSynchronize(c->tail_streams[k]);
     DevBuf* bufs[] = {&c->in_a,  &c->in_b,     &c->in_c,     &c->out,   &c->tmp_bases, &c->hist,
                       &c->offs,  &c->pmeta,    &c->item_idx, &c->item_sub, &c->order,  &c->entries,
-                      &c->buckets, &c->segsum, &c->wsum,     &c->big_list, &c->big_keys, &c->big_part, &c->glv_buf, &c->parts, &c->small,
+                      &c->buckets, &c->segsum, &c->wsum,     &c->big_list, &c->big_keys, &c->big_part, &c->glv_buf, &c->parts, &c->small, &c->endo_buf,
                       &c->sch_regs, &c->sch_in, &c->sch_scalars[0], &c->sch_scalars[1], &c->sch_bases[0], &c->sch_bases[1]};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
-    for (auto& kv : c->tables)
+    for (auto& kv : c->tables) {
         if (kv.second.d) hipFree(kv.second.d);
+        if (kv.second.endo_x) hipFree(kv.second.endo_x);
+    }
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->h_stage) hipHostFree(c->h_stage);
     for (int r = 0; r < h2agg_ctx::PROF_RING; ++r)
@@ -796,11 +806,26 @@ int h2agg_bases_free(h2agg_ctx* c, uint64_t handle) {
     if (it == c->tables.end()) return fail(c, H2AGG_ERR_INVALID, "unknown base-table handle");
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     hipFree(it->second.d);
+    if (it->second.endo_x) hipFree(it->second.endo_x);
     c->tables.erase(it);
     return H2AGG_OK;
 }
 
 // ---------------------------------------------------------------- MSM
+}  // extern "C"
+namespace {
+// beta * x column of a resident table, made once
+int table_endo(h2agg_ctx* c, Table& t, const uint8_t** out) {
+    if (!t.endo_x) {
+        if (hipMalloc((void**)&t.endo_x, 32 * t.n) != hipSuccess) return fail(c, H2AGG_ERR_NOMEM, "hipMalloc(endo table)");
+        hipLaunchKernelGGL(k_bases_endo_x, dim3(grid_for(c, t.n)), dim3(BLOCK), 0, c->stream, (const uint8_t*)t.d, t.n,
+                           t.endo_x);
+    }
+    *out = t.endo_x;
+    return H2AGG_OK;
+}
+}  // namespace
+extern "C" {
 int h2agg_g1_msm_device_async(h2agg_ctx* c, uint64_t handle, const void* d_scalars, size_t n, void* d_out_jac) {
     TRY(bind(c));
     auto it = c->tables.find(handle);
@@ -808,7 +833,9 @@ int h2agg_g1_msm_device_async(h2agg_ctx* c, uint64_t handle, const void* d_scala
     if (!d_scalars || !d_out_jac) return fail(c, H2AGG_ERR_INVALID, "null buffer");
     if (n == 0) return fail(c, H2AGG_ERR_EMPTY, "multi_exp of zero pairs (reference panics: mock/arith/ecc.rs:128)");
     if (n > it->second.n) return fail(c, H2AGG_ERR_INVALID, "more scalars than bases in the table");
-    return msm_run(c, it->second.d, (const uint8_t*)d_scalars, n, (uint8_t*)d_out_jac);
+    const uint8_t* endo = nullptr;
+    TRY(table_endo(c, it->second, &endo));
+    return msm_run(c, it->second.d, (const uint8_t*)d_scalars, n, (uint8_t*)d_out_jac, 1, endo);
 }
 
 int h2agg_g1_msm_device_batch_async(h2agg_ctx* c, uint64_t handle, const void* d_scalars, size_t n, size_t batch,
@@ -830,9 +857,12 @@ int h2agg_g1_msm_device_batch_async(h2agg_ctx* c, uint64_t handle, const void* d
     if (per * ent1 >= ((size_t)1 << 31)) per = (((size_t)1 << 31) - 1) / ent1;
     if (per * n >= ((size_t)1 << 29)) per = (((size_t)1 << 29) - 1) / n;
     if (per < 1) per = 1;
+    const uint8_t* endo = nullptr;
+    TRY(table_endo(c, it->second, &endo));
     for (size_t q = 0; q < batch; q += per) {
         const size_t b = batch - q < per ? batch - q : per;
-        TRY(msm_run(c, it->second.d, (const uint8_t*)d_scalars + 32 * n * q, n, (uint8_t*)d_out_jac + 96 * q, (uint32_t)b));
+        TRY(msm_run(c, it->second.d, (const uint8_t*)d_scalars + 32 * n * q, n, (uint8_t*)d_out_jac + 96 * q, (uint32_t)b,
+                    endo));
     }
     return H2AGG_OK;
 }

@@ -34,15 +34,23 @@ struct MsmPlan {
 };
 
 // ------------------------------------------------------------------ bucket accumulation
-FP_INLINE G1Affine msm_gather(const uint8_t* __restrict__ bases, uint32_t e) {
-    G1Affine p = affine_load(bases + 64 * (size_t)(e & ENT_IDX));
-    if (e & ENT_ENDO) {  // phi(P) = (beta * x, y); the identity (0, 0) maps to itself
-        Fq beta;
-#pragma unroll
-        for (int i = 0; i < NL; ++i) beta.l[i] = GlvConst::BETA_MONT[i];
-        p.x = FQ_MUL(p.x, beta);                          // 2*1/169 + 1 -> [2]
-    }
+// phi(P) = (beta * x, y): beta * x is computed ONCE per base (k_bases_endo_x, 32 B / point beside the table) instead of
+// once per bucket entry — with the multiplication inside the gather, every wave that holds one endo entry paid 223
+// instructions on all its lanes, 8 % of the accumulation.  The identity (0, 0) maps to itself.
+FP_INLINE G1Affine msm_gather(const uint8_t* __restrict__ bases, const uint8_t* __restrict__ endo_x, uint32_t e) {
+    const size_t idx = e & ENT_IDX;
+    G1Affine p;
+    p.x = fp_load<FqParams>((e & ENT_ENDO) ? endo_x + 32 * idx : bases + 64 * idx);
+    p.y = fp_load<FqParams>(bases + 64 * idx + 32);
     return (e & ENT_NEG) ? affine_neg(p) : p;
+}
+__global__ void __launch_bounds__(BLOCK) k_bases_endo_x(const uint8_t* __restrict__ bases, size_t n,
+                                                        uint8_t* __restrict__ endo_x) {
+    Fq beta;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) beta.l[i] = GlvConst::BETA_MONT[i];
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK)
+        fp_store<FqParams>(endo_x + 32 * i, FQ_MUL(fp_load<FqParams>(bases + 64 * i), beta));   // 2*1/169 + 1 -> [2]
 }
 
 // Buckets longer than `big` are cut into chunks of BIG_CHUNK entries, one workgroup per chunk (a narrow top
@@ -52,6 +60,7 @@ FP_INLINE G1Affine msm_gather(const uint8_t* __restrict__ bases, uint32_t e) {
 constexpr uint32_t BIG_CHUNK = 2048;
 
 __global__ void __launch_bounds__(BLOCK) k_msm_accumulate(const uint8_t* __restrict__ bases,
+                                                          const uint8_t* __restrict__ endo_x,
                                                           const uint32_t* __restrict__ entries,
                                                           const uint32_t* __restrict__ offs,
                                                           const uint32_t* __restrict__ hist,
@@ -90,11 +99,11 @@ __global__ void __launch_bounds__(BLOCK) k_msm_accumulate(const uint8_t* __restr
     const uint32_t* run = entries + offs[key];
     G1XYZZ acc = G1XYZZ::identity();
     if (hi > lo) {
-        G1Affine nxt = msm_gather(bases, run[lo]);
+        G1Affine nxt = msm_gather(bases, endo_x, run[lo]);
 #pragma unroll 1
         for (uint32_t k = lo; k < hi; ++k) {
             G1Affine cur = nxt;
-            if (k + 1 < hi) nxt = msm_gather(bases, run[k + 1]);  // next gather in flight under this add
+            if (k + 1 < hi) nxt = msm_gather(bases, endo_x, run[k + 1]);  // next gather in flight under this add
             xyzz_add_affine(acc, cur);
         }
     }
@@ -118,6 +127,7 @@ __global__ void __launch_bounds__(BLOCK) k_msm_bucket_combine(const uint8_t* __r
 
 // one workgroup per chunk of an over-long bucket
 __global__ void __launch_bounds__(BLOCK) k_msm_accumulate_big(const uint8_t* __restrict__ bases,
+                                                              const uint8_t* __restrict__ endo_x,
                                                               const uint32_t* __restrict__ entries,
                                                               const uint32_t* __restrict__ offs,
                                                               const uint32_t* __restrict__ hist,
@@ -134,7 +144,7 @@ __global__ void __launch_bounds__(BLOCK) k_msm_accumulate_big(const uint8_t* __r
         const uint32_t* run = entries + offs[key];
         G1XYZZ acc = G1XYZZ::identity();
 #pragma unroll 1
-        for (uint32_t k = lo + threadIdx.x; k < hi; k += BLOCK) xyzz_add_affine(acc, msm_gather(bases, run[k]));
+        for (uint32_t k = lo + threadIdx.x; k < hi; k += BLOCK) xyzz_add_affine(acc, msm_gather(bases, endo_x, run[k]));
         G1XYZZ tot = block_sum_xyzz(acc, lds);
         if (threadIdx.x == 0)
             xyzz_store(nch == 1 ? buckets + XYZZ_BYTES * (size_t)key * stride : big_part + XYZZ_BYTES * (size_t)b, tot);
