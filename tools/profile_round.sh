@@ -1,0 +1,27 @@
+#!/bin/bash
+# Round-end evidence: rocprofv3 kernel-trace summary of the default bench command + PMC passes (each in its own run,
+# never combined with other traces) for the dominant kernel.  Run on the GPU box from the repo root:
+#   tools/profile_round.sh r01_final      -> gpurun_out/<tag>_*.txt  (copy the ones to keep into profiles/)
+set -u
+tag=${1:-r01_final}
+root=$(pwd)
+out=$root/gpurun_out
+mkdir -p $out
+export TMPDIR=/tmp
+cmd="python $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --agg-proofs 0"
+cd /tmp
+rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o trace -- $cmd > $out/${tag}_bench_under_rocprof.json 2> /dev/null
+python $root/tools/rocpd_summary.py /tmp/prof_kt/trace_results.db > $out/${tag}_kernel_stats.txt 2>&1
+i=0
+for ctrs in "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY"; do
+  name=(sq fetch write mem)
+  rm -rf /tmp/prof_pmc && rocprofv3 --kernel-trace --pmc $ctrs -d /tmp/prof_pmc -o pmc -- $cmd > /dev/null 2>&1
+  python $root/tools/rocpd_summary.py /tmp/prof_pmc/pmc_results.db > $out/${tag}_pmc_${name[$i]}.txt 2>&1
+  i=$((i+1))
+done
+cd $root
+# full-size aggregation path trace
+cd /tmp && rm -rf /tmp/prof_agg && rocprofv3 --kernel-trace --stats -d /tmp/prof_agg -o agg -- python $root/tools/agg_phases.py --reps 10 > $out/${tag}_agg_phases.txt 2>/dev/null
+python $root/tools/rocpd_summary.py /tmp/prof_agg/agg_results.db > $out/${tag}_agg_kernel_stats.txt 2>&1
+cd $root
+ls -la $out | grep $tag
