@@ -18,7 +18,9 @@
 #pragma once
 #include <cstdint>
 #include <cstring>
+#include <deque>
 #include <string>
+#include <string_view>
 #include <unordered_map>
 #include <vector>
 
@@ -146,8 +148,10 @@ struct Tape {
     struct Chain {
         uint32_t root, c, e;  // register = root * c^e   (root == NONE: just c^e)
     };
-    std::unordered_map<uint32_t, Chain> chain_of;
-    std::unordered_map<uint64_t, uint32_t> pow_memo;  // (c << 32 | e) -> register
+    std::vector<Chain> chain_by_op;                   // parallel to ops; c == NONE: the result is not a chain
+    std::unordered_map<uint32_t, uint32_t> pow_slot;  // constant -> index into pow_tab
+    std::vector<std::vector<uint32_t>> pow_tab;       // pow_tab[slot][e] = register of c^e (NONE: not built yet)
+    uint32_t last_pow_c = NONE, last_pow_slot = 0;
     struct Lazy {
         uint32_t parent;  // LAZYBIT id of the sum this one extends, or NONE
         uint32_t head;    // first term when parent == NONE
@@ -171,7 +175,16 @@ struct Tape {
         b = materialize(b);
         TapeOp o{(uint32_t)ops.size() | OPBIT, a, b, opcode};
         ops.push_back(o);
+        chain_by_op.push_back(Chain{NONE, NONE, 0});
         return o.dst;
+    }
+    const Chain* chain_of(uint32_t r) const {
+        if (!(r & OPBIT)) return nullptr;
+        const Chain& ch = chain_by_op[r & ~OPBIT];
+        return ch.c == NONE ? nullptr : &ch;
+    }
+    void set_chain(uint32_t r, const Chain& ch) {
+        if ((r & OPBIT) && chain_by_op[r & ~OPBIT].c == NONE) chain_by_op[r & ~OPBIT] = ch;
     }
     // a * b where one side is (typically) a `scalar!` leaf: keeps multiplicative chains shallow
     uint32_t mul(uint32_t a, uint32_t b) {
@@ -182,34 +195,43 @@ struct Tape {
             if (is_const(a)) {
                 if (a == b) return chain(NONE, b, 2);
             } else {
-                auto it = chain_of.find(a);
-                if (it != chain_of.end() && it->second.c == b) {
-                    const Chain ch = it->second;
-                    return chain(ch.root, b, ch.e + 1);
+                const Chain* ch = chain_of(a);
+                if (ch && ch->c == b) {
+                    const Chain cc = *ch;
+                    return chain(cc.root, b, cc.e + 1);
                 }
             }
             const uint32_t r = record(TAPE_MUL, a, b);
-            chain_of.emplace(r, Chain{a, b, 1});
+            set_chain(r, Chain{a, b, 1});
             return r;
         }
         return record(TAPE_MUL, a, b);
     }
     uint32_t pow(uint32_t c, uint32_t e) {
         if (e == 1) return c;
-        const uint64_t key = ((uint64_t)c << 32) | e;
-        auto it = pow_memo.find(key);
-        if (it != pow_memo.end()) return it->second;
-        const uint32_t lo = pow(c, e / 2), hi = pow(c, e - e / 2);
+        if (c != last_pow_c) {
+            auto it = pow_slot.find(c);
+            if (it == pow_slot.end()) {
+                it = pow_slot.emplace(c, (uint32_t)pow_tab.size()).first;
+                pow_tab.emplace_back();
+            }
+            last_pow_c = c;
+            last_pow_slot = it->second;
+        }
+        const uint32_t slot = last_pow_slot;
+        if (pow_tab[slot].size() <= e) pow_tab[slot].resize((size_t)e + 16, NONE);
+        if (pow_tab[slot][e] != NONE) return pow_tab[slot][e];
+        const uint32_t lo = pow(c, e / 2), hi = pow(c, e - e / 2);   // (same c: the cached slot stays valid)
         const uint32_t r = record(TAPE_MUL, lo, hi);
-        pow_memo.emplace(key, r);
-        chain_of.emplace(r, Chain{NONE, c, e});
+        pow_tab[slot][e] = r;
+        set_chain(r, Chain{NONE, c, e});
         return r;
     }
     uint32_t chain(uint32_t root, uint32_t c, uint32_t e) {
         const uint32_t p = pow(c, e);
         if (root == NONE) return p;
         const uint32_t r = record(TAPE_MUL, root, p);
-        chain_of.emplace(r, Chain{root, c, e});
+        set_chain(r, Chain{root, c, e});
         return r;
     }
     // a + b, deferred
@@ -254,6 +276,7 @@ struct Tape {
             for (size_t i = 0; i + 1 < lvl.size(); i += 2) {
                 TapeOp op{(uint32_t)ops.size() | OPBIT, lvl[i], lvl[i + 1], TAPE_ADD};
                 ops.push_back(op);
+                chain_by_op.push_back(Chain{NONE, NONE, 0});
                 lvl[o++] = op.dst;
             }
             if (lvl.size() & 1) lvl[o++] = lvl.back();
@@ -278,16 +301,33 @@ struct PreparedEntry {
     uint32_t key;    // interned; 0 = ""
     int32_t point;   // -1 = None
     int64_t scalar;  // -1 = None, otherwise a tape register id (possibly OPBIT / LAZYBIT tagged)
+    uint64_t prev = 0;   // the key's stamp before this entry was pushed (see Prepared)
 };
+// The result lists of eval_prepare live back to back in ONE vector: a call appends its list at the end.  Merging the
+// right list of an Add into the left one (evaluation.rs:245-268: entries with an equal key add their scalars, the others
+// are appended) is then an in-place compaction, and "is key k in the left list, and where" is one stamp per interned key
+// (list id << 32 | position) instead of a hash map per list.  The right subtree is evaluated AFTER the left one and
+// overwrites the stamps of the keys it shares with it, so every entry remembers the stamp it displaced (`prev`): for
+// the surviving (leftmost) right entry of a key that is exactly the left list's stamp, if the key is there.  List ids are
+// never reused, so a stamp of a list that has since been merged away or popped cannot match a live list.
 struct Prepared {
     std::vector<PreparedEntry> v;
-    std::unordered_map<uint32_t, uint32_t> index;  // key -> position of its first entry
-    bool indexed = false;
-    void build_index() {
-        if (indexed) return;
-        index.reserve(v.size() * 2 + 8);
-        for (uint32_t i = 0; i < v.size(); ++i) index.emplace(v[i].key, i);  // emplace keeps the FIRST match
-        indexed = true;
+    std::vector<uint64_t> stamp;   // per key id
+    uint32_t next_list = 1;
+    void reset(size_t nkeys) {
+        v.clear();
+        stamp.assign(nkeys, 0);
+        next_list = 1;
+    }
+    uint32_t new_list() { return next_list++; }
+    void push(uint32_t list, PreparedEntry e) {
+        e.prev = stamp[e.key];
+        stamp[e.key] = ((uint64_t)list << 32) | (uint32_t)v.size();
+        v.push_back(e);
+    }
+    void pop() {   // drop the last entry (a temporary one-entry list) and give its key's stamp back
+        stamp[v.back().key] = v.back().prev;
+        v.pop_back();
     }
 };
 
@@ -298,19 +338,20 @@ struct Schema {
     uint32_t one_reg = 0;
     bool has_one = false;
     std::string err;
-    std::vector<std::string> key_names{std::string()};                 // interned keys, id 0 = ""
-    std::unordered_map<std::string, uint32_t> key_ids{{std::string(), 0u}};
+    std::deque<std::string> key_names{std::string()};                  // interned keys (stable addresses), id 0 = ""
+    std::unordered_map<std::string_view, uint32_t> key_ids{{std::string_view(), 0u}};   // views into key_names
 
     // results of the last eval (names: evaluation.rs:183), as interned key ids
     std::vector<uint32_t> names;
     size_t point_list_len = 0;     // what MockChipCtx::point_list.len() would be after multi_exp
 
     uint32_t intern(const char* key) {
-        auto it = key_ids.find(key);
+        const std::string_view sv(key);
+        auto it = key_ids.find(sv);
         if (it != key_ids.end()) return it->second;
         const uint32_t id = (uint32_t)key_names.size();
-        key_names.emplace_back(key);
-        key_ids.emplace(key_names.back(), id);
+        key_names.emplace_back(sv);
+        key_ids.emplace(std::string_view(key_names.back()), id);
         return id;
     }
     void grow_nodes(size_t extra) {
@@ -446,84 +487,106 @@ struct Schema {
         return 0;
     }
 
-    // eval_prepare (evaluation.rs:205-293); `scalar` = -1 for None.  Returns false on the reference's
-    // assertion failures (err is set).
-    bool eval_prepare(uint32_t id, int64_t scalar, Prepared& out) {
+    // eval_prepare (evaluation.rs:205-293); `scalar` = -1 for None.  Appends the result list to out.v and returns its id
+    // in `list` (its entries are out.v[start .. out.v.size()), `start` = out.v.size() at the call).  Returns false on the
+    // reference's assertion failures (err is set).
+    bool eval_prepare(uint32_t id, int64_t scalar, Prepared& out, uint32_t& list) {
         const SchemaNode n = nodes[id];
         switch (n.kind) {
         case SchemaNode::COMMITMENT:                                         // :216-218
-            out.v.push_back({n.key, n.point, scalar});
+            list = out.new_list();
+            out.push(list, {n.key, n.point, scalar});
             return true;
         case SchemaNode::EVAL: {                                             // :219-225
             int64_t e = scalar >= 0 ? (int64_t)tape.record(TAPE_MUL, (uint32_t)scalar, n.reg) : (int64_t)n.reg;
-            out.v.push_back({0u, -1, e});
+            list = out.new_list();
+            out.push(list, {0u, -1, e});
             return true;
         }
         case SchemaNode::SCALAR: {                                           // :226-232
             int64_t s = scalar >= 0 ? (int64_t)tape.mul(n.reg, (uint32_t)scalar) : (int64_t)n.reg;
-            out.v.push_back({0u, -1, s});
+            list = out.new_list();
+            out.push(list, {0u, -1, s});
             return true;
         }
         case SchemaNode::ADD: {
             const uint32_t l = n.l, r = n.r;
+            const size_t start = out.v.size();
             if (!nodes[l].has_commitment && !nodes[r].has_commitment) {      // :234-244
-                Prepared pl, pr;
-                if (!eval_prepare(l, -1, pl) || !eval_prepare(r, -1, pr)) return false;
-                if (pl.v.size() != 1 || pr.v.size() != 1) {
+                uint32_t ll, lr;
+                if (!eval_prepare(l, -1, out, ll)) return false;
+                const size_t mid = out.v.size();
+                if (!eval_prepare(r, -1, out, lr)) return false;
+                if (mid - start != 1 || out.v.size() - mid != 1) {
                     err = "assert!(l.len() == 1 && r.len() == 1) failed (evaluation.rs:237-238)";
                     return false;
                 }
-                int64_t sum = tape.add((uint32_t)pl.v[0].scalar, (uint32_t)pr.v[0].scalar);
+                int64_t sum = tape.add((uint32_t)out.v[start].scalar, (uint32_t)out.v[mid].scalar);
                 if (scalar >= 0) sum = tape.record(TAPE_MUL, (uint32_t)scalar, (uint32_t)sum);
-                out.v.push_back({0u, -1, sum});
+                out.pop();
+                out.pop();
+                list = out.new_list();
+                out.push(list, {0u, -1, sum});
                 return true;
             }
             // :245-268  merge entries with equal key by adding their scalars (None == one).
-            // Every list eval_prepare returns has unique keys (a single entry, or the `res` of an Add), so
-            // pushing the LEFT entries through the reference's find-or-push loop never merges anything:
-            // the left list is taken over as `res` (with its hash index carried along), and only the right
-            // entries are looked up.  Same result and order as the reference, without its O(n^2) scan.
-            Prepared res;
-            if (!eval_prepare(l, scalar, res)) return false;
-            Prepared rhs;
-            if (!eval_prepare(r, scalar, rhs)) return false;
-            res.build_index();
-            for (PreparedEntry& ev : rhs.v) {
-                auto it = res.index.find(ev.key);
-                if (it != res.index.end()) {
-                    PreparedEntry& p = res.v[it->second];
+            // Every list eval_prepare returns has unique keys (a single entry, or the `res` of an Add), so pushing the
+            // LEFT entries through the reference's find-or-push loop never merges anything: the left list is taken
+            // over as `res`, and only the right entries are looked up.  Same result and order as the reference,
+            // without its O(n^2) scan.
+            uint32_t res, rhs;
+            if (!eval_prepare(l, scalar, out, res)) return false;
+            const size_t mid = out.v.size();
+            if (!eval_prepare(r, scalar, out, rhs)) return false;
+            const size_t end = out.v.size();
+            size_t w = mid;                                                  // right entries kept are compacted to here
+            for (size_t k = mid; k < end; ++k) {
+                const PreparedEntry ev = out.v[k];
+                if ((uint32_t)(ev.prev >> 32) == res) {                       // the key is in the left list
+                    const size_t pos = (uint32_t)ev.prev;
+                    PreparedEntry& p = out.v[pos];
                     const uint32_t a = p.scalar >= 0 ? (uint32_t)p.scalar : one();
                     const uint32_t b = ev.scalar >= 0 ? (uint32_t)ev.scalar : one();
                     p.scalar = tape.add(a, b);
+                    out.stamp[ev.key] = ev.prev;
                 } else {
-                    res.index.emplace(ev.key, (uint32_t)res.v.size());
-                    res.v.push_back(ev);
+                    out.v[w] = ev;
+                    out.stamp[ev.key] = ((uint64_t)res << 32) | (uint32_t)w;
+                    ++w;
                 }
             }
-            out = std::move(res);
+            out.v.resize(w);
+            list = res;
             return true;
         }
         case SchemaNode::MUL: {                                              // :271-291
             const uint32_t l = n.l, r = n.r;
-            Prepared s;
+            const size_t start = out.v.size();
+            uint32_t ls;
             uint32_t rem;
             if (!nodes[l].has_commitment) {
-                if (!eval_prepare(l, -1, s)) return false;
+                if (!eval_prepare(l, -1, out, ls)) return false;
                 rem = r;
             } else {
-                if (!eval_prepare(r, -1, s)) return false;
+                if (!eval_prepare(r, -1, out, ls)) return false;
                 rem = l;
             }
-            if (s.v.size() != 1) {
+            if (out.v.size() - start != 1) {
                 err = "assert_eq!(s.len(), 1) failed (evaluation.rs:282)";
                 return false;
             }
-            int64_t sv = s.v[0].scalar;
+            int64_t sv = out.v[start].scalar;
+            out.pop();
             if (scalar >= 0) sv = tape.mul((uint32_t)scalar, (uint32_t)sv);
-            return eval_prepare(rem, sv, out);
+            return eval_prepare(rem, sv, out, list);
         }
         }
         return false;
+    }
+    bool eval_prepare(uint32_t id, int64_t scalar, Prepared& out) {
+        out.reset(key_names.size());
+        uint32_t list;
+        return eval_prepare(id, scalar, out, list);
     }
 };
 
