@@ -420,8 +420,9 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     // per bucket turn a 60-entry run into 8 entries + 7 adds of the combine.
     uint32_t lpb = 1;
     if (c->cfg_lpb) lpb = (uint32_t)c->cfg_lpb;
-    else
-        while (lpb < 8 && (size_t)p.NBT * lpb < (size_t)8192 * 64) lpb *= 2;
+    else   // ... but only while the mean run still covers the slices (measured, profiles/r01_sweeps.txt): sparse buckets
+           // (small MSMs with wide windows) gain nothing from slices and pay lpb - 1 additions per bucket in the combine
+        while (lpb < 8 && (size_t)p.NBT * lpb < (size_t)8192 * 64 && nent >= (size_t)lpb * p.NBT) lpb *= 2;
     uint8_t* acc_out = buckets;
     if (lpb > 1) {
         TRY(ensure(c, c->parts, (size_t)p.NBT * lpb * XYZZ_BYTES));
