@@ -405,4 +405,29 @@ __global__ void __launch_bounds__(BLOCK) k_eval_tail(const uint8_t* __restrict__
     if (threadIdx.x == 0) jac_store_canonical(out_jac, jac_from_xyzz(tot));
 }
 
+// both sides of evaluate_multiopen_proof in one launch (one workgroup each), straight to `to_value`:
+// out_aff[64 * side] = to_affine(msm_result + sum of the scalar-less points)   (evaluation.rs:198-200, verify.rs:730-731)
+__global__ void __launch_bounds__(BLOCK) k_eval_tail_affine2(const uint8_t* __restrict__ xyzz0,
+                                                             const uint8_t* __restrict__ xyzz1,
+                                                             const uint8_t* __restrict__ pts0,
+                                                             const uint8_t* __restrict__ pts1, size_t n0, size_t n1,
+                                                             uint8_t* __restrict__ out_aff, uint32_t* flags) {
+    __shared__ uint32_t lds[XYZZ_WORDS * BLOCK];
+    const bool side = blockIdx.x != 0;
+    const uint8_t* msm_xyzz = side ? xyzz1 : xyzz0;
+    const uint8_t* pts_aff = side ? pts1 : pts0;
+    const size_t n = side ? n1 : n0;
+    G1XYZZ acc = G1XYZZ::identity();
+    if (threadIdx.x == 0 && msm_xyzz) acc = xyzz_load(msm_xyzz);
+    uint32_t bad = 0;
+    for (size_t i = threadIdx.x; i < n; i += BLOCK) xyzz_add_affine(acc, affine_load_canonical(pts_aff + 64 * i, bad));
+    if (bad) atomicOr(flags, FLAG_NONCANONICAL);
+    G1XYZZ tot = block_sum_xyzz(acc, lds);
+    if (threadIdx.x == 0) {
+        const G1Affine a = affine_from_xyzz(tot);
+        fp_store<FqParams>(out_aff + 64 * blockIdx.x, fp_from_mont<FqParams>(a.x));
+        fp_store<FqParams>(out_aff + 64 * blockIdx.x + 32, fp_from_mont<FqParams>(a.y));
+    }
+}
+
 }  // namespace h2agg
