@@ -200,22 +200,28 @@ size_t h2agg_schema_names_joined(h2agg_schema* s, char* out, size_t cap);
 size_t h2agg_schema_point_list_len(h2agg_schema* s);
 
 /* ---- tuning / measurement -------------------------------------------------------------------------
- * window_bits: Pippenger window c in [2, 16], 0 = choose from n.  Other knobs: 0 = default. */
+ * window_bits: Pippenger window c in [2, 16]; 0 = the measured table (GLV: 8 / 13 / 16 for n <= 2^10 / <= 2^14 / larger;
+ * plain: 8 / 15 / 16 for n <= 2^12 / < 2^19 / larger — wide windows with a uniform top window).
+ * reduce_segment: buckets per running-sum segment of the bucket reduction (power of two; 0 = 2 / 4 / 8 by bucket count,
+ * 32 for n >= 2^20 in overlap mode).  big_bucket_threshold: run length above which a bucket is cut into
+ * workgroup-sized chunks (0 = max(256, 8 x mean)). */
 int h2agg_msm_configure(h2agg_ctx* ctx, int window_bits, int reduce_segment, int big_bucket_threshold);
 /* GLV / endomorphism split of the scalars (k = k1 + lambda*k2, |k_i| < 2^127; phi(P) = (beta*x, y)): halves the
  * number of windows — same bucket additions, half the bucket reduction and half the serial doubling chain.
- * It costs ~5 % more work in the accumulation (the beta multiplications), so mode 0 = auto turns it on
- * unless the tail is hidden anyway (overlap mode and n >= 2^19); 1 = on, -1 = off (254-bit windows). */
+ * beta*x is computed once per base (a 32 B/point column beside the table), so the price is the decomposition pass and
+ * the slice-combine pass of the half-as-many buckets: mode 0 = auto turns it on unless the tail is hidden anyway
+ * (overlap mode and n >= 2^20); 1 = on, -1 = off (254-bit windows). */
 int h2agg_msm_configure_glv(h2agg_ctx* ctx, int mode);
-/* Lanes per bucket in the accumulation kernel (1, 2, 4, 8, 16; 0 = chosen so that ~8192 waves are launched, at most 8). */
+/* Lanes per bucket in the accumulation kernel (1, 2, 4, 8, 16; 0 = chosen so that ~8192 waves are launched, at most 8
+ * and at most the mean bucket occupancy). */
 int h2agg_msm_configure_lanes_per_bucket(h2agg_ctx* ctx, int lanes);
 /* Bucket-sort knobs: low bucket bits resolved per partition in LDS (4..12) and scalars per level-1
  * workgroup; 0 = default.  tile = -1 forces the two-array direct sort kernels (otherwise used only when
  * n does not fit the packed item's index field, n > 2^(31 - sub_bits)); tile = -2 additionally stages level 1
  * through LDS (measured slower; kept as a tested variant). */
 int h2agg_msm_configure_sort(h2agg_ctx* ctx, int sub_bits, int tile);
-/* Overlap the serial Horner tail of one MSM (k_msm_final, one wave) with the bulk kernels of the next:
- * the tail runs on a second stream of the context.  With overlap on, a result written by
+/* Overlap the latency-shaped tail of one MSM (enable = 1: the Horner kernel, one wave; 2: bucket reduction + window
+ * sums + Horner) with the bulk kernels of the next ones: the tail runs on one of three tail streams of the context.  With overlap on, a result written by
  * h2agg_g1_msm_device_async is complete after h2agg_synchronize() (or after the next synchronous call on
  * the context), not merely after the caller's stream has drained.  Default: off. */
 int h2agg_msm_set_tail_overlap(h2agg_ctx* ctx, int enable);
