@@ -66,7 +66,9 @@ def load_library():
         "h2agg_g1_batch_scalar_mul": (i32, [ctxp, u8p, u8p, sz, vp]),
         "h2agg_g1_batch_to_affine": (i32, [ctxp, u8p, sz, vp]),
         "h2agg_g1_sum": (i32, [ctxp, u8p, sz, vp]),
-        "h2agg_g1_msm": (i32, [ctxp, u8p, u8p, sz, vp]),
+        "h2agg_g1_msm": (i32, [ctxp, vp, vp, sz, vp]),
+        "h2agg_host_alloc": (i32, [ctxp, sz, C.POINTER(vp)]),
+        "h2agg_host_free": (i32, [ctxp, vp]),
         "h2agg_eval_flat": (i32, [ctxp, u8p, u8p, u8p, sz, vp]),
         "h2agg_bases_upload": (i32, [ctxp, u8p, sz, C.POINTER(u64)]),
         "h2agg_bases_generate": (i32, [ctxp, vp, sz, C.POINTER(u64)]),
@@ -224,10 +226,23 @@ class H2Agg:
         return out.raw
 
     # ------------------------------------------------------------------ MSM
-    def g1_msm(self, bases_aff: bytes, scalars: bytes) -> bytes:
+    def g1_msm(self, bases_aff, scalars, n: Optional[int] = None) -> bytes:
+        """bases_aff / scalars: bytes, or addresses of host buffers (e.g. from host_alloc) together with n"""
         out = C.create_string_buffer(96)
-        self._check(self._lib.h2agg_g1_msm(self._ctx, bases_aff, scalars, len(scalars) // 32, out))
+        if n is None:
+            n = len(scalars) // 32
+        pb = C.cast(bases_aff, C.c_void_p) if isinstance(bases_aff, (bytes, bytearray)) else C.c_void_p(bases_aff)
+        ps = C.cast(scalars, C.c_void_p) if isinstance(scalars, (bytes, bytearray)) else C.c_void_p(scalars)
+        self._check(self._lib.h2agg_g1_msm(self._ctx, pb, ps, n, out))
         return out.raw
+
+    def host_alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._check(self._lib.h2agg_host_alloc(self._ctx, nbytes, C.byref(p)))
+        return p.value
+
+    def host_free(self, ptr: int):
+        self._check(self._lib.h2agg_host_free(self._ctx, C.c_void_p(ptr)))
 
     def eval_flat(self, pts_aff: bytes, scalars: bytes, has_scalar: bytes) -> bytes:
         out = C.create_string_buffer(96)

@@ -41,6 +41,8 @@ struct Table {
 
 }  // namespace
 
+constexpr int MSM_MAX_SLICES = 8;
+
 struct h2agg_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
@@ -64,6 +66,10 @@ struct h2agg_ctx {
     uint8_t* h_stage = nullptr;
     size_t h_stage_cap = 0;
     const void* sch_owner = nullptr;  // the schema whose tape sch_regs reflects
+
+    // host-buffer MSM: slices are copied on this stream while the previous slice is computed
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t ev_copy[8] = {}, ev_ready = nullptr;
 
     std::map<uint64_t, Table> tables;
     uint64_t next_handle = 1;
@@ -582,6 +588,13 @@ void h2agg_destroy(h2agg_ctx* c) {
     }
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->h_stage) hipHostFree(c->h_stage);
+    if (c->copy_stream) {
+        hipStreamSynchronize(c->copy_stream);
+        for (int k = 0; k < MSM_MAX_SLICES; ++k)
+            if (c->ev_copy[k]) hipEventDestroy(c->ev_copy[k]);
+        if (c->ev_ready) hipEventDestroy(c->ev_ready);
+        hipStreamDestroy(c->copy_stream);
+    }
     for (int r = 0; r < h2agg_ctx::PROF_RING; ++r)
         for (int s = 0; s < ST_N; ++s)
             for (int k = 0; k < 2; ++k)
@@ -904,6 +917,19 @@ int h2agg_instance_commitment(h2agg_ctx* c, uint64_t g_lagrange_handle, const ui
     return h2agg_g1_msm_preloaded(c, g_lagrange_handle, instance, len, out_jac);
 }
 
+int h2agg_host_alloc(h2agg_ctx* c, size_t bytes, void** out) {
+    TRY(bind(c));
+    if (!out || bytes == 0) return fail(c, H2AGG_ERR_INVALID, "null out or zero size");
+    hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (e != hipSuccess) return fail(c, H2AGG_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
+    return H2AGG_OK;
+}
+int h2agg_host_free(h2agg_ctx* c, void* p) {
+    TRY(bind(c));
+    if (p) HIP_TRY(c, hipHostFree(p));
+    return H2AGG_OK;
+}
+
 int h2agg_g1_msm(h2agg_ctx* c, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[96]) {
     TRY(bind(c));
     if (!out) return fail(c, H2AGG_ERR_INVALID, "null buffer");
@@ -913,12 +939,60 @@ int h2agg_g1_msm(h2agg_ctx* c, const uint8_t* bases, const uint8_t* scalars, siz
     TRY(ensure(c, c->in_a, 64 * n));
     TRY(ensure(c, c->in_b, 32 * n));
     TRY(ensure(c, c->tmp_bases, 64 * n));
-    HIP_TRY(c, hipMemcpyAsync(c->in_a.p, bases, 64 * n, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->in_b.p, scalars, 32 * n, hipMemcpyHostToDevice, c->stream));
     TRY(clear_flags(c));
-    hipLaunchKernelGGL(k_bases_to_mont, dim3(grid_for(c, n)), dim3(BLOCK), 0, c->stream, (const uint8_t*)c->in_a.p, n,
-                       (uint8_t*)c->tmp_bases.p, c->d_flags);
-    TRY(msm_run(c, (const uint8_t*)c->tmp_bases.p, (const uint8_t*)c->in_b.p, n, c->d_res_jac));
+    // Large inputs are cut into slices that cross PCIe on a copy stream while the previous slice is being computed
+    // (an MSM is a sum over points, so the slices' results just add up): 96 B/point of transfer hide under ~1.7 ns/point
+    // of arithmetic, instead of preceding it.  Slices of >= 2^19 points keep the per-MSM efficiency (2^18-point slices lose more than the overlap gains).
+    const size_t MIN_SLICE = (size_t)1 << 19;
+    size_t nslices = n / MIN_SLICE;
+    if (nslices > MSM_MAX_SLICES) nslices = MSM_MAX_SLICES;
+    if (nslices < 2) {
+        HIP_TRY(c, hipMemcpyAsync(c->in_a.p, bases, 64 * n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->in_b.p, scalars, 32 * n, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_bases_to_mont, dim3(grid_for(c, n)), dim3(BLOCK), 0, c->stream, (const uint8_t*)c->in_a.p, n,
+                           (uint8_t*)c->tmp_bases.p, c->d_flags);
+        TRY(msm_run(c, (const uint8_t*)c->tmp_bases.p, (const uint8_t*)c->in_b.p, n, c->d_res_jac));
+        return fetch_result_jac(c, out);
+    }
+    if (!c->copy_stream) {
+        HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+        for (int k = 0; k < MSM_MAX_SLICES; ++k) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_copy[k], hipEventDisableTiming));
+        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+    }
+    TRY(ensure(c, c->out, 96 * MSM_MAX_SLICES));
+    // the copy stream must not overwrite in_a / in_b while earlier work on the main stream still reads them
+    HIP_TRY(c, hipEventRecord(c->ev_ready, c->stream));
+    HIP_TRY(c, hipStreamWaitEvent(c->copy_stream, c->ev_ready, 0));
+    const size_t per = (n + nslices - 1) / nslices;
+    const bool was_overlap = c->tail_overlap;
+    const int was_level = c->overlap_level;
+    c->tail_overlap = true;   // slice k's reduction / Horner tail under slice k+1's sort + accumulation
+    c->overlap_level = 2;
+    int rc = H2AGG_OK;
+    size_t done = 0, k = 0;
+    for (; done < n && rc == H2AGG_OK; done += per, ++k) {
+        const size_t m = n - done < per ? n - done : per;
+        hipError_t e = hipMemcpyAsync((uint8_t*)c->in_b.p + 32 * done, scalars + 32 * done, 32 * m, hipMemcpyHostToDevice,
+                                      c->copy_stream);
+        if (e == hipSuccess)
+            e = hipMemcpyAsync((uint8_t*)c->in_a.p + 64 * done, bases + 64 * done, 64 * m, hipMemcpyHostToDevice,
+                               c->copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(c->ev_copy[k], c->copy_stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_copy[k], 0);
+        if (e != hipSuccess) {
+            rc = fail(c, H2AGG_ERR_HIP, hipGetErrorString(e));
+            break;
+        }
+        hipLaunchKernelGGL(k_bases_to_mont, dim3(grid_for(c, m)), dim3(BLOCK), 0, c->stream,
+                           (const uint8_t*)c->in_a.p + 64 * done, m, (uint8_t*)c->tmp_bases.p + 64 * done, c->d_flags);
+        rc = msm_run(c, (const uint8_t*)c->tmp_bases.p + 64 * done, (const uint8_t*)c->in_b.p + 32 * done, m,
+                     (uint8_t*)c->out.p + 96 * k);
+    }
+    c->tail_overlap = was_overlap;
+    c->overlap_level = was_level;
+    TRY(rc);
+    TRY(join_tails(c));
+    hipLaunchKernelGGL(k_g1_sum, dim3(1), dim3(BLOCK), 0, c->stream, (const uint8_t*)c->out.p, k, c->d_res_jac, c->d_flags);
     return fetch_result_jac(c, out);
 }
 

@@ -99,6 +99,11 @@ int h2agg_g1_batch_to_affine_device(h2agg_ctx* ctx, const uint8_t* d_in_jac, siz
  * SURVEY.md §8e; arithmetic = MockEccChip::add, mock/arith/ecc.rs:30-37).  n == 0 -> identity. */
 int h2agg_g1_sum(h2agg_ctx* ctx, const uint8_t* in_jac, size_t n, uint8_t out_jac[96]);
 
+/* Page-locked host memory for the buffers handed to the host-buffer entry points (h2agg_g1_msm, h2agg_eval_flat, ...):
+ * from pageable memory the 96 B/point cross PCIe through the runtime's bounce buffers (~15 GB/s); from these buffers the
+ * copies run at link rate and asynchronously.  A binding marshals its points / scalars straight into them. */
+int h2agg_host_alloc(h2agg_ctx* ctx, size_t bytes, void** out);
+int h2agg_host_free(h2agg_ctx* ctx, void* p);
 /* ---- multi-scalar multiplication ------------------------------------------------------------------
  * replaces: MockEccChip::multi_exp / ArithEccChip::multi_exp default — sum_i scalars[i] * bases[i]
  * (halo2-snark-aggregator-api/src/mock/arith/ecc.rs:106-129, .../arith/ecc.rs:42-60), called from

@@ -228,3 +228,33 @@ def test_msm_2p22_identity(eng):
     finally:
         eng.msm_configure_glv(0)
         eng.bases_free(table)
+
+
+def test_host_buffer_msm_sliced_pipeline(eng):
+    """h2agg_g1_msm cuts inputs of >= 2^20 points into slices copied on a side stream under the previous slice's
+    compute; ragged size, pageable and page-locked sources, against the resident-table path."""
+    import ctypes
+    n = (1 << 20) + 4099
+    dev = torch.device("cuda", 0)
+    ks, k_np = _workload(n, 31)
+    ss, s_np = _workload(n, 32)
+    d_k = torch.from_numpy(k_np.copy()).to(dev)
+    d_s = torch.from_numpy(s_np.copy()).to(dev)
+    table = eng.bases_generate(d_k.data_ptr(), n)
+    try:
+        want = eng.g1_batch_to_affine(eng.g1_msm_device(table, d_s.data_ptr(), n))
+        t = sum(k * s for k, s in zip(ks, ss)) % O.R
+        assert want == eng.g1_batch_to_affine(eng.g1_batch_scalar_mul(O.aff_to_bytes(O.G1), O.fe_to_bytes(t)))
+        bases, scalars = eng.bases_download(table, 0, n), bytes(s_np.tobytes())
+        assert eng.g1_batch_to_affine(eng.g1_msm(bases, scalars)) == want
+        pb, ps = eng.host_alloc(64 * n), eng.host_alloc(32 * n)
+        try:
+            ctypes.memmove(pb, bases, 64 * n)
+            ctypes.memmove(ps, scalars, 32 * n)
+            for _ in range(2):
+                assert eng.g1_batch_to_affine(eng.g1_msm(pb, ps, n)) == want
+        finally:
+            eng.host_free(pb)
+            eng.host_free(ps)
+    finally:
+        eng.bases_free(table)
