@@ -26,6 +26,12 @@ extern "C" {
     fn h2agg_last_error(ctx: *const h2agg_ctx) -> *const c_char;
     fn h2agg_g1_msm(ctx: *mut h2agg_ctx, bases_aff: *const u8, scalars: *const u8, n: usize, out_jac: *mut u8) -> c_int;
     fn h2agg_g1_batch_scalar_mul(ctx: *mut h2agg_ctx, bases_aff: *const u8, scalars: *const u8, n: usize, out_jac: *mut u8) -> c_int;
+    // page-locked marshalling buffers: for large multi_exps, serialise points / scalars straight into memory from
+    // h2agg_host_alloc instead of a Vec<u8> (the 96 B/point then cross PCIe at link rate, sliced under the compute)
+    #[allow(dead_code)]
+    fn h2agg_host_alloc(ctx: *mut h2agg_ctx, bytes: usize, out: *mut *mut u8) -> c_int;
+    #[allow(dead_code)]
+    fn h2agg_host_free(ctx: *mut h2agg_ctx, p: *mut u8) -> c_int;
 }
 
 pub struct GpuEccChip<C: CurveAffine, E> {
