@@ -18,7 +18,7 @@ LIB_PATH = os.path.join(_HERE, "libh2agg.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "h2agg.h")
 
 OK, ERR_INVALID, ERR_DIV_ZERO, ERR_EMPTY, ERR_HIP, ERR_NONCANONICAL, ERR_NOMEM = range(7)
-OP_ADD, OP_SUB, OP_MUL, OP_SQR, OP_INV = range(5)
+OP_ADD, OP_SUB, OP_MUL, OP_SQR, OP_INV, OP_DIV = range(6)
 
 IDENTITY_JAC = (0).to_bytes(32, "little") + (1).to_bytes(32, "little") + (0).to_bytes(32, "little")
 
@@ -60,6 +60,7 @@ def load_library():
         "h2agg_synchronize": (i32, [ctxp]),
         "h2agg_describe": (C.c_char_p, [ctxp]),
         "h2agg_fr_batch_op": (i32, [ctxp, i32, u8p, u8p, sz, vp]),
+        "h2agg_fr_batch_pow_constant": (i32, [ctxp, u8p, sz, u64, vp]),
         "h2agg_fr_mul_add_accumulate": (i32, [ctxp, u8p, sz, u8p, vp]),
         "h2agg_fr_sum_with_coeff_and_constant": (i32, [ctxp, u8p, u8p, sz, u8p, vp]),
         "h2agg_g1_batch_add": (i32, [ctxp, u8p, u8p, sz, i32, vp]),
@@ -184,6 +185,12 @@ class H2Agg:
         n = len(a) // 32
         out = C.create_string_buffer(32 * n) if n else C.create_string_buffer(1)
         self._check(self._lib.h2agg_fr_batch_op(self._ctx, op, a, b, n, out))
+        return out.raw[:32 * n]
+
+    def fr_batch_pow_constant(self, a: bytes, exponent: int) -> bytes:
+        n = len(a) // 32
+        out = C.create_string_buffer(max(32 * n, 1))
+        self._check(self._lib.h2agg_fr_batch_pow_constant(self._ctx, a, n, exponent, out))
         return out.raw[:32 * n]
 
     def fr_mul_add_accumulate(self, v: bytes, b: bytes) -> bytes:

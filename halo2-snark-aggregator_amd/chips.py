@@ -18,7 +18,7 @@ from __future__ import annotations
 
 from typing import List, Sequence, Tuple
 
-OP_ADD, OP_SUB, OP_MUL, OP_SQR, OP_INV = range(5)
+OP_ADD, OP_SUB, OP_MUL, OP_SQR, OP_INV, OP_DIV = range(6)
 _ZERO32 = bytes(32)
 _ONE32 = (1).to_bytes(32, "little")
 IDENTITY_JAC = bytes(32) + _ONE32 + bytes(32)
@@ -71,7 +71,7 @@ class GpuFieldChip:
         return self.eng.fr_batch_op(OP_MUL, a, b)
 
     def div(self, ctx, a: bytes, b: bytes) -> bytes:                   # :107-114  a * b.invert().unwrap()
-        return self.eng.fr_batch_op(OP_MUL, a, self.eng.fr_batch_op(OP_INV, b))
+        return self.eng.fr_batch_op(OP_DIV, a, b)
 
     def square(self, ctx, a: bytes) -> bytes:                          # :116-122
         return self.eng.fr_batch_op(OP_SQR, a)
@@ -99,17 +99,7 @@ class GpuFieldChip:
 
     def pow_constant(self, ctx, base: bytes, exponent: int) -> bytes:                 # arith/field.rs:83-104
         assert exponent >= 1
-        acc = base
-        second_bit = 1
-        while second_bit <= exponent:
-            second_bit <<= 1
-        second_bit >>= 2
-        while second_bit > 0:
-            acc = self.square(ctx, acc)
-            if exponent & second_bit:
-                acc = self.mul(ctx, acc, base)
-            second_bit >>= 1
-        return acc
+        return self.eng.fr_batch_pow_constant(base, exponent)
 
 
 class GpuEccChip:

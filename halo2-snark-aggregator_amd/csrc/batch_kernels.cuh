@@ -81,7 +81,7 @@ __global__ void __launch_bounds__(BLOCK) k_fr_batch_op(int op, const uint8_t* __
         Fr x = fp_load<FrParams>(a + 32 * i);
         uint32_t bad = !fp_is_canonical<FrParams>(x);
         Fr y = Fr::zero();
-        if (op <= 2) {
+        if (op <= 2 || op == 5) {
             y = fp_load<FrParams>(b + 32 * i);
             bad |= !fp_is_canonical<FrParams>(y);
         }
@@ -92,6 +92,10 @@ __global__ void __launch_bounds__(BLOCK) k_fr_batch_op(int op, const uint8_t* __
         case 1: z = fp_cond_sub<FrParams>(fp_sub<1, FrParams>(x, y)); break;
         case 2: z = fp_cond_sub<FrParams>(fp_mul<FrParams>(fp_to_mont<FrParams>(x), y)); break;  // (xR)*y/R = xy
         case 3: z = fp_cond_sub<FrParams>(fp_mul<FrParams>(fp_to_mont<FrParams>(x), x)); break;
+        case 5:   // div: a * b.invert().unwrap()   (mock/arith/field.rs:107-114)
+            if (y.is_zero_int()) atomicOr(flags, FLAG_DIV_ZERO);
+            z = fp_cond_sub<FrParams>(fp_mul<FrParams>(fp_inv<FrParams>(fp_to_mont<FrParams>(y)), x));  // (R/y) * x / R
+            break;
         default:
             if (x.is_zero_int()) atomicOr(flags, FLAG_DIV_ZERO);
             z = fp_from_mont<FrParams>(fp_inv<FrParams>(fp_to_mont<FrParams>(x)));
@@ -110,6 +114,16 @@ __device__ __noinline__ Fr fr_pow_u64(Fr x, uint64_t e) {
         if ((e >> bit) & 1) acc = fp_mul<FrParams>(acc, x);
     }
     return acc;
+}
+
+// ArithFieldChip::pow_constant (arith/field.rs:83-104): out_i = a_i^e for one exponent e >= 1
+__global__ void __launch_bounds__(BLOCK) k_fr_batch_pow(const uint8_t* __restrict__ a, size_t n, uint64_t e,
+                                                        uint8_t* __restrict__ out, uint32_t* flags) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        Fr x = fp_load<FrParams>(a + 32 * i);
+        if (!fp_is_canonical<FrParams>(x)) atomicOr(flags, FLAG_NONCANONICAL);
+        fp_store<FrParams>(out + 32 * i, fp_from_mont<FrParams>(fr_pow_u64(fp_to_mont<FrParams>(x), e)));
+    }
 }
 
 // ArithFieldChip::mul_add_accumulate default: acc = acc*b + v_i  (arith/field.rs:68-81)

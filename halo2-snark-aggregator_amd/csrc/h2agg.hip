@@ -629,9 +629,9 @@ int h2agg_synchronize(h2agg_ctx* c) {
 // ---------------------------------------------------------------- Fr
 int h2agg_fr_batch_op(h2agg_ctx* c, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {
     TRY(bind(c));
-    if (op < H2AGG_OP_ADD || op > H2AGG_OP_INV) return fail(c, H2AGG_ERR_INVALID, "unknown field op");
+    if (op < H2AGG_OP_ADD || op > H2AGG_OP_DIV) return fail(c, H2AGG_ERR_INVALID, "unknown field op");
     if (n == 0) return H2AGG_OK;
-    const bool binary = op <= H2AGG_OP_MUL;
+    const bool binary = op <= H2AGG_OP_MUL || op == H2AGG_OP_DIV;
     if (!a || !out || (binary && !b)) return fail(c, H2AGG_ERR_INVALID, "null buffer");
     TRY(ensure(c, c->in_a, 32 * n));
     TRY(ensure(c, c->out, 32 * n));
@@ -643,6 +643,21 @@ int h2agg_fr_batch_op(h2agg_ctx* c, int op, const uint8_t* a, const uint8_t* b, 
     TRY(clear_flags(c));
     hipLaunchKernelGGL(k_fr_batch_op, dim3(grid_for(c, n)), dim3(BLOCK), 0, c->stream, op, (const uint8_t*)c->in_a.p,
                        (const uint8_t*)c->in_b.p, n, (uint8_t*)c->out.p, c->d_flags);
+    HIP_TRY(c, hipMemcpyAsync(out, c->out.p, 32 * n, hipMemcpyDeviceToHost, c->stream));
+    return finish(c);
+}
+
+int h2agg_fr_batch_pow_constant(h2agg_ctx* c, const uint8_t* a, size_t n, uint64_t exponent, uint8_t* out) {
+    TRY(bind(c));
+    if (exponent < 1) return fail(c, H2AGG_ERR_INVALID, "assert!(exponent >= 1) failed (arith/field.rs:89)");
+    if (n == 0) return H2AGG_OK;
+    if (!a || !out) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    TRY(ensure(c, c->in_a, 32 * n));
+    TRY(ensure(c, c->out, 32 * n));
+    HIP_TRY(c, hipMemcpyAsync(c->in_a.p, a, 32 * n, hipMemcpyHostToDevice, c->stream));
+    TRY(clear_flags(c));
+    hipLaunchKernelGGL(k_fr_batch_pow, dim3(grid_for(c, n)), dim3(BLOCK), 0, c->stream, (const uint8_t*)c->in_a.p, n,
+                       exponent, (uint8_t*)c->out.p, c->d_flags);
     HIP_TRY(c, hipMemcpyAsync(out, c->out.p, 32 * n, hipMemcpyDeviceToHost, c->stream));
     return finish(c);
 }

@@ -47,7 +47,7 @@ enum {
 };
 
 /* field ops of h2agg_fr_batch_op */
-enum { H2AGG_OP_ADD = 0, H2AGG_OP_SUB = 1, H2AGG_OP_MUL = 2, H2AGG_OP_SQR = 3, H2AGG_OP_INV = 4 };
+enum { H2AGG_OP_ADD = 0, H2AGG_OP_SUB = 1, H2AGG_OP_MUL = 2, H2AGG_OP_SQR = 3, H2AGG_OP_INV = 4, H2AGG_OP_DIV = 5 };
 
 /* ---- lifetime -------------------------------------------------------------------------------------
  * replaces: `MockEccChip::default()` / `MockFieldChip::default()` / `MockChipCtx::default()`
@@ -65,8 +65,11 @@ const char* h2agg_describe(h2agg_ctx* ctx);
 /* ---- Fr batch ops (host buffers) ------------------------------------------------------------------
  * replaces: MockFieldChip::{add,sub,mul,square,div} element-wise over n operands
  * (halo2-snark-aggregator-api/src/mock/arith/field.rs:39-55, 98-122).  `b` is ignored for SQR / INV.
- * INV of 0 -> H2AGG_ERR_DIV_ZERO (reference: `invert().unwrap()` panics).  n == 0 is a no-op. */
+ * INV of 0 and DIV by 0 -> H2AGG_ERR_DIV_ZERO (reference: `invert().unwrap()` panics).  n == 0 is a no-op. */
 int h2agg_fr_batch_op(h2agg_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out);
+/* replaces: ArithFieldChip::pow_constant (arith/field.rs:83-104) over n bases with one exponent >= 1
+ * (exponent 0 -> H2AGG_ERR_INVALID: the reference asserts). */
+int h2agg_fr_batch_pow_constant(h2agg_ctx* ctx, const uint8_t* a, size_t n, uint64_t exponent, uint8_t* out);
 
 /* replaces: ArithFieldChip::mul_add_accumulate default (Horner: acc = acc*b + v_i, acc_0 = 0)
  * (halo2-snark-aggregator-api/src/arith/field.rs:68-81). */

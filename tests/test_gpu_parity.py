@@ -26,6 +26,21 @@ def test_fr_batch_op(eng, op):
     assert got == cref.field_batch_op(0, op, ab, bb if op <= 2 else None, n)
 
 
+def test_fr_div_and_pow_constant(eng, pkg):
+    """MockFieldChip::div (mock/arith/field.rs:107-114) and ArithFieldChip::pow_constant (arith/field.rs:83-104)"""
+    rng = O.SplitMix64(0xD1F)
+    a = rand_frs(rng, 500) + [0, 1, O.R - 1]
+    b = [x or 3 for x in rand_frs(rng, 500)] + [5, O.R - 1, 1]
+    got = eng.fr_batch_op(5, fr_bytes(a), fr_bytes(b))
+    assert got == fr_bytes([x * pow(y, -1, O.R) % O.R for x, y in zip(a, b)])
+    with pytest.raises(pkg.DivisionByZero):
+        eng.fr_batch_op(5, fr_bytes([1, 2]), fr_bytes([3, 0]))
+    for e in (1, 2, 3, 7, 1 << 17, (1 << 32) + 5, (1 << 64) - 1):
+        assert eng.fr_batch_pow_constant(fr_bytes(a), e) == fr_bytes([pow(x, e, O.R) for x in a])
+    with pytest.raises(pkg.H2AggError):
+        eng.fr_batch_pow_constant(fr_bytes(a), 0)
+
+
 def test_fr_inv_zero_is_an_error(eng, pkg):
     # MockFieldChip::div: `b.invert().unwrap()` panics on zero (mock/arith/field.rs:113)
     with pytest.raises(pkg.DivisionByZero):
