@@ -111,13 +111,14 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
     d_inst = d_inst_out = None
     my_idx = agg.shard_indices(n_total, world, rank)
     if n_inst and my_idx:
-        rows = []
-        for i in my_idx:                                       # seeded per GLOBAL proof id: sharding-independent
-            gen = torch.Generator(device="cpu").manual_seed(0x1A57 + i)
-            rows.append(torch.randint(0, 256, (n_inst, 32), dtype=torch.uint8, generator=gen))
-        inst = torch.stack(rows)
-        inst[:, :, 31] &= 0x1F                                 # < 2^253 < r: canonical
-        d_inst = inst.to(dev)                                  # this rank's proofs, contiguous: [local][n_inst][32]
+        # generated on the device, seeded per GLOBAL proof id (sharding-independent; SURVEY.md 8(d) config 5: "scalars
+        # generated on device from (seed, proof-id) to keep PCIe out of the measurement")
+        d_inst = torch.empty((len(my_idx), n_inst, 32), dtype=torch.uint8, device=dev)
+        gen = torch.Generator(device=dev)
+        for j, i in enumerate(my_idx):
+            gen.manual_seed(0x1A57 + i)
+            d_inst[j] = torch.randint(0, 256, (n_inst, 32), dtype=torch.uint8, device=dev, generator=gen)
+        d_inst[:, :, 31] &= 0x1F                               # < 2^253 < r: canonical
         d_inst_out = torch.zeros((len(my_idx), 96), dtype=torch.uint8, device=dev)
 
     packed = []
@@ -327,7 +328,9 @@ def main():
         agg_info = aggregation_leg(pkg, eng, args, rank, world, dist, (dev, coll_dev), g_table)  # configs[2]/[3]: 4 proofs per GPU
         big = argparse.Namespace(**vars(args))
         big.agg_proofs = 4 * args.agg_proofs                                       # configs[4]: 16 proofs per GPU
-        more = aggregation_leg(pkg, eng, big, rank, world, dist, (dev, coll_dev), g_table)
+        more = None
+        if args.agg_instance_log2 < 20:     # (a config-5 run, --agg-proofs 16 --agg-instance-log2 22, is one leg only)
+            more = aggregation_leg(pkg, eng, big, rank, world, dist, (dev, coll_dev), g_table)
         if agg_info is not None and more is not None:
             agg_info["at_%d_proofs_per_gpu" % big.agg_proofs] = {
                 k: more[k] for k in ("proofs_per_sec", "proofs", "seconds_per_aggregation")}
