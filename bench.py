@@ -70,6 +70,33 @@ def measured_traffic(stage_name: str, log2n: int):
     return None
 
 
+def valu_view(stage_name: str, log2n: int, avg_kernel_s: float):
+    """The roofline that actually bounds the dominant kernel: VALU issue.  Instruction count and shader clock come from
+    the committed PMC pass over the same command (profiles/r01_final_pmc_sq.txt: SQ_INSTS_VALU, GRBM_GUI_ACTIVE summed
+    over the 8 XCDs); the duration is this run's live figure.  `ideal` = cycles per wave-instruction per SIMD if the VALU
+    never stalled, from the kernel's instruction mix at the measured issue rates (tools/ubench.hip: v_mad_u64_u32,
+    v_mul_lo_u32, v_lshl_add_u64, 64-bit shifts 4 cycles per wave64; 32-bit add / and / cndmask 2): 3.56."""
+    if not (log2n == 20 and stage_name == "msm_accumulate"):
+        return None
+    try:
+        vals = {}
+        with open(os.path.join(ROOT, "profiles", "r01_final_pmc_sq.txt")) as f:
+            for line in f:
+                p = line.split()
+                if len(p) == 5 and p[0] == "h2agg::k_msm_accumulate":
+                    vals[p[1]] = (float(p[3]), float(p[4]))
+        insts, dur_us = vals["SQ_INSTS_VALU"]
+        clk_hz = vals["GRBM_GUI_ACTIVE"][0] / 8.0 / (dur_us * 1e-6)
+    except (OSError, KeyError, ValueError):
+        return None
+    simds = 256 * 4
+    cpi = avg_kernel_s * clk_hz * simds / insts
+    ideal = 3.56
+    return {"wave_instructions_per_launch": insts, "shader_clock_ghz": clk_hz / 1e9, "simds": simds,
+            "cycles_per_instruction_per_simd": cpi, "ideal_cycles_per_instruction": ideal, "issue_frac": ideal / cpi,
+            "source": "profiles/r01_final_pmc_sq.txt (rocprofv3 --pmc, same command) + this run's avg_kernel_ms"}
+
+
 def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
     """Secondary figure (BASELINE.json metric, second half): aggregated proofs/s through the full
     EvaluationQuerySchema::eval path.  `agg_proofs` synthetic proofs per GPU (shape: `agg_commitments`
@@ -376,11 +403,12 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": measured_traffic(dom_name, args.log2n),
+                "valu": valu_view(dom_name, args.log2n, dom_avg_s),
                 "avg_kernel_ms": dom_avg_s * 1e3,
                 "note": "MSM is integer-VALU-bound (v_mad_u64_u32 chains), not HBM-bound: the algorithmic "
-                        "96 B/point is a tiny fraction of peak by construction (SURVEY.md \u00a78d). VALU view "
-                        "(profiles/r01_final_pmc_sq.txt): 692 M wave-instructions per launch, 4.29 cycles per "
-                        "instruction per SIMD at 2.05 GHz against ~3.5 for this instruction mix = ~82 % VALU issue",
+                        "96 B/point is a tiny fraction of peak by construction (SURVEY.md \u00a78d).  The bound that "
+                        "applies is VALU issue: see `valu` (instruction count and clock from the committed PMC pass, "
+                        "duration from this run)",
                 "stages_ms_per_step": {k: v[0] / max(v[1], 1) for k, v in stages.items()},
                 "stages_note": "per-stage table from an untimed pass with all nine stages bracketed by events; inside "
                                "the timed region only the dominant kernel is bracketed (avg_kernel_ms)",
