@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libh2agg.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "h2agg.h")
 
-OK, ERR_INVALID, ERR_DIV_ZERO, ERR_EMPTY, ERR_HIP, ERR_NONCANONICAL, ERR_NOMEM = range(7)
+OK, ERR_INVALID, ERR_DIV_ZERO, ERR_EMPTY, ERR_HIP, ERR_NONCANONICAL, ERR_NOMEM, ERR_BAD_POINT = range(8)
 OP_ADD, OP_SUB, OP_MUL, OP_SQR, OP_INV, OP_DIV = range(6)
 
 IDENTITY_JAC = (0).to_bytes(32, "little") + (1).to_bytes(32, "little") + (0).to_bytes(32, "little")
@@ -31,6 +31,10 @@ class H2AggError(RuntimeError):
 
 class EmptyMultiExp(H2AggError):
     """multi_exp of zero pairs — the reference panics (`acc.unwrap()`, mock/arith/ecc.rs:128)."""
+
+
+class BadPoint(H2AggError, ValueError):
+    """"invalid point encoding in proof" (systems/halo2/transcript.rs:65-70)."""
 
 
 class DivisionByZero(H2AggError, ZeroDivisionError):
@@ -67,6 +71,8 @@ def load_library():
         "h2agg_g1_batch_scalar_mul": (i32, [ctxp, u8p, u8p, sz, vp]),
         "h2agg_g1_batch_to_affine": (i32, [ctxp, u8p, sz, vp]),
         "h2agg_g1_sum": (i32, [ctxp, u8p, sz, vp]),
+        "h2agg_g1_batch_decompress": (i32, [ctxp, u8p, sz, vp, vp]),
+        "h2agg_g1_batch_compress": (i32, [ctxp, u8p, sz, vp]),
         "h2agg_g1_msm": (i32, [ctxp, vp, vp, sz, vp]),
         "h2agg_host_alloc": (i32, [ctxp, sz, C.POINTER(vp)]),
         "h2agg_host_free": (i32, [ctxp, vp]),
@@ -169,6 +175,8 @@ class H2Agg:
             raise EmptyMultiExp(rc, msg)
         if rc == ERR_DIV_ZERO:
             raise DivisionByZero(rc, msg)
+        if rc == ERR_BAD_POINT:
+            raise BadPoint(rc, msg)
         raise H2AggError(rc, msg)
 
     def describe(self) -> str:
@@ -226,6 +234,22 @@ class H2Agg:
         out = C.create_string_buffer(64 * n)
         self._check(self._lib.h2agg_g1_batch_to_affine_device(self._ctx, C.c_void_p(d_jac_ptr), n, out))
         return out.raw
+
+    def g1_batch_decompress(self, data: bytes, with_ok: bool = False):
+        """proof wire format -> canonical affine (transcript.rs:63-70); raises BadPoint unless with_ok"""
+        n = len(data) // 32
+        out, ok = C.create_string_buffer(max(64 * n, 1)), C.create_string_buffer(max(n, 1))
+        rc = self._lib.h2agg_g1_batch_decompress(self._ctx, data, n, out, ok)
+        if with_ok and rc in (OK, ERR_BAD_POINT):
+            return out.raw[:64 * n], ok.raw[:n]
+        self._check(rc)
+        return out.raw[:64 * n]
+
+    def g1_batch_compress(self, aff: bytes) -> bytes:
+        n = len(aff) // 64
+        out = C.create_string_buffer(max(32 * n, 1))
+        self._check(self._lib.h2agg_g1_batch_compress(self._ctx, aff, n, out))
+        return out.raw[:32 * n]
 
     def g1_sum(self, jac: bytes) -> bytes:
         out = C.create_string_buffer(96)

@@ -6,7 +6,7 @@
 namespace h2agg {
 
 // status bits a kernel may raise (atomicOr into ctx->d_flags)
-enum : uint32_t { FLAG_NONCANONICAL = 1u, FLAG_DIV_ZERO = 2u };
+enum : uint32_t { FLAG_NONCANONICAL = 1u, FLAG_DIV_ZERO = 2u, FLAG_BAD_POINT = 4u };
 
 constexpr int BLOCK = 256;
 
@@ -287,6 +287,79 @@ __global__ void __launch_bounds__(BLOCK) k_g1_batch_to_affine(const uint8_t* __r
         G1Affine a = affine_from_xyzz(xyzz_from_jac(jac_load_canonical(in + 96 * i)));
         fp_store<FqParams>(out + 64 * i, fp_from_mont<FqParams>(a.x));
         fp_store<FqParams>(out + 64 * i + 32, fp_from_mont<FqParams>(a.y));
+    }
+}
+
+// ------------------------------------------------------------------ proof wire format of a G1 point
+// What the transcript reader hands to the path (systems/halo2/transcript.rs:56-79: read_exact(32 bytes) ->
+// C::from_bytes -> "invalid point encoding in proof").  Encoding (halo2curves 0.2.1 GroupEncoding for bn256, recalled
+// from upstream — SURVEY.md appendix C; the crate is not vendored in the reference): 32 bytes little-endian x with the
+// parity of y (y.to_bytes()[0] & 1) in bit 7 of byte 31; the identity is 32 zero bytes.
+// Decoding: x must be canonical (< p); x = 0 without the sign bit is the identity; otherwise y = sqrt(x^3 + 3) must exist
+// (p = 3 mod 4: y = rhs^((p+1)/4), valid iff y^2 = rhs) and the root with the encoded parity is taken.
+FP_INLINE Fq fq_sqrt_candidate(const Fq& a) {   // a^((p+1)/4), Montgomery in / out
+    constexpr uint32_t E[8] = {0xb61f3f52u, 0x4f082305u, 0x5a1c72a3u, 0x65e05aa4u,
+                               0xa0605617u, 0x6e14116du, 0xb84c680au, 0x0c19139cu};   // (p + 1) / 4, 252 bits
+    Fq acc = Fq::one();
+#pragma unroll 1
+    for (int bit = 251; bit >= 0; --bit) {
+        acc = FQ_SQR(acc);
+        uint32_t w = 0;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) w = (bit / 32 == i) ? E[i] : w;
+        if ((w >> (bit % 32)) & 1u) acc = FQ_MUL(acc, a);
+    }
+    return acc;
+}
+__global__ void __launch_bounds__(BLOCK) k_g1_batch_decompress(const uint8_t* __restrict__ in, size_t n,
+                                                               uint8_t* __restrict__ out_aff, uint8_t* __restrict__ ok,
+                                                               uint32_t* flags) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        U256 w = u256_load(in + 32 * i);
+        const uint32_t ysign = w.w[7] >> 31;
+        w.w[7] &= 0x7fffffffu;
+        Fq x = fp_unpack<FqParams>(w.w);
+        bool good = fp_is_canonical<FqParams>(x);
+        Fq ox = Fq::zero(), oy = Fq::zero();
+        if (good && !(x.is_zero_int() && !ysign)) {
+            const Fq xm = fp_to_mont<FqParams>(x);
+            Fq three;
+#pragma unroll
+            for (int k = 0; k < NL; ++k) three.l[k] = 0;
+            three.l[0] = 3;
+            const Fq rhs = FQ_ADD(FQ_MUL(FQ_SQR(xm), xm), fp_to_mont<FqParams>(three));   // x^3 + 3, [4]
+            const Fq y = fq_sqrt_candidate(rhs);
+            good = fp_is_zero_mod<8, FqParams>(FQ_SUB(4, FQ_SQR(y), rhs));               // y^2 == rhs
+            Fq yc = fp_from_mont<FqParams>(y);                                             // canonical
+            if ((yc.l[0] & 1u) != ysign) {                                                 // take the other root: p - y
+                int32_t d[NL];
+#pragma unroll
+                for (int k = 0; k < NL; ++k) d[k] = (int32_t)FqParams::MOD[k] - (int32_t)yc.l[k];
+                yc = fp_normalize<FqParams>(d);                                            // y != 0 here (3 is a non-residue)
+            }
+            if (good) {
+                ox = x;
+                oy = yc;
+            }
+        }
+        if (!good) atomicOr(flags, FLAG_BAD_POINT);
+        if (ok) ok[i] = good ? 1 : 0;
+        fp_store<FqParams>(out_aff + 64 * i, ox);
+        fp_store<FqParams>(out_aff + 64 * i + 32, oy);
+    }
+}
+// canonical affine (64 B, identity = zeros) -> 32-byte encoding
+__global__ void __launch_bounds__(BLOCK) k_g1_batch_compress(const uint8_t* __restrict__ aff, size_t n,
+                                                             uint8_t* __restrict__ out, uint32_t* flags) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        Fq x = fp_load<FqParams>(aff + 64 * i), y = fp_load<FqParams>(aff + 64 * i + 32);
+        if (!fp_is_canonical<FqParams>(x) | !fp_is_canonical<FqParams>(y)) atomicOr(flags, FLAG_NONCANONICAL);
+        uint32_t w[8];
+        fp_pack<FqParams>(w, x);
+        if (!(x.is_zero_int() && y.is_zero_int())) w[7] |= (y.l[0] & 1u) << 31;
+        uint4* o = reinterpret_cast<uint4*>(out + 32 * i);
+        o[0] = make_uint4(w[0], w[1], w[2], w[3]);
+        o[1] = make_uint4(w[4], w[5], w[6], w[7]);
     }
 }
 

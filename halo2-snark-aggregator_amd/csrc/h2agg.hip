@@ -159,6 +159,7 @@ int finish(h2agg_ctx* c) {
     memcpy(&f, c->h_pinned + 2048, 4);
     if (f & FLAG_DIV_ZERO) return fail(c, H2AGG_ERR_DIV_ZERO, "inversion of zero (reference: invert().unwrap() panics)");
     if (f & FLAG_NONCANONICAL) return fail(c, H2AGG_ERR_NONCANONICAL, "input integer >= modulus");
+    if (f & FLAG_BAD_POINT) return fail(c, H2AGG_ERR_BAD_POINT, "invalid point encoding in proof");
     return H2AGG_OK;
 }
 
@@ -754,6 +755,35 @@ int h2agg_g1_batch_to_affine_device(h2agg_ctx* c, const uint8_t* d_in_jac, size_
     hipLaunchKernelGGL(k_g1_batch_to_affine, dim3(grid_for(c, n)), dim3(BLOCK), 0, c->stream, d_in_jac, n,
                        (uint8_t*)c->out.p, c->d_flags);
     HIP_TRY(c, hipMemcpyAsync(out, c->out.p, 64 * n, hipMemcpyDeviceToHost, c->stream));
+    return finish(c);
+}
+
+int h2agg_g1_batch_decompress(h2agg_ctx* c, const uint8_t* in, size_t n, uint8_t* out_aff, uint8_t* ok) {
+    TRY(bind(c));
+    if (n == 0) return H2AGG_OK;
+    if (!in || !out_aff) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    TRY(ensure(c, c->in_a, 32 * n));
+    TRY(ensure(c, c->out, 64 * n));
+    TRY(ensure(c, c->in_b, n + 16));
+    HIP_TRY(c, hipMemcpyAsync(c->in_a.p, in, 32 * n, hipMemcpyHostToDevice, c->stream));
+    TRY(clear_flags(c));
+    hipLaunchKernelGGL(k_g1_batch_decompress, dim3(grid_for(c, n)), dim3(BLOCK), 0, c->stream, (const uint8_t*)c->in_a.p, n,
+                       (uint8_t*)c->out.p, (uint8_t*)c->in_b.p, c->d_flags);
+    HIP_TRY(c, hipMemcpyAsync(out_aff, c->out.p, 64 * n, hipMemcpyDeviceToHost, c->stream));
+    if (ok) HIP_TRY(c, hipMemcpyAsync(ok, c->in_b.p, n, hipMemcpyDeviceToHost, c->stream));
+    return finish(c);
+}
+int h2agg_g1_batch_compress(h2agg_ctx* c, const uint8_t* aff, size_t n, uint8_t* out) {
+    TRY(bind(c));
+    if (n == 0) return H2AGG_OK;
+    if (!aff || !out) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    TRY(ensure(c, c->in_a, 64 * n));
+    TRY(ensure(c, c->out, 32 * n));
+    HIP_TRY(c, hipMemcpyAsync(c->in_a.p, aff, 64 * n, hipMemcpyHostToDevice, c->stream));
+    TRY(clear_flags(c));
+    hipLaunchKernelGGL(k_g1_batch_compress, dim3(grid_for(c, n)), dim3(BLOCK), 0, c->stream, (const uint8_t*)c->in_a.p, n,
+                       (uint8_t*)c->out.p, c->d_flags);
+    HIP_TRY(c, hipMemcpyAsync(out, c->out.p, 32 * n, hipMemcpyDeviceToHost, c->stream));
     return finish(c);
 }
 

@@ -43,7 +43,8 @@ enum {
     H2AGG_ERR_EMPTY = 3,        /* multi_exp of zero pairs: reference panics, mock/arith/ecc.rs:128 */
     H2AGG_ERR_HIP = 4,          /* HIP runtime / device failure */
     H2AGG_ERR_NONCANONICAL = 5, /* an input integer was >= its modulus */
-    H2AGG_ERR_NOMEM = 6
+    H2AGG_ERR_NOMEM = 6,
+    H2AGG_ERR_BAD_POINT = 7     /* a compressed point does not decode: "invalid point encoding in proof", transcript.rs:65-70 */
 };
 
 /* field ops of h2agg_fr_batch_op */
@@ -98,6 +99,16 @@ int h2agg_g1_batch_to_affine(h2agg_ctx* ctx, const uint8_t* in_jac, size_t n, ui
 /* h2agg_g1_batch_to_affine for Jacobian points already in device memory (e.g. the outputs of
  * h2agg_g1_msm_device_async: N instance-column commitments become affine with one launch and one download). */
 int h2agg_g1_batch_to_affine_device(h2agg_ctx* ctx, const uint8_t* d_in_jac, size_t n, uint8_t* out_aff);
+/* ---- proof wire format (the data format on the input side of the path) ----------
+ * replaces: the `C::from_bytes(&compressed)` of TranscriptRead::read_point / read_constant_point
+ * (halo2-snark-aggregator-api/src/systems/halo2/transcript.rs:56-99), for all the points of a proof (or of N proofs) at once.
+ * Encoding: 32 bytes little-endian x, parity of y in bit 7 of byte 31, identity = 32 zero bytes (halo2curves 0.2.1, recalled
+ * from upstream: the crate is not vendored in the reference).  out_aff: canonical affine, 64 B each; ok (optional): one byte
+ * per point, 1 = decoded.  Any point that does not decode (x >= p, or x^3 + 3 not a square) -> H2AGG_ERR_BAD_POINT with that
+ * point's output zeroed and ok = 0; the others are still written. */
+int h2agg_g1_batch_decompress(h2agg_ctx* ctx, const uint8_t* in, size_t n, uint8_t* out_aff, uint8_t* ok);
+/* the inverse (G1Affine::to_bytes): canonical affine points -> 32-byte encodings */
+int h2agg_g1_batch_compress(h2agg_ctx* ctx, const uint8_t* aff, size_t n, uint8_t* out);
 /* Sum of n Jacobian points (the local fold after the multi-GPU all-gather of partial (W_x, W_g),
  * SURVEY.md §8e; arithmetic = MockEccChip::add, mock/arith/ecc.rs:30-37).  n == 0 -> identity. */
 int h2agg_g1_sum(h2agg_ctx* ctx, const uint8_t* in_jac, size_t n, uint8_t out_jac[96]);

@@ -159,6 +159,35 @@ def aff_from_bytes(b: bytes):
     return (x, y)
 
 
+def compress(pt) -> bytes:
+    """G1Affine::to_bytes — the 32-byte point encoding of the proof wire format (written by the prover's transcript,
+    read back at systems/halo2/transcript.rs:56-79).  halo2curves 0.2.1 (unvendored; layout recalled from upstream,
+    SURVEY.md appendix C): little-endian x, parity of y in bit 7 of byte 31, identity = zeros."""
+    if pt is INF:
+        return bytes(32)
+    b = bytearray(fe_to_bytes(pt[0]))
+    b[31] |= (pt[1] & 1) << 7
+    return bytes(b)
+
+
+def decompress(b: bytes):
+    """G1Affine::from_bytes.  Returns the point, INF, or raises ValueError ("invalid point encoding in proof")."""
+    assert len(b) == 32
+    ysign = b[31] >> 7
+    x = int.from_bytes(b[:31] + bytes([b[31] & 0x7F]), "little")
+    if x >= P:
+        raise ValueError("invalid point encoding in proof (x >= p)")
+    if x == 0 and not ysign:
+        return INF
+    rhs = (x * x * x + B) % P
+    y = pow(rhs, (P + 1) // 4, P)                # p = 3 mod 4
+    if y * y % P != rhs:
+        raise ValueError("invalid point encoding in proof (not on the curve)")
+    if (y & 1) != ysign:
+        y = P - y
+    return (x, y)
+
+
 def jac_to_bytes(pt, z: int = 1) -> bytes:
     """Encode an affine point as Jacobian with the given non-zero z (tests use z != 1 to make sure
     consumers do not assume normalised inputs)."""

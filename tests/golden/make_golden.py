@@ -147,9 +147,18 @@ def schema_kats():
     return out
 
 
+def wire_kats():
+    """proof wire format of G1 points (oracle.bn254.compress / decompress; transcript.rs:56-79)"""
+    rng = O.SplitMix64(0x31370000)
+    pts = [O.scalar_mul(rng.fr(), O.G1) for _ in range(16)] + [O.INF, O.G1, O.neg(O.G1)]
+    return {"note": "seed 0x31370000: 16 random multiples of G, identity, G, -G",
+            "compressed": b"".join(O.compress(p) for p in pts).hex(),
+            "affine": b"".join(O.aff_to_bytes(p) for p in pts).hex()}
+
+
 def main():
     files = {"field_kats.json": field_kats(), "point_kats.json": point_kats(), "msm_kats.json": msm_kats(),
-             "schema_kats.json": schema_kats()}
+             "schema_kats.json": schema_kats(), "wire_kats.json": wire_kats()}
     for name, data in files.items():
         with open(os.path.join(HERE, name), "w") as f:
             json.dump(data, f, indent=0, sort_keys=True)

@@ -203,3 +203,27 @@ def test_schema_eval_semantics_small():
     # a schema whose only commitment has no scalar hits the reference panic (multi_exp of zero pairs)
     with pytest.raises(ValueError):
         S.commit(cp).eval(ctx, sc, pc, 1)
+
+
+def test_point_wire_format_roundtrip():
+    """compress / decompress (the proof wire format, transcript.rs:56-79) are inverse on curve points, reject
+    non-residues and non-canonical x, and map 32 zero bytes to the identity."""
+    rng = O.SplitMix64(0x77)
+    for _ in range(40):
+        p = O.scalar_mul(rng.fr(), O.G1)
+        enc = O.compress(p)
+        assert len(enc) == 32 and O.decompress(enc) == p and O.is_on_curve(p)
+        assert O.decompress(O.compress(O.neg(p))) == O.neg(p) and O.compress(O.neg(p))[:31] == enc[:31]
+    assert O.compress(O.INF) == bytes(32) and O.decompress(bytes(32)) is O.INF
+    assert O.decompress(O.compress(O.G1)) == (1, 2) and O.compress(O.G1)[31] == 0      # y = 2 is even
+    bad = 0
+    for x in range(2, 60):
+        try:
+            O.decompress(x.to_bytes(32, "little"))
+        except ValueError:
+            bad += 1
+    assert 15 < bad < 45                                                                 # about half are non-residues
+    with pytest.raises(ValueError):
+        O.decompress((O.P + 1).to_bytes(32, "little"))
+    with pytest.raises(ValueError):
+        O.decompress(bytes(31) + bytes([0x80]))                                          # x = 0 with the sign bit: 3 is a non-residue
