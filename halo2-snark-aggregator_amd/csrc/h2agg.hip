@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <new>
 #include <string>
 #include <vector>
 
@@ -531,7 +532,7 @@ int bind(h2agg_ctx* c) {
 
 extern "C" {
 
-int h2agg_create(int device_ordinal, h2agg_ctx** out) {
+int h2agg_create(int device_ordinal, h2agg_ctx** out) try {
     if (!out) return H2AGG_ERR_INVALID;
     *out = nullptr;
     int count = 0;
@@ -569,6 +570,10 @@ int h2agg_create(int device_ordinal, h2agg_ctx** out) {
     hipMemset(c->small.p, 0, 2048);
     *out = c;
     return H2AGG_OK;
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
 void h2agg_destroy(h2agg_ctx* c) {
@@ -612,23 +617,31 @@ void h2agg_destroy(h2agg_ctx* c) {
 const char* h2agg_last_error(const h2agg_ctx* c) { return c ? c->err.c_str() : "null context"; }
 const char* h2agg_describe(h2agg_ctx* c) { return c ? c->desc.c_str() : ""; }
 
-int h2agg_set_stream(h2agg_ctx* c, void* hip_stream) {
+int h2agg_set_stream(h2agg_ctx* c, void* hip_stream) try {
     TRY(bind(c));
     TRY(join_tails(c));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     return H2AGG_OK;
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
-int h2agg_synchronize(h2agg_ctx* c) {
+int h2agg_synchronize(h2agg_ctx* c) try {
     TRY(bind(c));
     TRY(join_tails(c));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return H2AGG_OK;
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
 // ---------------------------------------------------------------- Fr
-int h2agg_fr_batch_op(h2agg_ctx* c, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) {
+int h2agg_fr_batch_op(h2agg_ctx* c, int op, const uint8_t* a, const uint8_t* b, size_t n, uint8_t* out) try {
     TRY(bind(c));
     if (op < H2AGG_OP_ADD || op > H2AGG_OP_DIV) return fail(c, H2AGG_ERR_INVALID, "unknown field op");
     if (n == 0) return H2AGG_OK;
@@ -646,9 +659,13 @@ int h2agg_fr_batch_op(h2agg_ctx* c, int op, const uint8_t* a, const uint8_t* b, 
                        (const uint8_t*)c->in_b.p, n, (uint8_t*)c->out.p, c->d_flags);
     HIP_TRY(c, hipMemcpyAsync(out, c->out.p, 32 * n, hipMemcpyDeviceToHost, c->stream));
     return finish(c);
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
-int h2agg_fr_batch_pow_constant(h2agg_ctx* c, const uint8_t* a, size_t n, uint64_t exponent, uint8_t* out) {
+int h2agg_fr_batch_pow_constant(h2agg_ctx* c, const uint8_t* a, size_t n, uint64_t exponent, uint8_t* out) try {
     TRY(bind(c));
     if (exponent < 1) return fail(c, H2AGG_ERR_INVALID, "assert!(exponent >= 1) failed (arith/field.rs:89)");
     if (n == 0) return H2AGG_OK;
@@ -661,9 +678,13 @@ int h2agg_fr_batch_pow_constant(h2agg_ctx* c, const uint8_t* a, size_t n, uint64
                        exponent, (uint8_t*)c->out.p, c->d_flags);
     HIP_TRY(c, hipMemcpyAsync(out, c->out.p, 32 * n, hipMemcpyDeviceToHost, c->stream));
     return finish(c);
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
-int h2agg_fr_mul_add_accumulate(h2agg_ctx* c, const uint8_t* v, size_t n, const uint8_t b[32], uint8_t out[32]) {
+int h2agg_fr_mul_add_accumulate(h2agg_ctx* c, const uint8_t* v, size_t n, const uint8_t b[32], uint8_t out[32]) try {
     TRY(bind(c));
     if ((n && !v) || !b || !out) return fail(c, H2AGG_ERR_INVALID, "null buffer");
     TRY(ensure(c, c->in_a, 32 * n + 32));
@@ -676,10 +697,14 @@ int h2agg_fr_mul_add_accumulate(h2agg_ctx* c, const uint8_t* v, size_t n, const 
                        (const uint8_t*)c->in_b.p, (uint8_t*)c->out.p, c->d_flags);
     HIP_TRY(c, hipMemcpyAsync(out, c->out.p, 32, hipMemcpyDeviceToHost, c->stream));
     return finish(c);
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
 int h2agg_fr_sum_with_coeff_and_constant(h2agg_ctx* c, const uint8_t* x, const uint8_t* coeff, size_t n,
-                                         const uint8_t b[32], uint8_t out[32]) {
+                                         const uint8_t b[32], uint8_t out[32]) try {
     TRY(bind(c));
     if ((n && (!x || !coeff)) || !b || !out) return fail(c, H2AGG_ERR_INVALID, "null buffer");
     TRY(ensure(c, c->in_a, 32 * n + 32));
@@ -696,10 +721,14 @@ int h2agg_fr_sum_with_coeff_and_constant(h2agg_ctx* c, const uint8_t* x, const u
                        (const uint8_t*)c->in_b.p, n, (const uint8_t*)c->in_c.p, (uint8_t*)c->out.p, c->d_flags);
     HIP_TRY(c, hipMemcpyAsync(out, c->out.p, 32, hipMemcpyDeviceToHost, c->stream));
     return finish(c);
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
 // ---------------------------------------------------------------- G1 batch
-int h2agg_g1_batch_add(h2agg_ctx* c, const uint8_t* a, const uint8_t* b, size_t n, int subtract, uint8_t* out) {
+int h2agg_g1_batch_add(h2agg_ctx* c, const uint8_t* a, const uint8_t* b, size_t n, int subtract, uint8_t* out) try {
     TRY(bind(c));
     if (n == 0) return H2AGG_OK;
     if (!a || !b || !out) return fail(c, H2AGG_ERR_INVALID, "null buffer");
@@ -713,9 +742,13 @@ int h2agg_g1_batch_add(h2agg_ctx* c, const uint8_t* a, const uint8_t* b, size_t 
                        (const uint8_t*)c->in_b.p, n, subtract, (uint8_t*)c->out.p, c->d_flags);
     HIP_TRY(c, hipMemcpyAsync(out, c->out.p, 96 * n, hipMemcpyDeviceToHost, c->stream));
     return finish(c);
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
-int h2agg_g1_batch_scalar_mul(h2agg_ctx* c, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t* out) {
+int h2agg_g1_batch_scalar_mul(h2agg_ctx* c, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t* out) try {
     TRY(bind(c));
     if (n == 0) return H2AGG_OK;
     if (!bases || !scalars || !out) return fail(c, H2AGG_ERR_INVALID, "null buffer");
@@ -729,9 +762,13 @@ int h2agg_g1_batch_scalar_mul(h2agg_ctx* c, const uint8_t* bases, const uint8_t*
                        (const uint8_t*)c->in_a.p, (const uint8_t*)c->in_b.p, n, (uint8_t*)c->out.p, c->d_flags);
     HIP_TRY(c, hipMemcpyAsync(out, c->out.p, 96 * n, hipMemcpyDeviceToHost, c->stream));
     return finish(c);
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
-int h2agg_g1_batch_to_affine(h2agg_ctx* c, const uint8_t* in, size_t n, uint8_t* out) {
+int h2agg_g1_batch_to_affine(h2agg_ctx* c, const uint8_t* in, size_t n, uint8_t* out) try {
     TRY(bind(c));
     if (n == 0) return H2AGG_OK;
     if (!in || !out) return fail(c, H2AGG_ERR_INVALID, "null buffer");
@@ -743,9 +780,13 @@ int h2agg_g1_batch_to_affine(h2agg_ctx* c, const uint8_t* in, size_t n, uint8_t*
                        (const uint8_t*)c->in_a.p, n, (uint8_t*)c->out.p, c->d_flags);
     HIP_TRY(c, hipMemcpyAsync(out, c->out.p, 64 * n, hipMemcpyDeviceToHost, c->stream));
     return finish(c);
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
-int h2agg_g1_batch_to_affine_device(h2agg_ctx* c, const uint8_t* d_in_jac, size_t n, uint8_t* out) {
+int h2agg_g1_batch_to_affine_device(h2agg_ctx* c, const uint8_t* d_in_jac, size_t n, uint8_t* out) try {
     TRY(bind(c));
     if (n == 0) return H2AGG_OK;
     if (!d_in_jac || !out) return fail(c, H2AGG_ERR_INVALID, "null buffer");
@@ -756,9 +797,13 @@ int h2agg_g1_batch_to_affine_device(h2agg_ctx* c, const uint8_t* d_in_jac, size_
                        (uint8_t*)c->out.p, c->d_flags);
     HIP_TRY(c, hipMemcpyAsync(out, c->out.p, 64 * n, hipMemcpyDeviceToHost, c->stream));
     return finish(c);
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
-int h2agg_g1_batch_decompress(h2agg_ctx* c, const uint8_t* in, size_t n, uint8_t* out_aff, uint8_t* ok) {
+int h2agg_g1_batch_decompress(h2agg_ctx* c, const uint8_t* in, size_t n, uint8_t* out_aff, uint8_t* ok) try {
     TRY(bind(c));
     if (n == 0) return H2AGG_OK;
     if (!in || !out_aff) return fail(c, H2AGG_ERR_INVALID, "null buffer");
@@ -772,8 +817,12 @@ int h2agg_g1_batch_decompress(h2agg_ctx* c, const uint8_t* in, size_t n, uint8_t
     HIP_TRY(c, hipMemcpyAsync(out_aff, c->out.p, 64 * n, hipMemcpyDeviceToHost, c->stream));
     if (ok) HIP_TRY(c, hipMemcpyAsync(ok, c->in_b.p, n, hipMemcpyDeviceToHost, c->stream));
     return finish(c);
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
-int h2agg_g1_batch_compress(h2agg_ctx* c, const uint8_t* aff, size_t n, uint8_t* out) {
+int h2agg_g1_batch_compress(h2agg_ctx* c, const uint8_t* aff, size_t n, uint8_t* out) try {
     TRY(bind(c));
     if (n == 0) return H2AGG_OK;
     if (!aff || !out) return fail(c, H2AGG_ERR_INVALID, "null buffer");
@@ -785,9 +834,13 @@ int h2agg_g1_batch_compress(h2agg_ctx* c, const uint8_t* aff, size_t n, uint8_t*
                        (uint8_t*)c->out.p, c->d_flags);
     HIP_TRY(c, hipMemcpyAsync(out, c->out.p, 32 * n, hipMemcpyDeviceToHost, c->stream));
     return finish(c);
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
-int h2agg_g1_sum(h2agg_ctx* c, const uint8_t* in, size_t n, uint8_t out[96]) {
+int h2agg_g1_sum(h2agg_ctx* c, const uint8_t* in, size_t n, uint8_t out[96]) try {
     TRY(bind(c));
     if (!out || (n && !in)) return fail(c, H2AGG_ERR_INVALID, "null buffer");
     TRY(ensure(c, c->in_a, 96 * n + 96));
@@ -796,10 +849,14 @@ int h2agg_g1_sum(h2agg_ctx* c, const uint8_t* in, size_t n, uint8_t out[96]) {
     hipLaunchKernelGGL(k_g1_sum, dim3(1), dim3(BLOCK), 0, c->stream, (const uint8_t*)c->in_a.p, n, c->d_res_jac,
                        c->d_flags);
     return fetch_result_jac(c, out);
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
 // ---------------------------------------------------------------- base tables
-int h2agg_bases_upload(h2agg_ctx* c, const uint8_t* bases, size_t n, uint64_t* handle_out) {
+int h2agg_bases_upload(h2agg_ctx* c, const uint8_t* bases, size_t n, uint64_t* handle_out) try {
     TRY(bind(c));
     if (!bases || !handle_out || n == 0) return fail(c, H2AGG_ERR_INVALID, "null buffer or n == 0");
     Table t;
@@ -824,9 +881,13 @@ int h2agg_bases_upload(h2agg_ctx* c, const uint8_t* bases, size_t n, uint64_t* h
     c->tables[h] = t;
     *handle_out = h;
     return H2AGG_OK;
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
-int h2agg_bases_generate(h2agg_ctx* c, const void* d_k, size_t n, uint64_t* handle_out) {
+int h2agg_bases_generate(h2agg_ctx* c, const void* d_k, size_t n, uint64_t* handle_out) try {
     TRY(bind(c));
     if (!d_k || !handle_out || n == 0) return fail(c, H2AGG_ERR_INVALID, "null buffer or n == 0");
     Table t;
@@ -847,9 +908,13 @@ int h2agg_bases_generate(h2agg_ctx* c, const void* d_k, size_t n, uint64_t* hand
     c->tables[h] = t;
     *handle_out = h;
     return H2AGG_OK;
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
-int h2agg_bases_download(h2agg_ctx* c, uint64_t handle, size_t first, size_t n, uint8_t* out) {
+int h2agg_bases_download(h2agg_ctx* c, uint64_t handle, size_t first, size_t n, uint8_t* out) try {
     TRY(bind(c));
     auto it = c->tables.find(handle);
     if (it == c->tables.end()) return fail(c, H2AGG_ERR_INVALID, "unknown base-table handle");
@@ -861,9 +926,13 @@ int h2agg_bases_download(h2agg_ctx* c, uint64_t handle, size_t first, size_t n, 
     HIP_TRY(c, hipMemcpyAsync(out, c->out.p, 64 * n, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return H2AGG_OK;
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
-int h2agg_bases_free(h2agg_ctx* c, uint64_t handle) {
+int h2agg_bases_free(h2agg_ctx* c, uint64_t handle) try {
     TRY(bind(c));
     auto it = c->tables.find(handle);
     if (it == c->tables.end()) return fail(c, H2AGG_ERR_INVALID, "unknown base-table handle");
@@ -872,6 +941,10 @@ int h2agg_bases_free(h2agg_ctx* c, uint64_t handle) {
     if (it->second.endo_x) hipFree(it->second.endo_x);
     c->tables.erase(it);
     return H2AGG_OK;
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
 // ---------------------------------------------------------------- MSM
@@ -889,7 +962,7 @@ int table_endo(h2agg_ctx* c, Table& t, const uint8_t** out) {
 }
 }  // namespace
 extern "C" {
-int h2agg_g1_msm_device_async(h2agg_ctx* c, uint64_t handle, const void* d_scalars, size_t n, void* d_out_jac) {
+int h2agg_g1_msm_device_async(h2agg_ctx* c, uint64_t handle, const void* d_scalars, size_t n, void* d_out_jac) try {
     TRY(bind(c));
     auto it = c->tables.find(handle);
     if (it == c->tables.end()) return fail(c, H2AGG_ERR_INVALID, "unknown base-table handle");
@@ -899,10 +972,14 @@ int h2agg_g1_msm_device_async(h2agg_ctx* c, uint64_t handle, const void* d_scala
     const uint8_t* endo = nullptr;
     TRY(table_endo(c, it->second, &endo));
     return msm_run(c, it->second.d, (const uint8_t*)d_scalars, n, (uint8_t*)d_out_jac, 1, endo);
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
 int h2agg_g1_msm_device_batch_async(h2agg_ctx* c, uint64_t handle, const void* d_scalars, size_t n, size_t batch,
-                                    void* d_out_jac) {
+                                    void* d_out_jac) try {
     TRY(bind(c));
     auto it = c->tables.find(handle);
     if (it == c->tables.end()) return fail(c, H2AGG_ERR_INVALID, "unknown base-table handle");
@@ -928,18 +1005,26 @@ int h2agg_g1_msm_device_batch_async(h2agg_ctx* c, uint64_t handle, const void* d
                     endo));
     }
     return H2AGG_OK;
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
-int h2agg_g1_msm_device(h2agg_ctx* c, uint64_t handle, const void* d_scalars, size_t n, uint8_t out[96]) {
+int h2agg_g1_msm_device(h2agg_ctx* c, uint64_t handle, const void* d_scalars, size_t n, uint8_t out[96]) try {
     TRY(bind(c));
     if (!out) return fail(c, H2AGG_ERR_INVALID, "null buffer");
     set_identity_jac(out);
     TRY(clear_flags(c));
     TRY(h2agg_g1_msm_device_async(c, handle, d_scalars, n, c->d_res_jac));
     return fetch_result_jac(c, out);
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
-int h2agg_g1_msm_preloaded(h2agg_ctx* c, uint64_t handle, const uint8_t* scalars, size_t n, uint8_t out[96]) {
+int h2agg_g1_msm_preloaded(h2agg_ctx* c, uint64_t handle, const uint8_t* scalars, size_t n, uint8_t out[96]) try {
     TRY(bind(c));
     if (!out) return fail(c, H2AGG_ERR_INVALID, "null buffer");
     set_identity_jac(out);
@@ -948,11 +1033,15 @@ int h2agg_g1_msm_preloaded(h2agg_ctx* c, uint64_t handle, const uint8_t* scalars
     TRY(ensure(c, c->in_b, 32 * n));
     HIP_TRY(c, hipMemcpyAsync(c->in_b.p, scalars, 32 * n, hipMemcpyHostToDevice, c->stream));
     return h2agg_g1_msm_device(c, handle, c->in_b.p, n, out);
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
 // assign_instance_commitment for one instance column (verify.rs:601-603, 623-639)
 int h2agg_instance_commitment(h2agg_ctx* c, uint64_t g_lagrange_handle, const uint8_t* instance, size_t len,
-                              size_t max_len, uint8_t out_jac[96]) {
+                              size_t max_len, uint8_t out_jac[96]) try {
     TRY(bind(c));
     if (!out_jac) return fail(c, H2AGG_ERR_INVALID, "null buffer");
     set_identity_jac(out_jac);
@@ -960,22 +1049,34 @@ int h2agg_instance_commitment(h2agg_ctx* c, uint64_t g_lagrange_handle, const ui
         return fail(c, H2AGG_ERR_INVALID, "assert!(instance.len() <= params.n() - (blinding_factors + 1)) failed (verify.rs:601-603)");
     if (len == 0) return H2AGG_OK;  // None => pchip.assign_const(identity)  (verify.rs:638)
     return h2agg_g1_msm_preloaded(c, g_lagrange_handle, instance, len, out_jac);
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
-int h2agg_host_alloc(h2agg_ctx* c, size_t bytes, void** out) {
+int h2agg_host_alloc(h2agg_ctx* c, size_t bytes, void** out) try {
     TRY(bind(c));
     if (!out || bytes == 0) return fail(c, H2AGG_ERR_INVALID, "null out or zero size");
     hipError_t e = hipHostMalloc(out, bytes, hipHostMallocDefault);
     if (e != hipSuccess) return fail(c, H2AGG_ERR_NOMEM, std::string("hipHostMalloc: ") + hipGetErrorString(e));
     return H2AGG_OK;
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
-int h2agg_host_free(h2agg_ctx* c, void* p) {
+int h2agg_host_free(h2agg_ctx* c, void* p) try {
     TRY(bind(c));
     if (p) HIP_TRY(c, hipHostFree(p));
     return H2AGG_OK;
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
-int h2agg_g1_msm(h2agg_ctx* c, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[96]) {
+int h2agg_g1_msm(h2agg_ctx* c, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[96]) try {
     TRY(bind(c));
     if (!out) return fail(c, H2AGG_ERR_INVALID, "null buffer");
     set_identity_jac(out);
@@ -1039,10 +1140,14 @@ int h2agg_g1_msm(h2agg_ctx* c, const uint8_t* bases, const uint8_t* scalars, siz
     TRY(join_tails(c));
     hipLaunchKernelGGL(k_g1_sum, dim3(1), dim3(BLOCK), 0, c->stream, (const uint8_t*)c->out.p, k, c->d_res_jac, c->d_flags);
     return fetch_result_jac(c, out);
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
 int h2agg_eval_flat(h2agg_ctx* c, const uint8_t* pts, const uint8_t* scalars, const uint8_t* has_scalar, size_t n,
-                    uint8_t out[96]) {
+                    uint8_t out[96]) try {
     TRY(bind(c));
     if (!out) return fail(c, H2AGG_ERR_INVALID, "null buffer");
     set_identity_jac(out);
@@ -1076,10 +1181,14 @@ int h2agg_eval_flat(h2agg_ctx* c, const uint8_t* pts, const uint8_t* scalars, co
     hipLaunchKernelGGL(k_eval_tail, dim3(1), dim3(BLOCK), 0, c->stream, (const uint8_t*)c->d_res_xyzz,
                        (const uint8_t*)c->in_c.p, k, c->d_res_jac, c->d_flags);
     return fetch_result_jac(c, out);
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
 // ---------------------------------------------------------------- tuning / measurement
-int h2agg_msm_configure(h2agg_ctx* c, int window_bits, int reduce_segment, int big_bucket_threshold) {
+int h2agg_msm_configure(h2agg_ctx* c, int window_bits, int reduce_segment, int big_bucket_threshold) try {
     if (!c) return H2AGG_ERR_INVALID;
     if (window_bits != 0 && (window_bits < 2 || window_bits > 16))
         return fail(c, H2AGG_ERR_INVALID, "window_bits must be 0 or in [2, 16]");
@@ -1090,23 +1199,35 @@ int h2agg_msm_configure(h2agg_ctx* c, int window_bits, int reduce_segment, int b
     c->cfg_seg = reduce_segment;
     c->cfg_big = big_bucket_threshold;
     return H2AGG_OK;
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
-int h2agg_msm_configure_glv(h2agg_ctx* c, int mode) {
+int h2agg_msm_configure_glv(h2agg_ctx* c, int mode) try {
     if (!c) return H2AGG_ERR_INVALID;
     if (mode < -1 || mode > 1) return fail(c, H2AGG_ERR_INVALID, "mode must be -1 (off), 0 (auto) or 1 (on)");
     c->cfg_glv = mode;
     return H2AGG_OK;
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
-int h2agg_msm_configure_lanes_per_bucket(h2agg_ctx* c, int lanes) {
+int h2agg_msm_configure_lanes_per_bucket(h2agg_ctx* c, int lanes) try {
     if (!c) return H2AGG_ERR_INVALID;
     if (lanes != 0 && lanes != 1 && lanes != 2 && lanes != 4 && lanes != 8 && lanes != 16)
         return fail(c, H2AGG_ERR_INVALID, "lanes must be 0, 1, 2, 4, 8 or 16");
     c->cfg_lpb = lanes;
     return H2AGG_OK;
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
-int h2agg_msm_configure_sort(h2agg_ctx* c, int sub_bits, int tile) {
+int h2agg_msm_configure_sort(h2agg_ctx* c, int sub_bits, int tile) try {
     if (!c) return H2AGG_ERR_INVALID;
     if (sub_bits != 0 && (sub_bits < 4 || sub_bits > SORT_MAX_SUB_BITS))
         return fail(c, H2AGG_ERR_INVALID, "sub_bits must be 0 or in [4, 12]");
@@ -1117,18 +1238,26 @@ int h2agg_msm_configure_sort(h2agg_ctx* c, int sub_bits, int tile) {
     c->cfg_stage_l1 = tile == -2;   // -2: also stage level 1 through LDS (experiment: slower, kept for tests)
     c->cfg_tile = tile > 0 ? tile : 0;
     return H2AGG_OK;
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
-int h2agg_msm_set_tail_overlap(h2agg_ctx* c, int enable) {
+int h2agg_msm_set_tail_overlap(h2agg_ctx* c, int enable) try {
     TRY(bind(c));
     TRY(join_tails(c));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->tail_overlap = enable != 0;
     if (enable == 1 || enable == 2) c->overlap_level = enable;
     return H2AGG_OK;
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
-int h2agg_profile_enable(h2agg_ctx* c, int enable) {
+int h2agg_profile_enable(h2agg_ctx* c, int enable) try {
     TRY(bind(c));
     if (enable && !c->prof_events_created) {
         for (int r = 0; r < h2agg_ctx::PROF_RING; ++r)
@@ -1140,8 +1269,12 @@ int h2agg_profile_enable(h2agg_ctx* c, int enable) {
     c->profiling = enable != 0;
     c->prof_only = (enable >= 2 && enable - 2 < ST_N) ? enable - 2 : -1;
     return H2AGG_OK;
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
-int h2agg_profile_reset(h2agg_ctx* c) {
+int h2agg_profile_reset(h2agg_ctx* c) try {
     if (!c) return H2AGG_ERR_INVALID;
     profile_harvest_all(c);
     for (int s = 0; s < ST_N; ++s) {
@@ -1149,15 +1282,23 @@ int h2agg_profile_reset(h2agg_ctx* c) {
         c->stage_launches[s] = 0;
     }
     return H2AGG_OK;
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 int h2agg_profile_stage_count(h2agg_ctx*) { return ST_N; }
 const char* h2agg_profile_stage_name(h2agg_ctx*, int i) { return (i >= 0 && i < ST_N) ? STAGE_NAMES[i] : ""; }
-int h2agg_profile_stage_get(h2agg_ctx* c, int i, double* total_ms, uint64_t* launches) {
+int h2agg_profile_stage_get(h2agg_ctx* c, int i, double* total_ms, uint64_t* launches) try {
     if (!c || i < 0 || i >= ST_N) return H2AGG_ERR_INVALID;
     profile_harvest_all(c);
     if (total_ms) *total_ms = c->stage_ms[i];
     if (launches) *launches = c->stage_launches[i];
     return H2AGG_OK;
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
 }
 
 }  // extern "C"
