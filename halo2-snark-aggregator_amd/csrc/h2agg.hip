@@ -201,7 +201,7 @@ MsmPlan make_plan(const h2agg_ctx* c, size_t n, uint32_t batch = 1) {
     // (short segments = short chains; when the tail is hidden under the next MSM's bulk its WORK is what costs, and the
     // double-and-add by the segment offset — as much work as 8 buckets of running sums — amortises over longer segments)
     uint32_t seg = c->cfg_seg ? (uint32_t)c->cfg_seg
-                              : (p.NBT >= (1u << 18) ? (c->tail_overlap && n >= ((size_t)1 << 20) ? 32u : 8u)
+                              : (p.NBT >= (1u << 18) ? (c->tail_overlap && p.NBT >= (1u << 19) ? 32u : 8u)
                                                      : (p.NBT >= (1u << 15) ? 4u : 2u));
     if (seg > p.NB) seg = p.NB;
     p.seg = seg;
