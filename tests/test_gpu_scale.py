@@ -178,10 +178,12 @@ def test_msm_2p20_against_cpu_pippenger(eng):
         eng.bases_free(table)
 
 
-@pytest.mark.parametrize("n,batch,glv", [(3000, 5, 0), (1 << 15, 3, 0), (1 << 15, 3, -1), (77, 20, 0), (1 << 17, 6, 0)])
+@pytest.mark.parametrize("n,batch,glv", [(3000, 5, 0), (1 << 15, 3, 0), (1 << 15, 3, -1), (77, 20, 0), (1 << 17, 6, 0),
+                                          (1 << 15, 19, 0), (1 << 14, 70, -1)])
 def test_msm_batch_over_one_table(eng, n, batch, glv):
     """h2agg_g1_msm_device_batch_async: `batch` MSMs over the same bases in one set of launches must each equal
-    the single MSM (and (sum k_i s_i) * G); covers chunking (6 x 2^17 is split) and both scalar recodings."""
+    the single MSM (and (sum k_i s_i) * G); covers chunking (19 x 2^15 and 70 x 2^14 are split into several sets of
+    launches) and both scalar recodings."""
     dev = torch.device("cuda", 0)
     ks, k_np = _workload(n, 11)
     d_k = torch.from_numpy(k_np.copy()).to(dev)
