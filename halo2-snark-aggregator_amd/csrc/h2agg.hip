@@ -971,7 +971,30 @@ int h2agg_g1_msm_device_async(h2agg_ctx* c, uint64_t handle, const void* d_scala
     if (n > it->second.n) return fail(c, H2AGG_ERR_INVALID, "more scalars than bases in the table");
     const uint8_t* endo = nullptr;
     TRY(table_endo(c, it->second, &endo));
-    return msm_run(c, it->second.d, (const uint8_t*)d_scalars, n, (uint8_t*)d_out_jac, 1, endo);
+    // Beyond 2^22 points the packed (index | sub-bucket) sort item no longer fits 32 bits and the sort would fall back to
+    // its slower two-array kernels: cut the MSM into slices of <= 2^22 points instead (their tails overlap the next
+    // slice's bulk) and add the slices' results.
+    const size_t SLICE = (size_t)1 << 22;
+    if (n <= SLICE) return msm_run(c, it->second.d, (const uint8_t*)d_scalars, n, (uint8_t*)d_out_jac, 1, endo);
+    const size_t nsl = (n + SLICE - 1) / SLICE;
+    TRY(ensure(c, c->out, 96 * nsl));
+    const bool was_overlap = c->tail_overlap;
+    const int was_level = c->overlap_level;
+    c->tail_overlap = true;
+    c->overlap_level = 2;
+    int rc = H2AGG_OK;
+    for (size_t k = 0; k < nsl && rc == H2AGG_OK; ++k) {
+        const size_t off = k * SLICE, m = n - off < SLICE ? n - off : SLICE;
+        rc = msm_run(c, it->second.d + 64 * off, (const uint8_t*)d_scalars + 32 * off, m, (uint8_t*)c->out.p + 96 * k, 1,
+                     endo + 32 * off);
+    }
+    c->tail_overlap = was_overlap;
+    c->overlap_level = was_level;
+    TRY(rc);
+    TRY(join_tails(c));
+    hipLaunchKernelGGL(k_g1_sum, dim3(1), dim3(BLOCK), 0, c->stream, (const uint8_t*)c->out.p, nsl, (uint8_t*)d_out_jac,
+                       c->d_flags);
+    return H2AGG_OK;
 } catch (const std::bad_alloc&) {
     return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
 } catch (...) {
