@@ -55,7 +55,7 @@ struct h2agg_ctx {
     // grow-only device workspace
     DevBuf in_a, in_b, in_c, out, tmp_bases;                      // host-buffer entry points
     DevBuf hist, offs, pmeta, item_idx, item_sub, order, entries, buckets, segsum, wsum, big_list, big_keys, big_part,
-        glv_buf, parts, small, endo_buf;  // MSM
+        glv_buf, parts, small, endo_buf, tile_counts;  // MSM
     uint32_t* d_flags = nullptr;      // in `small`: [0] status flags, [1] big_count
     uint8_t* d_res_xyzz = nullptr;    // in `small` + 1024 + 144 * slot of the LAST msm_run (see msm_run)
     uint8_t* d_res_jac = nullptr;     // in `small` + 256
@@ -354,6 +354,12 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     uint32_t* big_count = c->d_flags + 2;   // [0] chunk slots, [1] multi-chunk buckets
     hipStream_t st = c->stream;
     const unsigned ntiles = (unsigned)((n + sp.tile - 1) / sp.tile);
+    // per-tile partition counts from the counting pass, read back by the packed scatter pass (same tiles)
+    uint32_t* tile_counts = nullptr;
+    if (staged && !c->cfg_stage_l1) {
+        TRY(ensure(c, c->tile_counts, (size_t)ntiles * sp.PW * 4));
+        tile_counts = (uint32_t*)c->tile_counts.p;
+    }
     profile_begin_call(c);
 
     if (p.glv && !d_endo_x) {
@@ -374,7 +380,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         HIP_TRY(c, hipMemsetAsync(meta, 0, 12288 * 4, st));
         HIP_TRY(c, hipMemsetAsync(big_count, 0, 8, st));
         hipLaunchKernelGGL(k_part_count, dim3(ntiles), dim3(BLOCK), 0, st, d_scalars, n, p.c, W1, sp, pcount,
-                           c->d_flags);
+                           c->d_flags, tile_counts);
         hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(BLOCK), 0, st, pcount, sp.PW, pstart, pcursor);
     }
     if (staged) {
@@ -395,7 +401,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
                                    sp, idx_bits, pcursor, item_idx);
             else
                 hipLaunchKernelGGL(k_part_scatter_packed, dim3(ntiles), dim3(BLOCK), 0, st, d_scalars, n, p.c, W1, sp,
-                                   idx_bits, pcursor, item_idx);
+                                   idx_bits, pcursor, item_idx, (const uint32_t*)tile_counts);
         }
         {
             StageTimer t(c, ST_BUCKET_SORT);
@@ -584,7 +590,7 @@ void h2agg_destroy(h2agg_ctx* c) {
         if (c->tail_streams[k]) hipStreamSynchronize(c->tail_streams[k]);
     DevBuf* bufs[] = {&c->in_a,  &c->in_b,     &c->in_c,     &c->out,   &c->tmp_bases, &c->hist,
                       &c->offs,  &c->pmeta,    &c->item_idx, &c->item_sub, &c->order,  &c->entries,
-                      &c->buckets, &c->segsum, &c->wsum,     &c->big_list, &c->big_keys, &c->big_part, &c->glv_buf, &c->parts, &c->small, &c->endo_buf,
+                      &c->buckets, &c->segsum, &c->wsum,     &c->big_list, &c->big_keys, &c->big_part, &c->glv_buf, &c->parts, &c->small, &c->endo_buf, &c->tile_counts,
                       &c->sch_regs, &c->sch_in, &c->sch_scalars[0], &c->sch_scalars[1], &c->sch_bases[0], &c->sch_bases[1]};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);

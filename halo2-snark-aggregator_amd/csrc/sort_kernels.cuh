@@ -249,8 +249,11 @@ constexpr uint32_t ENT_IDX = 0x3fffffffu;
     }
 
 // ------------------------------------------------------------------ level 1
+// tile_counts (optional): this tile's count of every partition, [tile][PW] — the scatter pass of the same tile reads it
+// back instead of recoding its scalars a second time just to count
 __global__ void __launch_bounds__(BLOCK) k_part_count(const uint8_t* __restrict__ scalars, size_t n, int c, int W,
-                                                      SortPlan sp, uint32_t* __restrict__ pcount, uint32_t* flags) {
+                                                      SortPlan sp, uint32_t* __restrict__ pcount, uint32_t* flags,
+                                                      uint32_t* __restrict__ tile_counts) {
     __shared__ uint32_t cnt[SORT_MAX_PW];
     for (uint32_t p = threadIdx.x; p < sp.PW; p += BLOCK) cnt[p] = 0;
     __syncthreads();
@@ -267,6 +270,7 @@ __global__ void __launch_bounds__(BLOCK) k_part_count(const uint8_t* __restrict_
     for (uint32_t p = threadIdx.x; p < sp.PW; p += BLOCK) {
         const uint32_t v = cnt[p];
         if (v) atomicAdd(&pcount[p], v);
+        if (tile_counts) tile_counts[(size_t)blockIdx.x * sp.PW + p] = v;
     }
 }
 
@@ -488,22 +492,31 @@ __global__ void __launch_bounds__(BLOCK) k_part_scatter_staged(const uint8_t* __
 __global__ void __launch_bounds__(BLOCK) k_part_scatter_packed(const uint8_t* __restrict__ scalars, size_t n, int c,
                                                                int W, SortPlan sp, int idx_bits,
                                                                uint32_t* __restrict__ pcursor,
-                                                               uint32_t* __restrict__ items) {
+                                                               uint32_t* __restrict__ items,
+                                                               const uint32_t* __restrict__ tile_counts) {
     __shared__ uint32_t cnt[SORT_MAX_PW];
     __shared__ uint32_t basep[SORT_MAX_PW];
-    for (uint32_t p = threadIdx.x; p < sp.PW; p += BLOCK) cnt[p] = 0;
-    __syncthreads();
     const size_t base = (size_t)blockIdx.x * sp.tile;
-    TILE_SCALARS_BEGIN(threadIdx.x)
-        msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool, bool) {
-            atomicAdd(&cnt[((uint32_t)w + wofs) * sp.ppw + (b >> sp.sub_bits)], 1u);
-        });
-    TILE_SCALARS_END
-    __syncthreads();
-    for (uint32_t p = threadIdx.x; p < sp.PW; p += BLOCK) {
-        const uint32_t v = cnt[p];
-        basep[p] = v ? atomicAdd(&pcursor[p], v) : 0u;
-        cnt[p] = 0;
+    if (tile_counts) {   // counted by k_part_count over the same tile: one global reservation per non-empty partition
+        for (uint32_t p = threadIdx.x; p < sp.PW; p += BLOCK) {
+            const uint32_t v = tile_counts[(size_t)blockIdx.x * sp.PW + p];
+            basep[p] = v ? atomicAdd(&pcursor[p], v) : 0u;
+            cnt[p] = 0;
+        }
+    } else {
+        for (uint32_t p = threadIdx.x; p < sp.PW; p += BLOCK) cnt[p] = 0;
+        __syncthreads();
+        TILE_SCALARS_BEGIN(threadIdx.x)
+            msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool, bool) {
+                atomicAdd(&cnt[((uint32_t)w + wofs) * sp.ppw + (b >> sp.sub_bits)], 1u);
+            });
+        TILE_SCALARS_END
+        __syncthreads();
+        for (uint32_t p = threadIdx.x; p < sp.PW; p += BLOCK) {
+            const uint32_t v = cnt[p];
+            basep[p] = v ? atomicAdd(&pcursor[p], v) : 0u;
+            cnt[p] = 0;
+        }
     }
     __syncthreads();
     const uint32_t submask = sp.SB - 1u;
