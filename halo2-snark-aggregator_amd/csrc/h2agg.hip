@@ -307,17 +307,20 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     const int idx_bits = (p.glv ? 30 : 31) - sp.sub_bits;   // packed item: sub | neg | (endo) | idx
     bool staged = !c->cfg_no_stage && n_base <= ((size_t)1 << idx_bits);   // items carry the BASE index
     const size_t keys_per_scalar = (size_t)W1 * (p.glv ? 2 : 1);
-    if (staged && c->cfg_stage_l1 && (size_t)sp.tile * keys_per_scalar > (size_t)STAGE_ITEMS)
-        sp.tile = (uint32_t)(STAGE_ITEMS / keys_per_scalar);
+    if (staged && c->cfg_stage_l1 && (size_t)sp.tile * keys_per_scalar > (size_t)STAGE_ITEMS_L1)
+        sp.tile = (uint32_t)(STAGE_ITEMS_L1 / keys_per_scalar);
     if (staged && sp.tile < (uint32_t)BLOCK) staged = false;
     if (sp.PW > (uint32_t)SORT_MAX_PW) return fail(c, H2AGG_ERR_INVALID, "too many sort partitions");
     const uint32_t nseg_total = WT * p.spw;
     // 4 lanes per chain in the bucket reduction / window sums (latency) or 1 (least work): see msm_kernels.cuh
     static const int par4_env = getenv("H2AGG_PAR4") ? atoi(getenv("H2AGG_PAR4")) : 0;
     const bool par4 = par4_env ? par4_env > 0 : nseg_total <= 16384;   // measured: wins up to c = 13, loses (extra work) above
-    // pmeta words: [0,PW] pcount | [2048, +PW+1] pstart | [4096, +PW] pcursor | [6144,+1024] bin_count |
-    //              [8192,+1025] bin_start | [10240,+1024] bin_cursor
-    TRY(ensure(c, c->pmeta, 12288 * 4));
+    // pmeta words: pcount [PW] | pstart [PW + 1] | pcursor [PW] | bin_count [SIZE_BINS] | bin_start [SIZE_BINS + 1] |
+    //              bin_cursor [SIZE_BINS], each padded by 64 words
+    constexpr uint32_t M_PSTART = SORT_MAX_PW + 64, M_PCURSOR = M_PSTART + SORT_MAX_PW + 64,
+                       M_BCOUNT = M_PCURSOR + SORT_MAX_PW + 64, M_BSTART = M_BCOUNT + SIZE_BINS + 64,
+                       M_BCURSOR = M_BSTART + SIZE_BINS + 64, M_WORDS = M_BCURSOR + SIZE_BINS + 64;
+    TRY(ensure(c, c->pmeta, M_WORDS * 4));
     TRY(ensure(c, c->hist, (size_t)p.NBT * 4));
     TRY(ensure(c, c->offs, (size_t)p.NBT * 4));
     TRY(ensure(c, c->order, (size_t)p.NBT * 4));
@@ -335,8 +338,8 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     TRY(ensure(c, c->big_keys, max_keys * 12));
     TRY(ensure(c, c->big_part, max_slots * XYZZ_BYTES));
     uint32_t* meta = (uint32_t*)c->pmeta.p;
-    uint32_t *pcount = meta, *pstart = meta + 2048, *pcursor = meta + 4096;
-    uint32_t *bin_count = meta + 6144, *bin_start = meta + 8192, *bin_cursor = meta + 10240;
+    uint32_t *pcount = meta, *pstart = meta + M_PSTART, *pcursor = meta + M_PCURSOR;
+    uint32_t *bin_count = meta + M_BCOUNT, *bin_start = meta + M_BSTART, *bin_cursor = meta + M_BCURSOR;
     uint32_t* hist = (uint32_t*)c->hist.p;
     uint32_t* offs = (uint32_t*)c->offs.p;
     uint32_t* order = (uint32_t*)c->order.p;
@@ -377,7 +380,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     }
     {
         StageTimer t(c, ST_PART_COUNT);
-        HIP_TRY(c, hipMemsetAsync(meta, 0, 12288 * 4, st));
+        HIP_TRY(c, hipMemsetAsync(meta, 0, M_WORDS * 4, st));
         HIP_TRY(c, hipMemsetAsync(big_count, 0, 8, st));
         hipLaunchKernelGGL(k_part_count, dim3(ntiles), dim3(BLOCK), 0, st, d_scalars, n, p.c, W1, sp, pcount,
                            c->d_flags, tile_counts);
@@ -385,7 +388,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     }
     if (staged) {
         // LDS-staged sort: keys leave the CU as contiguous runs (n fits the packed item's index field)
-        const size_t lds1 = (size_t)(4 * SORT_MAX_PW + STAGE_ITEMS) * 4;
+        const size_t lds1 = (size_t)(4 * SORT_MAX_PW + STAGE_ITEMS_L1) * 4;
         const size_t lds2 = (size_t)(SORT_MAX_SB + BLOCK + STAGE_ITEMS) * 4;
         if (!c->staged_attr_set) {
             HIP_TRY(c, hipFuncSetAttribute((const void*)k_part_scatter_staged,

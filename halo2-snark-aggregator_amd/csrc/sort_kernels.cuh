@@ -20,7 +20,7 @@
 
 namespace h2agg {
 
-constexpr int SORT_MAX_PW = 1024;   // partitions (LDS counters in level 1)
+constexpr int SORT_MAX_PW = 2048;   // partitions (LDS counters in level 1)
 constexpr int SORT_SUB_BITS = 9;    // default low bucket bits resolved in level 2 (tunable, <= 12; sweep: profiles/r01_sweeps.txt)
 constexpr int SORT_MAX_SUB_BITS = 12;
 constexpr int SORT_MAX_SB = 1 << SORT_MAX_SUB_BITS;
@@ -414,6 +414,7 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_sort(const uint32_t* __restric
 // first ordered in LDS and then leave the CU as contiguous runs written by consecutive lanes.
 // Item = sub-bucket | negative | endo (GLV only) | point index, packed from the top; see pack_item().
 constexpr int STAGE_ITEMS = 32768;  // 128 KiB of LDS
+constexpr int STAGE_ITEMS_L1 = 24576;  // level-1 staging shares the LDS with 4 x SORT_MAX_PW counters
 
 __global__ void __launch_bounds__(BLOCK) k_part_scatter_staged(const uint8_t* __restrict__ scalars, size_t n, int c,
                                                                int W, SortPlan sp, int idx_bits,
