@@ -260,3 +260,39 @@ def test_host_buffer_msm_sliced_pipeline(eng):
             eng.host_free(ps)
     finally:
         eng.bases_free(table)
+
+
+def test_throughput_mode_paths(eng):
+    """Overlap (throughput) mode switches a large MSM to plain recoding, 32-bucket segments and the hierarchical bucket
+    reduction (k_msm_reduce_segments2 / k_msm_window_sum2), with tails on the side streams: several MSMs queued back
+    to back, and a 16-MSM batch, must give the same points as the default mode."""
+    n = 1 << 20
+    dev = torch.device("cuda", 0)
+    ks, k_np = _workload(n, 41)
+    d_k = torch.from_numpy(k_np.copy()).to(dev)
+    table = eng.bases_generate(d_k.data_ptr(), n)
+    try:
+        scal = [_workload(n, 50 + i) for i in range(3)]
+        d_s = [torch.from_numpy(a.copy()).to(dev) for _v, a in scal]
+        want = [eng.g1_batch_to_affine(eng.g1_msm_device(table, d.data_ptr(), n)) for d in d_s]
+        t0 = sum(k * s for k, s in zip(ks, scal[0][0])) % O.R
+        assert want[0] == O.aff_to_bytes(O.scalar_mul(t0, O.G1))
+        d_out = torch.zeros((3, 96), dtype=torch.uint8, device=dev)
+        eng._check(eng._lib.h2agg_msm_set_tail_overlap(eng._ctx, 2))
+        try:
+            for rep in range(2):
+                for i, d in enumerate(d_s):
+                    eng.g1_msm_device_async(table, d.data_ptr(), n, d_out[i].data_ptr())
+                eng.synchronize()
+                assert eng.g1_batch_to_affine_device(d_out.data_ptr(), 3) == b"".join(want)
+            m, B = (1 << 17) - 6, 16
+            d_b = torch.from_numpy(np.stack([_workload(m, 70 + q)[1] for q in range(B)]).copy()).to(dev)
+            d_bo = torch.zeros((B, 96), dtype=torch.uint8, device=dev)
+            eng.g1_msm_device_batch_async(table, d_b.data_ptr(), m, B, d_bo.data_ptr())
+            got = eng.g1_batch_to_affine_device(d_bo.data_ptr(), B)
+        finally:
+            eng._check(eng._lib.h2agg_msm_set_tail_overlap(eng._ctx, 0))
+        for q in range(B):
+            assert got[64 * q:64 * q + 64] == eng.g1_batch_to_affine(eng.g1_msm_device(table, d_b[q].data_ptr(), m)), q
+    finally:
+        eng.bases_free(table)
