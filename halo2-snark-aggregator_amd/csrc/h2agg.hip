@@ -314,10 +314,9 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     const uint32_t nseg_total = WT * p.spw;
     // 4 lanes per chain in the bucket reduction / window sums (latency) or 1 (least work): see msm_kernels.cuh
     static const int par4_env = getenv("H2AGG_PAR4") ? atoi(getenv("H2AGG_PAR4")) : 0;
-    const bool par4 = par4_env ? par4_env > 0 : nseg_total <= 16384;   // measured: wins up to c = 13, loses (extra work) above
-    static const int hier_env = getenv("H2AGG_HIER") ? atoi(getenv("H2AGG_HIER")) : 0;
-    // hierarchical reduction (msm_kernels.cuh): least work, longest chain — only where the tail is hidden under a bulk
-    const bool hier = !par4 && (hier_env ? hier_env > 0 : (c->tail_overlap && p.NBT >= (1u << 19)));
+    // measured: wins up to 16384 segments (c <= 13; also a 2^20-point MSM with 32-bucket segments in throughput mode,
+    // where 1 024 waves of 94-addition chains would otherwise outlast the step), loses to the extra work above
+    const bool par4 = par4_env ? par4_env > 0 : nseg_total <= 16384;
     // pmeta words: pcount [PW] | pstart [PW + 1] | pcursor [PW] | bin_count [SIZE_BINS] | bin_start [SIZE_BINS + 1] |
     //              bin_cursor [SIZE_BINS], each padded by 64 words
     constexpr uint32_t M_PSTART = SORT_MAX_PW + 64, M_PCURSOR = M_PSTART + SORT_MAX_PW + 64,
@@ -333,7 +332,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     // buckets / segsum / wsum are double-buffered: in overlap mode the reduction of MSM k (tail stream)
     // runs while MSM k+1 fills the other set
     TRY(ensure(c, c->buckets, h2agg_ctx::TAIL_SLOTS * (size_t)p.NBT * XYZZ_BYTES));
-    TRY(ensure(c, c->segsum, h2agg_ctx::TAIL_SLOTS * (size_t)nseg_total * 2 * XYZZ_BYTES));   // (acc, run) per segment
+    TRY(ensure(c, c->segsum, h2agg_ctx::TAIL_SLOTS * (size_t)nseg_total * XYZZ_BYTES));
     TRY(ensure(c, c->wsum, h2agg_ctx::TAIL_SLOTS * (size_t)WT * XYZZ_BYTES));
     const size_t max_slots = nent / BIG_CHUNK + nent / ((size_t)p.big + 1) + 2;   // chunks of over-long buckets
     const size_t max_keys = nent / ((size_t)p.big + 1) + 2;
@@ -352,7 +351,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     const int par = c->parity;
     c->d_res_xyzz = (uint8_t*)c->small.p + 1024 + 144 * par;   // each tail slot has its own XYZZ result
     uint8_t* buckets = (uint8_t*)c->buckets.p + (size_t)par * p.NBT * XYZZ_BYTES;
-    uint8_t* segsum = (uint8_t*)c->segsum.p + (size_t)par * nseg_total * 2 * XYZZ_BYTES;
+    uint8_t* segsum = (uint8_t*)c->segsum.p + (size_t)par * nseg_total * XYZZ_BYTES;
     uint8_t* wsum = (uint8_t*)c->wsum.p + (size_t)par * WT * XYZZ_BYTES;
     uint32_t* big_list = (uint32_t*)c->big_list.p;
     uint32_t* big_keys = (uint32_t*)c->big_keys.p;
@@ -486,9 +485,6 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         if (par4)
             hipLaunchKernelGGL(k_msm_reduce_segments_par4, dim3((4 * nseg_total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ts,
                                buckets, p.NB, p.seg, p.spw, nseg_total, segsum);
-        else if (hier)
-            hipLaunchKernelGGL(k_msm_reduce_segments2, dim3((nseg_total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ts, buckets,
-                               p.NB, p.seg, p.spw, nseg_total, segsum, segsum + (size_t)nseg_total * XYZZ_BYTES);
         else
             hipLaunchKernelGGL(k_msm_reduce_segments, dim3((nseg_total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ts, buckets,
                                p.NB, p.seg, p.spw, nseg_total, segsum);
@@ -497,9 +493,6 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         StageTimer t(c, ST_WINDOW_SUM, ts);
         if (par4)
             hipLaunchKernelGGL(k_msm_window_sum_par4, dim3(WT), dim3(PAR4_THREADS), 0, ts, segsum, p.spw, wsum);
-        else if (hier)
-            hipLaunchKernelGGL(k_msm_window_sum2, dim3(WT), dim3(BLOCK), 0, ts, segsum,
-                               segsum + (size_t)nseg_total * XYZZ_BYTES, p.spw, p.seg, wsum);
         else
             hipLaunchKernelGGL(k_msm_window_sum, dim3(WT), dim3(BLOCK), 0, ts, segsum, p.spw, wsum);
     }

@@ -215,81 +215,6 @@ __global__ void __launch_bounds__(BLOCK) k_msm_window_sum(const uint8_t* __restr
     if (threadIdx.x == 0) xyzz_store(wsum + XYZZ_BYTES * (size_t)w, tot);
 }
 
-// ---- hierarchical bucket reduction (no per-segment scalar multiplication) ---------------------------------------
-// sum_b (b + 1) B_b over a window, b = s * seg + j:   sum_s [ acc_s + (s * seg) * run_s ],   acc_s = sum_j (j + 1) B,
-// run_s = sum_j B.  k_msm_reduce_segments multiplies run_s by s * seg with a double-and-add per segment — as much work
-// as 8 buckets of running sums, and divergent.  Here level 1 only emits (acc_s, run_s); level 2 (one workgroup per
-// window) applies the same running-sum trick to the run_s themselves:  with s = t * q + i (thread t, q segments each)
-//     sum_s s * run_s = sum_t T_t + q * sum_t t * R_t,   T_t = sum_i i * run_(tq+i),   R_t = sum_i run_(tq+i),
-//     sum_t t * R_t   = sum_(t >= 1) Suf_t,               Suf_t = sum_(u >= t) R_u      (a suffix scan in LDS),
-// so the only multiplications left are by the powers of two seg and q: a handful of doublings per thread / per window.
-__global__ void __launch_bounds__(BLOCK) k_msm_reduce_segments2(const uint8_t* __restrict__ buckets, uint32_t NB,
-                                                                uint32_t seg, uint32_t spw, uint32_t total,
-                                                                uint8_t* __restrict__ segacc,
-                                                                uint8_t* __restrict__ segrun) {
-    const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
-    if (t >= total) return;
-    const uint32_t w = t / spw, sidx = t - w * spw;
-    const uint8_t* B = buckets + XYZZ_BYTES * ((size_t)w * NB + (size_t)sidx * seg);
-    G1XYZZ running = G1XYZZ::identity(), acc = G1XYZZ::identity();
-#pragma unroll 1
-    for (int j = (int)seg - 1; j >= 0; --j) {
-        running = xyzz_add(running, xyzz_load(B + XYZZ_BYTES * (size_t)j));
-        acc = xyzz_add(acc, running);
-    }
-    xyzz_store(segacc + XYZZ_BYTES * (size_t)t, acc);
-    xyzz_store(segrun + XYZZ_BYTES * (size_t)t, running);
-}
-// wsum[w] = sum_s acc_s + seg * sum_s s * run_s;  seg and spw are powers of two
-__global__ void __launch_bounds__(BLOCK) k_msm_window_sum2(const uint8_t* __restrict__ segacc,
-                                                           const uint8_t* __restrict__ segrun, uint32_t spw,
-                                                           uint32_t seg, uint8_t* __restrict__ wsum) {
-    __shared__ uint32_t lds[XYZZ_WORDS * BLOCK];
-    const uint32_t w = blockIdx.x, tid = threadIdx.x;
-    const uint32_t q = spw > (uint32_t)BLOCK ? spw / BLOCK : 1u;
-    const uint32_t base = tid * q;
-    const uint8_t* pa = segacc + XYZZ_BYTES * (size_t)w * spw;
-    const uint8_t* pr = segrun + XYZZ_BYTES * (size_t)w * spw;
-    G1XYZZ A = G1XYZZ::identity(), R = G1XYZZ::identity(), T = G1XYZZ::identity();
-    if (base < spw) {
-#pragma unroll 1
-        for (int i = (int)q - 1; i >= 0; --i) {
-            const size_t s = base + (uint32_t)i;
-            A = xyzz_add(A, xyzz_load(pa + XYZZ_BYTES * s));
-            R = xyzz_add(R, xyzz_load(pr + XYZZ_BYTES * s));
-            if (i > 0) T = xyzz_add(T, R);   // sum_i i * run_(base+i)
-        }
-    }
-    // X_t = A_t + seg * T_t
-#pragma unroll 1
-    for (uint32_t m = seg; m > 1; m >>= 1) T = xyzz_double(T);
-    G1XYZZ X = xyzz_add(A, T);
-    G1XYZZ s1 = block_sum_xyzz(X, lds);            // valid in thread 0
-    __syncthreads();
-    // inclusive suffix scan of R over the threads
-    lds_put_xyzz(lds, tid, R);
-    __syncthreads();
-#pragma unroll 1
-    for (uint32_t d = 1; d < (uint32_t)BLOCK; d <<= 1) {
-        G1XYZZ o = G1XYZZ::identity();
-        const bool has = tid + d < (uint32_t)BLOCK;
-        if (has) o = lds_get_xyzz(lds, tid + d);
-        __syncthreads();
-        if (has) {
-            R = xyzz_add(R, o);
-            lds_put_xyzz(lds, tid, R);
-        }
-        __syncthreads();
-    }
-    // Y = sum_(t >= 1) Suf_t
-    G1XYZZ y = block_sum_xyzz(tid == 0 ? G1XYZZ::identity() : R, lds);
-    if (tid == 0) {
-#pragma unroll 1
-        for (uint32_t m = seg * q; m > 1; m >>= 1) y = xyzz_double(y);
-        xyzz_store(wsum + XYZZ_BYTES * (size_t)w, xyzz_add(s1, y));
-    }
-}
-
 // ---- 4-lane cooperative doubling for the serial Horner tail --------------------------------------------
 // A doubling is 9 field products on one lane (~2 300 VALU instructions, nothing to overlap with).  Its
 // dependency graph is only three products deep:   {V = U^2, XX = X^2} -> {W = U*V, S = X*V, M^2, V*ZZ}

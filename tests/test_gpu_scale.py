@@ -263,9 +263,9 @@ def test_host_buffer_msm_sliced_pipeline(eng):
 
 
 def test_throughput_mode_paths(eng):
-    """Overlap (throughput) mode switches a large MSM to plain recoding, 32-bucket segments and the hierarchical bucket
-    reduction (k_msm_reduce_segments2 / k_msm_window_sum2), with tails on the side streams: several MSMs queued back
-    to back, and a 16-MSM batch, must give the same points as the default mode."""
+    """Overlap (throughput) mode switches a large MSM to plain recoding and 32-bucket segments reduced by the 4-lane
+    kernels, with tails on the side streams: several MSMs queued back to back, and a 16-MSM batch, must give the same
+    points as the default mode."""
     n = 1 << 20
     dev = torch.device("cuda", 0)
     ks, k_np = _workload(n, 41)
