@@ -263,7 +263,7 @@ def main():
     if args.sub_bits or args.tile:
         eng.msm_configure_sort(args.sub_bits, args.tile)
     if not args.no_overlap:
-        eng._check(eng._lib.h2agg_msm_set_tail_overlap(eng._ctx, args.overlap_level))   # serial Horner tail of MSM k runs under the bulk of MSM k+1
+        eng.msm_set_tail_overlap(args.overlap_level)   # serial Horner tail of MSM k runs under the bulk of MSM k+1
 
     n = 1 << args.log2n
     seed = 0x48324147

@@ -334,8 +334,9 @@ class H2Agg:
     def msm_configure_sort(self, sub_bits: int = 0, tile: int = 0):
         self._check(self._lib.h2agg_msm_configure_sort(self._ctx, sub_bits, tile))
 
-    def msm_set_tail_overlap(self, on: bool = True):
-        self._check(self._lib.h2agg_msm_set_tail_overlap(self._ctx, int(on)))
+    def msm_set_tail_overlap(self, level: int = 2):
+        """0 = off, 1 = only the Horner kernel on a tail stream, 2 = bucket reduction + window sums + Horner"""
+        self._check(self._lib.h2agg_msm_set_tail_overlap(self._ctx, int(level)))
 
     def profile_enable(self, on=True, only_stage: Optional[int] = None):
         """only_stage: index into profile_stages() order -> bracket just that stage (cheaper)."""

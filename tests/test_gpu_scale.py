@@ -278,7 +278,7 @@ def test_throughput_mode_paths(eng):
         t0 = sum(k * s for k, s in zip(ks, scal[0][0])) % O.R
         assert want[0] == O.aff_to_bytes(O.scalar_mul(t0, O.G1))
         d_out = torch.zeros((3, 96), dtype=torch.uint8, device=dev)
-        eng._check(eng._lib.h2agg_msm_set_tail_overlap(eng._ctx, 2))
+        eng.msm_set_tail_overlap(2)
         try:
             for rep in range(2):
                 for i, d in enumerate(d_s):
@@ -291,7 +291,7 @@ def test_throughput_mode_paths(eng):
             eng.g1_msm_device_batch_async(table, d_b.data_ptr(), m, B, d_bo.data_ptr())
             got = eng.g1_batch_to_affine_device(d_bo.data_ptr(), B)
         finally:
-            eng._check(eng._lib.h2agg_msm_set_tail_overlap(eng._ctx, 0))
+            eng.msm_set_tail_overlap(0)
         for q in range(B):
             assert got[64 * q:64 * q + 64] == eng.g1_batch_to_affine(eng.g1_msm_device(table, d_b[q].data_ptr(), m)), q
     finally:

@@ -10,7 +10,7 @@ ap = argparse.ArgumentParser(); ap.add_argument("--proofs", type=int, default=4)
 ap.add_argument("--reps", type=int, default=10); ap.add_argument("--overlap", type=int, default=2)
 args = ap.parse_args()
 pkg = entry.load_package(); eng = pkg.H2Agg(0)
-if args.overlap: eng._check(eng._lib.h2agg_msm_set_tail_overlap(eng._ctx, args.overlap))
+if args.overlap: eng.msm_set_tail_overlap(args.overlap)
 agg = importlib.import_module(entry.PKG_NAME + ".aggregate"); mo = importlib.import_module(entry.PKG_NAME + ".multiopen")
 rng = np.random.Generator(np.random.PCG64(1))
 fr = lambda: (int.from_bytes(rng.bytes(64), "little") % R_MOD).to_bytes(32, "little")

@@ -3,7 +3,7 @@ sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import numpy as np, torch
 import __graft_entry__ as entry
 pkg = entry.load_package(); eng = pkg.H2Agg(0)
-eng._check(eng._lib.h2agg_msm_set_tail_overlap(eng._ctx, 2))
+eng.msm_set_tail_overlap(2)
 dev = torch.device("cuda:0")
 n = (1 << 17) - 6
 k = torch.randint(0, 256, (1 << 17, 32), dtype=torch.uint8); k[:, 31] &= 0x1f

@@ -22,7 +22,7 @@ def main():
     eng = pkg.H2Agg(0)
     dev = torch.device("cuda:0")
     eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
-    eng._check(eng._lib.h2agg_msm_set_tail_overlap(eng._ctx, args.overlap))
+    eng.msm_set_tail_overlap(args.overlap)
     rng = np.random.Generator(np.random.PCG64(7))
     nmax = 1 << args.hi
     d_k = torch.from_numpy(rng.integers(0, 256, size=(nmax, 32), dtype=np.uint8)).to(dev)
