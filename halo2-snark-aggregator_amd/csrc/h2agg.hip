@@ -318,10 +318,10 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     // where 1 024 waves of 94-addition chains would otherwise outlast the step), loses to the extra work above
     const bool par4 = par4_env ? par4_env > 0 : nseg_total <= 16384;
     // pmeta words: pcount [PW] | pstart [PW + 1] | pcursor [PW] | bin_count [SIZE_BINS] | bin_start [SIZE_BINS + 1] |
-    //              bin_cursor [SIZE_BINS], each padded by 64 words
+    //              bin_cursor [SIZE_BINS] | big-bucket counters [2], each padded by 64 words
     constexpr uint32_t M_PSTART = SORT_MAX_PW + 64, M_PCURSOR = M_PSTART + SORT_MAX_PW + 64,
                        M_BCOUNT = M_PCURSOR + SORT_MAX_PW + 64, M_BSTART = M_BCOUNT + SIZE_BINS + 64,
-                       M_BCURSOR = M_BSTART + SIZE_BINS + 64, M_WORDS = M_BCURSOR + SIZE_BINS + 64;
+                       M_BCURSOR = M_BSTART + SIZE_BINS + 64, M_BIG = M_BCURSOR + SIZE_BINS + 64, M_WORDS = M_BIG + 64;
     TRY(ensure(c, c->pmeta, M_WORDS * 4));
     TRY(ensure(c, c->hist, (size_t)p.NBT * 4));
     TRY(ensure(c, c->offs, (size_t)p.NBT * 4));
@@ -356,7 +356,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     uint32_t* big_list = (uint32_t*)c->big_list.p;
     uint32_t* big_keys = (uint32_t*)c->big_keys.p;
     uint8_t* big_part = (uint8_t*)c->big_part.p;
-    uint32_t* big_count = c->d_flags + 2;   // [0] chunk slots, [1] multi-chunk buckets
+    uint32_t* big_count = meta + M_BIG;   // [0] chunk slots, [1] multi-chunk buckets (zeroed with the rest of meta)
     hipStream_t st = c->stream;
     const unsigned ntiles = (unsigned)((n + sp.tile - 1) / sp.tile);
     // per-tile partition counts from the counting pass, read back by the packed scatter pass (same tiles)
@@ -383,7 +383,6 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     {
         StageTimer t(c, ST_PART_COUNT);
         HIP_TRY(c, hipMemsetAsync(meta, 0, M_WORDS * 4, st));
-        HIP_TRY(c, hipMemsetAsync(big_count, 0, 8, st));
         hipLaunchKernelGGL(k_part_count, dim3(ntiles), dim3(BLOCK), 0, st, d_scalars, n, p.c, W1, sp, pcount,
                            c->d_flags, tile_counts);
         hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(BLOCK), 0, st, pcount, sp.PW, pstart, pcursor);
