@@ -424,7 +424,10 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
                                hist, offs, entries);
         }
     }
-    {
+    // ordering the buckets by length balances the lanes of a wave; with few entries the longest run bounds the kernel
+    // either way and the three launches (~25 us) are pure latency
+    const bool ordered = nent >= ((size_t)1 << 16);
+    if (ordered) {
         StageTimer t(c, ST_ORDER);
         unsigned g = (p.NBT + BLOCK * 8 - 1) / (BLOCK * 8);
         if (g > (unsigned)c->cu_count * 4) g = (unsigned)c->cu_count * 4;
@@ -453,7 +456,8 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     {
         StageTimer t(c, ST_ACCUM);
         hipLaunchKernelGGL(k_msm_accumulate, dim3((unsigned)(((size_t)p.NBT * lpb + BLOCK - 1) / BLOCK)), dim3(BLOCK), 0,
-                           st, d_bases, d_endo_x, entries, offs, hist, order, p.NBT, p.big, lpb, acc_out, big_list, big_keys,
+                           st, d_bases, d_endo_x, entries, offs, hist, ordered ? order : (uint32_t*)nullptr, p.NBT, p.big, lpb, acc_out,
+                           big_list, big_keys,
                            big_count);
     }
     {

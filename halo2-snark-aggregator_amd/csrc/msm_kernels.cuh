@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(BLOCK) k_msm_accumulate(const uint8_t* __restr
     // there are few buckets — GLV halves their number); the slices' partial sums go to buckets[key*lpb + part]
     // and are folded by k_msm_bucket_combine.
     const uint32_t part = t % lpb;
-    const uint32_t key = order[t / lpb];
+    const uint32_t key = order ? order[t / lpb] : t / lpb;   // (small MSMs skip the ordering pass)
     const uint32_t len = hist[key];
     if (len > big) {
         if (part != 0) return;
