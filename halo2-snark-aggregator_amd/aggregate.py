@@ -64,6 +64,35 @@ def local_weighted_proof(b, proofs: Sequence[MultiOpenProof], indices: Sequence[
     return acc
 
 
+def slice_bounds(n: int, world: int, rank: int):
+    """contiguous slice [lo, hi) of n points for this rank (the remainder goes to the first ranks)"""
+    q, r = divmod(n, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def msm_sliced(backend, bases_aff: bytes, scalars: bytes, dist=None, device=None) -> bytes:
+    """One multi_exp split across the ranks by POINTS (second grain): rank r runs a full Pippenger on
+    its contiguous slice of (bases, scalars), the 64-byte partial results are all-gathered and every rank adds them —
+    no other communication.  `bases_aff` / `scalars` are this call's full inputs on every rank (a caller that keeps the
+    bases resident per rank passes only its slice and world = 1 semantics through `backend.msm`).  Returns the affine
+    result, identical on every rank.  An empty slice contributes the identity."""
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    n = len(scalars) // 32
+    lo, hi = slice_bounds(n, world, rank)
+    part = backend.msm(bases_aff[64 * lo:64 * hi], scalars[32 * lo:32 * hi]) if hi > lo else IDENTITY_AFF
+    if dist is None:
+        return part
+    import torch
+    mine = torch.frombuffer(bytearray(part), dtype=torch.uint8)
+    if device is not None:
+        mine = mine.to(device)
+    gathered = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    return backend.sum_affine([bytes(g.cpu().numpy().tobytes()) for g in gathered])
+
+
 class GpuBackend:
     """Product backend: everything runs through libh2agg.so."""
 
@@ -77,6 +106,10 @@ class GpuBackend:
     def evaluate(self, b, proof: MultiOpenProof):
         left, right, _names = b.evaluate_multiopen_proof(proof.w_x, proof.w_g)
         return left, right
+
+    def msm(self, bases_aff: bytes, scalars: bytes) -> bytes:
+        """h2agg_g1_msm + to_affine (MockEccChip::multi_exp, mock/arith/ecc.rs:106-129)"""
+        return self.eng.g1_batch_to_affine(self.eng.g1_msm(bases_aff, scalars))
 
     def sum_affine(self, pts: Sequence[bytes]) -> bytes:
         one = (1).to_bytes(32, "little")

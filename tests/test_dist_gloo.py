@@ -42,6 +42,12 @@ class OracleBackend:
                                              S.MultiOpenProof(proof.w_x, proof.w_g))
         return O.aff_to_bytes(l), O.aff_to_bytes(r)
 
+    def msm(self, bases_aff, scalars):
+        O = self.O
+        n = len(scalars) // 32
+        pts = [O.aff_from_bytes(bases_aff[64 * i:64 * i + 64]) for i in range(n)]
+        return O.aff_to_bytes(O.multi_exp(pts, [O.fe_from_bytes(scalars[32 * i:32 * i + 32]) for i in range(n)]))
+
     def sum_affine(self, pts):
         O = self.O
         acc = O.INF
@@ -114,6 +120,49 @@ def _worker(rank, world, port, n_total, q):
         dist.destroy_process_group()
 
 
+def _msm_inputs(n, seed=0x51CE):
+    from oracle import bn254 as O
+    rng = O.SplitMix64(seed)
+    pts = [O.scalar_mul(rng.fr(), O.G1) for _ in range(n)]
+    scs = [rng.fr() for _ in range(n)]
+    return pts, scs, b"".join(O.aff_to_bytes(p) for p in pts), b"".join(O.fe_to_bytes(s) for s in scs)
+
+
+def _msm_worker(rank, world, port, n, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import __graft_entry__ as entry
+    entry.load_package()
+    import importlib
+    agg = importlib.import_module(entry.PKG_NAME + ".aggregate")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        _pts, _scs, bases, scalars = _msm_inputs(n)
+        q.put((rank, agg.msm_sliced(OracleBackend(), bases, scalars, dist=dist).hex()))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n", [7, 1])
+def test_msm_split_by_points_world2_gloo(n):
+    """SURVEY.md 8(e), second grain: one multi_exp split across ranks by points; n = 1 leaves rank 1 an empty slice"""
+    from oracle import bn254 as O
+    world, port = 2, 31500 + (os.getpid() % 2000) + n
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_msm_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    pts, scs, _b, _s = _msm_inputs(n)
+    want = O.aff_to_bytes(O.multi_exp(pts, scs)).hex()
+    assert res[0] == want and res[1] == want
+
+
 @pytest.mark.parametrize("n_total", [5, 1])
 def test_sharded_aggregation_world2_gloo(n_total):
     from oracle import bn254 as O
@@ -138,6 +187,8 @@ def test_shard_and_lambda_helpers():
     entry.load_package()
     agg = importlib.import_module(entry.PKG_NAME + ".aggregate")
     assert agg.shard_indices(10, 4, 1) == [1, 5, 9] and agg.shard_indices(2, 4, 3) == []
+    assert [agg.slice_bounds(10, 4, r) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert [agg.slice_bounds(2, 4, r) for r in range(4)] == [(0, 1), (1, 2), (2, 2), (2, 2)]
     from oracle import bn254 as O, schema as S
     backend = OracleBackend()
     b = backend.new_builder()
