@@ -196,6 +196,7 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
         "seconds_per_aggregation": dt,
         "commitments_per_proof": len(specs[0][0]),
         "instance_msm_points_per_proof": n_inst,
+        "instance_msm_fixed_base_levels": bool(n_inst and args.agg_instance_log2 <= 18 and not args.no_fixed_base),
         "final_pair_sha": __import__("hashlib").sha256(pair[0] + pair[1]).hexdigest()[:16],
         "note": "synthetic shape-faithful schemas; per proof: the instance-column commitment MSM against the fixed "
                 "g_lagrange table (instance scalars resident in HBM), host-side schema construction (Python + C++) "
@@ -222,6 +223,8 @@ def main():
     ap.add_argument("--overlap-level", type=int, default=2, help="1: only the Horner tail overlaps; 2: + bucket reduction")
     ap.add_argument("--agg-proofs", type=int, default=4, help="proofs per GPU in the aggregation leg (0 = skip)")
     ap.add_argument("--agg-commitments", type=int, default=300, help="advice commitments per synthetic proof")
+    ap.add_argument("--no-fixed-base", action="store_true",
+                    help="do not precompute fixed-base levels for the g_lagrange stand-in (h2agg_bases_precompute)")
     ap.add_argument("--agg-instance-log2", type=int, default=17,
                     help="k of the per-proof instance-column commitment MSM (2^k - 6 scalars); 0 = leave it out")
     args = ap.parse_args()
@@ -352,6 +355,8 @@ def main():
             gk[:, 31] &= 0x1F
             gk = gk.to(dev)
             g_table = eng.bases_generate(gk.data_ptr(), 1 << args.agg_instance_log2)
+            if args.agg_instance_log2 <= 18 and not args.no_fixed_base:
+                eng.bases_precompute(g_table)          # g_lagrange is fixed per circuit size: one-off SRS-style setup
         agg_info = aggregation_leg(pkg, eng, args, rank, world, dist, (dev, coll_dev), g_table)  # configs[2]/[3]: 4 proofs per GPU
         big = argparse.Namespace(**vars(args))
         big.agg_proofs = 4 * args.agg_proofs                                       # configs[4]: 16 proofs per GPU

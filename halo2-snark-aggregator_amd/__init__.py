@@ -79,6 +79,7 @@ def load_library():
         "h2agg_eval_flat": (i32, [ctxp, u8p, u8p, u8p, sz, vp]),
         "h2agg_bases_upload": (i32, [ctxp, u8p, sz, C.POINTER(u64)]),
         "h2agg_bases_generate": (i32, [ctxp, vp, sz, C.POINTER(u64)]),
+        "h2agg_bases_precompute": (i32, [ctxp, u64, i32]),
         "h2agg_bases_download": (i32, [ctxp, u64, sz, sz, vp]),
         "h2agg_bases_free": (i32, [ctxp, u64]),
         "h2agg_g1_msm_preloaded": (i32, [ctxp, u64, u8p, sz, vp]),
@@ -289,6 +290,10 @@ class H2Agg:
         h = C.c_uint64()
         self._check(self._lib.h2agg_bases_generate(self._ctx, d_k_scalars_ptr, n, C.byref(h)))
         return h.value
+
+    def bases_precompute(self, handle: int, window_bits: int = 0):
+        """fixed-base levels for a resident table (SRS-style bases): later MSMs over it use one bucket set"""
+        self._check(self._lib.h2agg_bases_precompute(self._ctx, handle, window_bits))
 
     def bases_download(self, handle: int, first: int, n: int) -> bytes:
         out = C.create_string_buffer(max(64 * n, 1))

@@ -38,6 +38,14 @@ struct Table {
     uint8_t* d = nullptr;       // Montgomery affine, 64 B / point
     uint8_t* endo_x = nullptr;  // beta * x, 32 B / point (made on the first GLV MSM over this table)
     size_t n = 0;
+    // fixed-base levels (h2agg_bases_precompute): pre[(w * n + i) * 64] = 2^(pre_c * w) * P_i, w < pre_W
+    uint8_t* pre = nullptr;
+    int pre_c = 0, pre_W = 0;
+};
+struct PreTable {   // what msm_run needs of it
+    const uint8_t* d;
+    size_t n_level;
+    int c, W;
 };
 
 }  // namespace
@@ -273,14 +281,29 @@ int join_tails(h2agg_ctx* c) {
 // d_out_jac[96 * q] (c->d_res_xyzz then only holds MSM 0's XYZZ).  One set of launches does all of them: every
 // scalar's windows are numbered q * W + w, and the stages after the sort only see batch * W windows.
 // d_endo_x: beta * x per base (Table::endo_x) or nullptr = compute it here when the plan uses GLV.
+// pre: fixed-base levels of the table (then d_bases is ignored): plain c-bit digits of ALL positions into one bucket set
+// per MSM, bases looked up at level w; no Horner chain.
 int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size_t n_base, uint8_t* d_out_jac,
-            uint32_t batch = 1, const uint8_t* d_endo_x = nullptr) {
+            uint32_t batch = 1, const uint8_t* d_endo_x = nullptr, const PreTable* pre = nullptr) {
     const size_t n = n_base * batch;   // scalars
     if (n >= ((size_t)1 << 30)) return fail(c, H2AGG_ERR_INVALID, "n must be < 2^30");
     MsmPlan p = make_plan(c, n_base, batch);
-    const int W1 = p.W;                       // windows per MSM
+    int Wd = p.W;                             // digit positions per scalar (what the recoding loops over)
+    if (pre) {
+        p.glv = false;
+        p.c = pre->c;
+        Wd = pre->W;
+        p.W = 1;                              // one bucket set per MSM
+        p.NB = 1u << (p.c - 1);
+        p.NBT = batch * p.NB;
+        p.seg = c->cfg_seg ? (uint32_t)c->cfg_seg : 8u;
+        if (p.seg > p.NB) p.seg = p.NB;
+        p.spw = p.NB / p.seg;
+        d_bases = pre->d;
+    }
+    const int W1 = p.W;                       // windows (bucket sets) per MSM
     const uint32_t WT = (uint32_t)W1 * batch;  // windows in total
-    const size_t nent = n * (size_t)W1 * (p.glv ? 2 : 1);   // bucket insertions
+    const size_t nent = n * (size_t)Wd * (p.glv ? 2 : 1);   // bucket insertions
     if (!c->cfg_big) {
         // a lane walks a bucket alone up to `big` entries: 8x the mean keeps a denser top window (up to 4x the mean
         // when it holds c-2 bits) out of the workgroup-per-chunk path, whose LDS tree only pays for real outliers
@@ -289,7 +312,11 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     }
     if (nent >= ((size_t)1 << 32)) return fail(c, H2AGG_ERR_INVALID, "n * windows must be < 2^32");
     SortPlan sp;
-    const int want_sub = c->cfg_sub_bits ? c->cfg_sub_bits : SORT_SUB_BITS;
+    int want_sub = c->cfg_sub_bits ? c->cfg_sub_bits : SORT_SUB_BITS;
+    if (pre && !c->cfg_sub_bits) {
+        // one bucket set per MSM: keep >= 256 level-2 partitions (one workgroup each) so the sort still fills the chip
+        while (want_sub > 4 && (((size_t)p.NB * batch) >> want_sub) < 256) --want_sub;
+    }
     sp.sub_bits = (p.c - 1 < want_sub) ? p.c - 1 : want_sub;
     while ((WT * (p.NB >> sp.sub_bits)) > (uint32_t)SORT_MAX_PW && sp.sub_bits < p.c - 1 &&
            sp.sub_bits < SORT_MAX_SUB_BITS)
@@ -301,12 +328,14 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         sp.n_base = (uint32_t)n_base;
         sp.W1 = (uint32_t)W1;
     }
+    if (pre) sp.pre_n = (uint32_t)pre->n_level;
     sp.tile = c->cfg_tile ? (uint32_t)c->cfg_tile : 2048u;
     // packed-item staged path: index field of 31 - sub_bits bits, a tile's keys must fit the LDS stage
     sp.glv = p.glv;
     const int idx_bits = (p.glv ? 30 : 31) - sp.sub_bits;   // packed item: sub | neg | (endo) | idx
-    bool staged = !c->cfg_no_stage && n_base <= ((size_t)1 << idx_bits);   // items carry the BASE index
-    const size_t keys_per_scalar = (size_t)W1 * (p.glv ? 2 : 1);
+    // items carry the BASE index (fixed-base mode: up to W * n_level of them)
+    bool staged = !c->cfg_no_stage && (pre ? (size_t)pre->W * pre->n_level : n_base) <= ((size_t)1 << idx_bits);
+    const size_t keys_per_scalar = (size_t)Wd * (p.glv ? 2 : 1);
     if (staged && c->cfg_stage_l1 && (size_t)sp.tile * keys_per_scalar > (size_t)STAGE_ITEMS_L1)
         sp.tile = (uint32_t)(STAGE_ITEMS_L1 / keys_per_scalar);
     if (staged && sp.tile < (uint32_t)BLOCK) staged = false;
@@ -383,7 +412,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     {
         StageTimer t(c, ST_PART_COUNT);
         HIP_TRY(c, hipMemsetAsync(meta, 0, M_WORDS * 4, st));
-        hipLaunchKernelGGL(k_part_count, dim3(ntiles), dim3(BLOCK), 0, st, d_scalars, n, p.c, W1, sp, pcount,
+        hipLaunchKernelGGL(k_part_count, dim3(ntiles), dim3(BLOCK), 0, st, d_scalars, n, p.c, Wd, sp, pcount,
                            c->d_flags, tile_counts);
         hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(BLOCK), 0, st, pcount, sp.PW, pstart, pcursor);
     }
@@ -401,10 +430,10 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         {
             StageTimer t(c, ST_PART_SCATTER);
             if (c->cfg_stage_l1)
-                hipLaunchKernelGGL(k_part_scatter_staged, dim3(ntiles), dim3(BLOCK), lds1, st, d_scalars, n, p.c, W1,
+                hipLaunchKernelGGL(k_part_scatter_staged, dim3(ntiles), dim3(BLOCK), lds1, st, d_scalars, n, p.c, Wd,
                                    sp, idx_bits, pcursor, item_idx);
             else
-                hipLaunchKernelGGL(k_part_scatter_packed, dim3(ntiles), dim3(BLOCK), 0, st, d_scalars, n, p.c, W1, sp,
+                hipLaunchKernelGGL(k_part_scatter_packed, dim3(ntiles), dim3(BLOCK), 0, st, d_scalars, n, p.c, Wd, sp,
                                    idx_bits, pcursor, item_idx, (const uint32_t*)tile_counts);
         }
         {
@@ -415,7 +444,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     } else {
         {
             StageTimer t(c, ST_PART_SCATTER);
-            hipLaunchKernelGGL(k_part_scatter, dim3(ntiles), dim3(BLOCK), 0, st, d_scalars, n, p.c, W1, sp, pcursor,
+            hipLaunchKernelGGL(k_part_scatter, dim3(ntiles), dim3(BLOCK), 0, st, d_scalars, n, p.c, Wd, sp, pcursor,
                                item_idx, item_sub);
         }
         {
@@ -605,6 +634,7 @@ void h2agg_destroy(h2agg_ctx* c) {
     for (auto& kv : c->tables) {
         if (kv.second.d) hipFree(kv.second.d);
         if (kv.second.endo_x) hipFree(kv.second.endo_x);
+        if (kv.second.pre) hipFree(kv.second.pre);
     }
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->h_stage) hipHostFree(c->h_stage);
@@ -953,6 +983,7 @@ int h2agg_bases_free(h2agg_ctx* c, uint64_t handle) try {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     hipFree(it->second.d);
     if (it->second.endo_x) hipFree(it->second.endo_x);
+    if (it->second.pre) hipFree(it->second.pre);
     c->tables.erase(it);
     return H2AGG_OK;
 } catch (const std::bad_alloc&) {
@@ -976,6 +1007,56 @@ int table_endo(h2agg_ctx* c, Table& t, const uint8_t** out) {
 }
 }  // namespace
 extern "C" {
+// width of the fixed-base levels: n * ceil(255 / c) bucket insertions + one reduction of 2^(c-1) buckets (~4 mixed-add
+// equivalents per bucket), minimised over c; capped so the sort's packed items and partitions stay in range
+int choose_pre_window(size_t n) {
+    int best = 16;
+    double best_cost = 1e300;
+    for (int cc = 8; cc <= 20; ++cc) {
+        const double cost = (double)n * ((255 + cc - 1) / cc) + 4.0 * (double)((size_t)1 << (cc - 1));
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = cc;
+        }
+    }
+    return best;
+}
+
+int h2agg_bases_precompute(h2agg_ctx* c, uint64_t handle, int window_bits) try {
+    TRY(bind(c));
+    auto it = c->tables.find(handle);
+    if (it == c->tables.end()) return fail(c, H2AGG_ERR_INVALID, "unknown base-table handle");
+    Table& t = it->second;
+    if (window_bits != 0 && (window_bits < 4 || window_bits > 20))
+        return fail(c, H2AGG_ERR_INVALID, "fixed-base window must be 0 (auto) or in [4, 20]");
+    const int cc = window_bits ? window_bits : choose_pre_window(t.n);
+    const int W = (255 + cc - 1) / cc;
+    // the levels are addressed through the sort's packed 32-bit item (22 index bits next to 9 sub-bucket bits + sign):
+    // beyond that the sort falls back to its slower kernels and the levels (W x the table) stop paying for themselves
+    if ((size_t)W * t.n > ((size_t)1 << 22))
+        return fail(c, H2AGG_ERR_INVALID, "table too large for fixed-base levels (ceil(255 / c) * n must be <= 2^22)");
+    TRY(join_tails(c));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (t.pre) {
+        hipFree(t.pre);
+        t.pre = nullptr;
+    }
+    if (hipMalloc((void**)&t.pre, (size_t)W * t.n * 64) != hipSuccess)
+        return fail(c, H2AGG_ERR_NOMEM, "hipMalloc(fixed-base levels)");
+    HIP_TRY(c, hipMemcpyAsync(t.pre, t.d, t.n * 64, hipMemcpyDeviceToDevice, c->stream));
+    for (int w = 1; w < W; ++w)
+        hipLaunchKernelGGL(k_bases_shift, dim3(grid_for(c, t.n)), dim3(BLOCK), 0, c->stream,
+                           (const uint8_t*)t.pre + (size_t)(w - 1) * t.n * 64, t.n, cc, t.pre + (size_t)w * t.n * 64);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    t.pre_c = cc;
+    t.pre_W = W;
+    return H2AGG_OK;
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
+}
+
 int h2agg_g1_msm_device_async(h2agg_ctx* c, uint64_t handle, const void* d_scalars, size_t n, void* d_out_jac) try {
     TRY(bind(c));
     auto it = c->tables.find(handle);
@@ -988,6 +1069,11 @@ int h2agg_g1_msm_device_async(h2agg_ctx* c, uint64_t handle, const void* d_scala
     // Beyond 2^22 points the packed (index | sub-bucket) sort item no longer fits 32 bits and the sort would fall back to
     // its slower two-array kernels: cut the MSM into slices of <= 2^22 points instead (their tails overlap the next
     // slice's bulk) and add the slices' results.
+    if (it->second.pre && !c->cfg_c) {   // fixed-base levels (h2agg_bases_precompute); an explicit window_bits overrides
+        const PreTable pt{it->second.pre, it->second.n, it->second.pre_c, it->second.pre_W};
+        if ((size_t)pt.W * n < ((size_t)1 << 32))
+            return msm_run(c, it->second.d, (const uint8_t*)d_scalars, n, (uint8_t*)d_out_jac, 1, nullptr, &pt);
+    }
     const size_t SLICE = (size_t)1 << 22;
     if (n <= SLICE) return msm_run(c, it->second.d, (const uint8_t*)d_scalars, n, (uint8_t*)d_out_jac, 1, endo);
     const size_t nsl = (n + SLICE - 1) / SLICE;
@@ -1026,11 +1112,15 @@ int h2agg_g1_msm_device_batch_async(h2agg_ctx* c, uint64_t handle, const void* d
     if (n > it->second.n) return fail(c, H2AGG_ERR_INVALID, "more scalars than bases in the table");
     // MSMs per set of launches: the level-1 sort partitions (batch * W * NB >> sub_bits, sub_bits <= 11) must fit its
     // LDS counters, and the entry count its 32-bit offsets
+    const bool use_pre = it->second.pre && !c->cfg_c;   // fixed-base levels (h2agg_bases_precompute)
+    const PreTable pt{it->second.pre, it->second.n, it->second.pre_c, it->second.pre_W};
     const MsmPlan p1 = make_plan(c, n, 1);
-    uint32_t ppw_min = p1.NB >> 11;
+    const uint32_t nb1 = use_pre ? (1u << (pt.c - 1)) : p1.NB;
+    const size_t sets1 = use_pre ? 1 : (size_t)p1.W;                               // bucket sets per MSM
+    uint32_t ppw_min = nb1 >> 11;
     if (ppw_min < 1) ppw_min = 1;
-    size_t per = (size_t)SORT_MAX_PW / ((size_t)p1.W * ppw_min);
-    const size_t ent1 = n * (size_t)p1.W * (p1.glv ? 2 : 1);
+    size_t per = (size_t)SORT_MAX_PW / (sets1 * ppw_min);
+    const size_t ent1 = use_pre ? n * (size_t)pt.W : n * (size_t)p1.W * (p1.glv ? 2 : 1);
     if (per * ent1 >= ((size_t)1 << 31)) per = (((size_t)1 << 31) - 1) / ent1;
     if (per * n >= ((size_t)1 << 29)) per = (((size_t)1 << 29) - 1) / n;
     if (per < 1) per = 1;
@@ -1039,7 +1129,7 @@ int h2agg_g1_msm_device_batch_async(h2agg_ctx* c, uint64_t handle, const void* d
     for (size_t q = 0; q < batch; q += per) {
         const size_t b = batch - q < per ? batch - q : per;
         TRY(msm_run(c, it->second.d, (const uint8_t*)d_scalars + 32 * n * q, n, (uint8_t*)d_out_jac + 96 * q, (uint32_t)b,
-                    endo));
+                    use_pre ? nullptr : endo, use_pre ? &pt : nullptr));
     }
     return H2AGG_OK;
 } catch (const std::bad_alloc&) {

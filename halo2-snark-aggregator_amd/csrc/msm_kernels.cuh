@@ -53,6 +53,21 @@ __global__ void __launch_bounds__(BLOCK) k_bases_endo_x(const uint8_t* __restric
         fp_store<FqParams>(endo_x + 32 * i, FQ_MUL(fp_load<FqParams>(bases + 64 * i), beta));   // 2*1/169 + 1 -> [2]
 }
 
+// fixed-base tables: level w holds 2^(c*w) * P_i (Montgomery affine) for every base, so an MSM over the table needs no
+// per-window bucket sets and no doubling chain — every digit of every scalar lands in ONE bucket set, and the width can
+// exceed 16 bits because the bucket reduction is paid once, not once per window.  One level from the previous one:
+__global__ void __launch_bounds__(BLOCK) k_bases_shift(const uint8_t* __restrict__ in, size_t n, int c,
+                                                       uint8_t* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
+        const G1Affine a = affine_load(in + 64 * i);
+        G1XYZZ p = G1XYZZ::identity();
+        xyzz_add_affine(p, a);
+#pragma unroll 1
+        for (int k = 0; k < c; ++k) p = xyzz_double(p);
+        affine_store(out + 64 * i, affine_from_xyzz(p));
+    }
+}
+
 // Buckets longer than `big` are cut into chunks of BIG_CHUNK entries, one workgroup per chunk (a narrow top
 // window or skewed scalars can put a large share of all points into a handful of buckets — a 2-bit top
 // window at c = 14 holds n/4 points per bucket).  big_list: 3 words per chunk slot {key, chunk, nchunks};

@@ -37,6 +37,9 @@ struct SortPlan {
     // its windows are numbered q * W1 + w (so every stage downstream just sees more windows).  n_base = 0: no batch.
     uint32_t n_base = 0;
     uint32_t W1 = 0;
+    // fixed-base mode (Table::pre): the table holds 2^(c*w) * P_i for every digit position w at index w * pre_n + i, so
+    // ALL digits of a scalar go to ONE bucket set (window q of the batch, or window 0) and refer to base w * pre_n + i
+    uint32_t pre_n = 0;
 };
 
 // ------------------------------------------------------------------ GLV (endomorphism) decomposition
@@ -237,6 +240,9 @@ constexpr uint32_t ENT_IDX = 0x3fffffffu;
             const uint32_t q_ = sp.n_base ? (uint32_t)i / sp.n_base : 0u;              \
             const uint32_t wofs = q_ * sp.W1;            /* window offset of MSM q */   \
             const uint32_t bi = (uint32_t)i - q_ * sp.n_base;   /* base index */        \
+            /* window of digit w in the key space, base referred to by digit w */       \
+            auto WIN = [&](int w_) { return sp.pre_n ? q_ : (uint32_t)w_ + wofs; };     \
+            auto BASE = [&](int w_) { return sp.pre_n ? bi + (uint32_t)w_ * sp.pre_n : bi; }; \
             const uint32_t kn_ = k_ + BLOCK;                                           \
             const size_t in_ = base + kn_;                                             \
             const bool more_ = kn_ < sp.tile && in_ < n;                               \
@@ -262,7 +268,7 @@ __global__ void __launch_bounds__(BLOCK) k_part_count(const uint8_t* __restrict_
     TILE_SCALARS_BEGIN(threadIdx.x)
         if (!sp.glv) bad |= !u256_is_canonical_fr(s);  // (GLV words were range-checked by k_glv_decompose)
         msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool, bool) {
-            atomicAdd(&cnt[((uint32_t)w + wofs) * sp.ppw + (b >> sp.sub_bits)], 1u);
+            atomicAdd(&cnt[WIN(w) * sp.ppw + (b >> sp.sub_bits)], 1u);
         });
     TILE_SCALARS_END
     if (bad) atomicOr(flags, FLAG_NONCANONICAL);
@@ -320,7 +326,7 @@ __global__ void __launch_bounds__(BLOCK) k_part_scatter(const uint8_t* __restric
     const size_t base = (size_t)blockIdx.x * sp.tile;
     TILE_SCALARS_BEGIN(threadIdx.x)
         msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool, bool) {
-            atomicAdd(&cnt[((uint32_t)w + wofs) * sp.ppw + (b >> sp.sub_bits)], 1u);
+            atomicAdd(&cnt[WIN(w) * sp.ppw + (b >> sp.sub_bits)], 1u);
         });
     TILE_SCALARS_END
     __syncthreads();
@@ -333,9 +339,9 @@ __global__ void __launch_bounds__(BLOCK) k_part_scatter(const uint8_t* __restric
     const uint32_t submask = sp.SB - 1u;
     TILE_SCALARS_BEGIN(threadIdx.x)
         msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool neg, bool endo) {
-            const uint32_t p = ((uint32_t)w + wofs) * sp.ppw + (b >> sp.sub_bits);
+            const uint32_t p = WIN(w) * sp.ppw + (b >> sp.sub_bits);
             const uint32_t pos = basep[p] + atomicAdd(&cnt[p], 1u);
-            item_idx[pos] = bi | (neg ? ENT_NEG : 0u) | (endo ? ENT_ENDO : 0u);
+            item_idx[pos] = BASE(w) | (neg ? ENT_NEG : 0u) | (endo ? ENT_ENDO : 0u);
             item_sub[pos] = (uint16_t)(b & submask);
         });
     TILE_SCALARS_END
@@ -435,7 +441,7 @@ __global__ void __launch_bounds__(BLOCK) k_part_scatter_staged(const uint8_t* __
     const size_t base = (size_t)blockIdx.x * sp.tile;
     TILE_SCALARS_BEGIN(tid)
         msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool, bool) {
-            atomicAdd(&len[((uint32_t)w + wofs) * sp.ppw + (b >> sp.sub_bits)], 1u);
+            atomicAdd(&len[WIN(w) * sp.ppw + (b >> sp.sub_bits)], 1u);
         });
     TILE_SCALARS_END
     __syncthreads();
@@ -474,9 +480,9 @@ __global__ void __launch_bounds__(BLOCK) k_part_scatter_staged(const uint8_t* __
     const uint32_t submask = sp.SB - 1u;
     TILE_SCALARS_BEGIN(tid)
         msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool neg, bool endo) {
-            const uint32_t p = ((uint32_t)w + wofs) * sp.ppw + (b >> sp.sub_bits);
+            const uint32_t p = WIN(w) * sp.ppw + (b >> sp.sub_bits);
             const uint32_t r = atomicAdd(&cur[p], 1u);
-            stage[lbase[p] + r] = pack_item(b & submask, neg, endo, bi, idx_bits, sp.glv);
+            stage[lbase[p] + r] = pack_item(b & submask, neg, endo, BASE(w), idx_bits, sp.glv);
         });
     TILE_SCALARS_END
     __syncthreads();
@@ -509,7 +515,7 @@ __global__ void __launch_bounds__(BLOCK) k_part_scatter_packed(const uint8_t* __
         __syncthreads();
         TILE_SCALARS_BEGIN(threadIdx.x)
             msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool, bool) {
-                atomicAdd(&cnt[((uint32_t)w + wofs) * sp.ppw + (b >> sp.sub_bits)], 1u);
+                atomicAdd(&cnt[WIN(w) * sp.ppw + (b >> sp.sub_bits)], 1u);
             });
         TILE_SCALARS_END
         __syncthreads();
@@ -523,9 +529,9 @@ __global__ void __launch_bounds__(BLOCK) k_part_scatter_packed(const uint8_t* __
     const uint32_t submask = sp.SB - 1u;
     TILE_SCALARS_BEGIN(threadIdx.x)
         msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool neg, bool endo) {
-            const uint32_t p = ((uint32_t)w + wofs) * sp.ppw + (b >> sp.sub_bits);
+            const uint32_t p = WIN(w) * sp.ppw + (b >> sp.sub_bits);
             const uint32_t pos = basep[p] + atomicAdd(&cnt[p], 1u);
-            items[pos] = pack_item(b & submask, neg, endo, bi, idx_bits, sp.glv);
+            items[pos] = pack_item(b & submask, neg, endo, BASE(w), idx_bits, sp.glv);
         });
     TILE_SCALARS_END
 }

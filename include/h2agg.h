@@ -139,6 +139,15 @@ int h2agg_eval_flat(h2agg_ctx* ctx, const uint8_t* pts_aff, const uint8_t* scala
  * MSM against `params.g_lagrange` (halo2-snark-aggregator-api/src/systems/halo2/verify.rs:623-635) and
  * for benchmarking with inputs already resident. */
 int h2agg_bases_upload(h2agg_ctx* ctx, const uint8_t* bases_aff, size_t n, uint64_t* handle_out);
+/* Fixed-base acceleration of a resident table (an SRS such as ParamsKZG.g_lagrange, the bases of
+ * assign_instance_commitment, verify.rs:574-649): stores 2^(c*w) * P_i for every digit position w beside the table
+ * (ceil(255 / c) x 64 B per point).  Every later MSM over this handle (h2agg_g1_msm_preloaded / _device / _device_async /
+ * _device_batch_async, h2agg_instance_commitment) then drops all digits of a scalar into ONE bucket set: one bucket
+ * reduction instead of one per window, no doubling chain, and a wider window.  window_bits: 0 = chosen from the table
+ * size, else 4..20; ceil(255 / c) * n must be <= 2^22 (tables up to ~2^18 points), larger tables are refused
+ * (H2AGG_ERR_INVALID) and keep the ordinary path.  Results are the same points (h2agg_msm_configure's explicit
+ * window_bits disables the fast path). */
+int h2agg_bases_precompute(h2agg_ctx* ctx, uint64_t bases_handle, int window_bits);
 /* bases[i] = k_i * G for n canonical Fr scalars held in DEVICE memory (workload generation: the
  * expected MSM is then (sum k_i * s_i) * G).  Arithmetic = scalar_mul_constant + to_affine. */
 int h2agg_bases_generate(h2agg_ctx* ctx, const void* d_k_scalars, size_t n, uint64_t* handle_out);

@@ -296,3 +296,36 @@ def test_throughput_mode_paths(eng):
             assert got[64 * q:64 * q + 64] == eng.g1_batch_to_affine(eng.g1_msm_device(table, d_b[q].data_ptr(), m)), q
     finally:
         eng.bases_free(table)
+
+
+@pytest.mark.parametrize("n,cw", [(5000, 0), (5000, 11), (1 << 15, 0), (300, 20), ((1 << 17) - 6, 0)])
+def test_fixed_base_levels(eng, n, cw):
+    """h2agg_bases_precompute: MSMs over a table with fixed-base levels (single bucket set, digits looked up at level
+    w) give the same points as the ordinary path — single, prefix, batched; zero / r-1 / one scalars included."""
+    dev = torch.device("cuda", 0)
+    ks, k_np = _workload(n, 81)
+    d_k = torch.from_numpy(k_np.copy()).to(dev)
+    table = eng.bases_generate(d_k.data_ptr(), n)
+    try:
+        B = 3
+        rows = [_workload(n, 90 + q) for q in range(B)]
+        arr = np.stack([a for _v, a in rows]).copy()
+        arr[0, :7] = 0
+        arr[0, 7] = np.frombuffer((O.R - 1).to_bytes(32, "little"), dtype=np.uint8)
+        arr[0, 8] = np.frombuffer((1).to_bytes(32, "little"), dtype=np.uint8)
+        d_s = torch.from_numpy(arr).to(dev)
+        m = max(1, n - n // 3)
+        want_full = [eng.g1_batch_to_affine(eng.g1_msm_device(table, d_s[q].data_ptr(), n)) for q in range(B)]
+        want_prefix = eng.g1_batch_to_affine(eng.g1_msm_device(table, d_s[1].data_ptr(), m))
+        t1 = sum(k * s for k, s in zip(ks, rows[1][0])) % O.R
+        assert want_full[1] == O.aff_to_bytes(O.scalar_mul(t1, O.G1))
+        eng.bases_precompute(table, cw)
+        for q in range(B):
+            assert eng.g1_batch_to_affine(eng.g1_msm_device(table, d_s[q].data_ptr(), n)) == want_full[q], q
+        assert eng.g1_batch_to_affine(eng.g1_msm_device(table, d_s[1].data_ptr(), m)) == want_prefix
+        d_out = torch.zeros((B, 96), dtype=torch.uint8, device=dev)
+        eng.g1_msm_device_batch_async(table, d_s.data_ptr(), n, B, d_out.data_ptr())
+        assert eng.g1_batch_to_affine_device(d_out.data_ptr(), B) == b"".join(want_full)
+        assert eng.g1_batch_to_affine(eng.g1_msm_preloaded(table, bytes(arr[2].tobytes()))) == want_full[2]
+    finally:
+        eng.bases_free(table)
