@@ -70,3 +70,37 @@ def test_decompress_throughput_shape(eng):
     out = eng.g1_batch_decompress(enc)
     assert out[:64 * 64] == b"".join(O.aff_to_bytes(p) for p in base) and out[-64 * 64:] == out[:64 * 64]
     assert eng.g1_batch_compress(out) == enc
+
+
+def test_read_proofs_layout(eng, pkg):
+    import importlib
+    import __graft_entry__ as entry
+    wire = importlib.import_module(entry.PKG_NAME + ".wire")
+    rng = O.SplitMix64(0x3139)
+    layout = list("PPSPSSPP")
+    proofs, want = [], []
+    for _ in range(3):
+        pts = [O.scalar_mul(rng.fr(), O.G1) for _ in range(layout.count("P"))]
+        scs = [rng.fr() for _ in range(layout.count("S"))]
+        ip, isc = iter(pts), iter(scs)
+        proofs.append(b"".join(O.compress(next(ip)) if t == "P" else O.fe_to_bytes(next(isc)) for t in layout))
+        want.append(([O.aff_to_bytes(p) for p in pts], [O.fe_to_bytes(s) for s in scs]))
+    assert wire.read_proofs(eng, layout, proofs) == want
+    assert wire.read_proofs(eng, layout, []) == []
+    with pytest.raises(wire.ProofFormatError):                       # short read
+        wire.read_proofs(eng, layout, [proofs[0][:-1]])
+    bad_scalar = bytearray(proofs[0])
+    bad_scalar[32 * 2:32 * 3] = (O.R + 1).to_bytes(32, "little")
+    with pytest.raises(wire.ProofFormatError):                       # Fr::from_repr rejects >= r
+        wire.read_proofs(eng, layout, [bytes(bad_scalar)])
+    bad_point = bytearray(proofs[1])
+    x = 2
+    while True:
+        try:
+            O.decompress(x.to_bytes(32, "little"))
+            x += 1
+        except ValueError:
+            break
+    bad_point[0:32] = x.to_bytes(32, "little")
+    with pytest.raises(pkg.BadPoint):                                # "invalid point encoding in proof"
+        wire.read_proofs(eng, layout, [proofs[0], bytes(bad_point)])
