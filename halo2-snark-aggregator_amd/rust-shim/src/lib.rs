@@ -10,8 +10,7 @@
 use group::{Curve, Group};
 use halo2_proofs::arithmetic::{CurveAffine, FieldExt};
 use halo2_snark_aggregator_api::arith::{common::ArithCommonChip, ecc::ArithEccChip};
-use halo2_snark_aggregator_api::mock::arith::field::{MockChipCtx, MockFieldChip};
-use std::marker::PhantomData;
+use halo2_snark_aggregator_api::mock::arith::ecc::MockEccChip;
 use std::os::raw::{c_char, c_int};
 
 #[repr(C)]
@@ -34,11 +33,10 @@ extern "C" {
     fn h2agg_host_free(ctx: *mut h2agg_ctx, p: *mut u8) -> c_int;
 }
 
+/// Wraps the reference's own Mock chip and forwards everything to it except `multi_exp`.
 pub struct GpuEccChip<C: CurveAffine, E> {
-    zero: C::CurveExt,
-    one: C::CurveExt,
+    host: MockEccChip<C, E>,
     gpu: *mut h2agg_ctx, // single-thread-affine, like the reference's use of the chips
-    _data: PhantomData<E>,
 }
 
 impl<C: CurveAffine, E> Default for GpuEccChip<C, E> {
@@ -46,7 +44,7 @@ impl<C: CurveAffine, E> Default for GpuEccChip<C, E> {
         let mut gpu = std::ptr::null_mut();
         let rc = unsafe { h2agg_create(0, &mut gpu) };
         assert_eq!(rc, 0, "h2agg_create failed: a HIP device is required");
-        Self { zero: C::CurveExt::identity(), one: C::CurveExt::generator(), gpu, _data: PhantomData }
+        Self { host: MockEccChip::default(), gpu }
     }
 }
 impl<C: CurveAffine, E> Drop for GpuEccChip<C, E> {
@@ -85,41 +83,63 @@ fn curve_from_jac<C: CurveAffine>(b: &[u8; 96]) -> C::CurveExt {
     C::from_xy(x * zi2, y * zi2 * zi).unwrap().to_curve()
 }
 
+type Host<C, E> = MockEccChip<C, E>;
+type Ctx<C, E> = <Host<C, E> as ArithCommonChip>::Context;
+type Pt<C, E> = <Host<C, E> as ArithCommonChip>::AssignedValue;
+type Sc<C, E> = <Host<C, E> as ArithEccChip>::AssignedScalar;
+
 impl<C: CurveAffine, E> ArithCommonChip for GpuEccChip<C, E> {
-    type Context = MockChipCtx;
-    type Value = C;
-    type AssignedValue = C::CurveExt;
+    type Context = Ctx<C, E>;
+    type Value = <Host<C, E> as ArithCommonChip>::Value;
+    type AssignedValue = Pt<C, E>;
     type Error = E;
-    // identical to mock/arith/ecc.rs:30-75
-    fn add(&self, _: &mut MockChipCtx, a: &C::CurveExt, b: &C::CurveExt) -> Result<C::CurveExt, E> { Ok(*a + *b) }
-    fn sub(&self, _: &mut MockChipCtx, a: &C::CurveExt, b: &C::CurveExt) -> Result<C::CurveExt, E> { Ok(*a - *b) }
-    fn assign_zero(&self, _: &mut MockChipCtx) -> Result<C::CurveExt, E> { Ok(self.zero) }
-    fn assign_one(&self, _: &mut MockChipCtx) -> Result<C::CurveExt, E> { Ok(self.one) }
-    fn assign_const(&self, _: &mut MockChipCtx, c: C) -> Result<C::CurveExt, E> { Ok(c.to_curve()) }
-    fn assign_var(&self, _: &mut MockChipCtx, v: C) -> Result<C::CurveExt, E> { Ok(v.to_curve()) }
-    fn to_value(&self, v: &C::CurveExt) -> Result<C, E> { Ok(v.to_affine()) }
-    fn normalize(&self, _: &mut MockChipCtx, v: &C::CurveExt) -> Result<C::CurveExt, E> { Ok(*v) }
+    // element-wise group operations: forwarded to the host chip unchanged
+    fn add(&self, ctx: &mut Self::Context, a: &Pt<C, E>, b: &Pt<C, E>) -> Result<Pt<C, E>, E> {
+        self.host.add(ctx, a, b)
+    }
+    fn sub(&self, ctx: &mut Self::Context, a: &Pt<C, E>, b: &Pt<C, E>) -> Result<Pt<C, E>, E> {
+        self.host.sub(ctx, a, b)
+    }
+    fn assign_zero(&self, ctx: &mut Self::Context) -> Result<Pt<C, E>, E> {
+        self.host.assign_zero(ctx)
+    }
+    fn assign_one(&self, ctx: &mut Self::Context) -> Result<Pt<C, E>, E> {
+        self.host.assign_one(ctx)
+    }
+    fn assign_const(&self, ctx: &mut Self::Context, c: C) -> Result<Pt<C, E>, E> {
+        self.host.assign_const(ctx, c)
+    }
+    fn assign_var(&self, ctx: &mut Self::Context, v: C) -> Result<Pt<C, E>, E> {
+        self.host.assign_var(ctx, v)
+    }
+    fn to_value(&self, v: &Pt<C, E>) -> Result<C, E> {
+        self.host.to_value(v)
+    }
+    fn normalize(&self, ctx: &mut Self::Context, v: &Pt<C, E>) -> Result<Pt<C, E>, E> {
+        self.host.normalize(ctx, v)
+    }
 }
 
 impl<C: CurveAffine, E> ArithEccChip for GpuEccChip<C, E> {
     type Point = C;
-    type AssignedPoint = C::CurveExt;
-    type Scalar = C::ScalarExt;
-    type AssignedScalar = C::ScalarExt;
-    type Native = C::ScalarExt;
-    type AssignedNative = C::ScalarExt;
-    type ScalarChip = MockFieldChip<C::ScalarExt, E>;
-    type NativeChip = MockFieldChip<C::ScalarExt, E>;
+    type AssignedPoint = Pt<C, E>;
+    type Scalar = <Host<C, E> as ArithEccChip>::Scalar;
+    type AssignedScalar = Sc<C, E>;
+    type Native = <Host<C, E> as ArithEccChip>::Native;
+    type AssignedNative = <Host<C, E> as ArithEccChip>::AssignedNative;
+    type ScalarChip = <Host<C, E> as ArithEccChip>::ScalarChip;
+    type NativeChip = <Host<C, E> as ArithEccChip>::NativeChip;
 
-    fn scalar_mul(&self, _: &mut MockChipCtx, lhs: &C::ScalarExt, rhs: &C::CurveExt) -> Result<C::CurveExt, E> {
-        Ok(*rhs * *lhs) // single products stay on the host, as in mock/arith/ecc.rs:88-95
+    // single products stay on the host chip (a kernel launch costs more than one scalar multiplication)
+    fn scalar_mul(&self, ctx: &mut Self::Context, lhs: &Sc<C, E>, rhs: &Pt<C, E>) -> Result<Pt<C, E>, E> {
+        self.host.scalar_mul(ctx, lhs, rhs)
     }
-    fn scalar_mul_constant(&self, _: &mut MockChipCtx, lhs: &C::ScalarExt, rhs: C) -> Result<C::CurveExt, E> {
-        Ok(rhs * *lhs)
+    fn scalar_mul_constant(&self, ctx: &mut Self::Context, lhs: &Sc<C, E>, rhs: C) -> Result<Pt<C, E>, E> {
+        self.host.scalar_mul_constant(ctx, lhs, rhs)
     }
 
     /// mock/arith/ecc.rs:106-129 with the loop of scalar muls replaced by one GPU MSM.
-    fn multi_exp(&self, ctx: &mut MockChipCtx, points: Vec<C::CurveExt>, scalars: Vec<C::ScalarExt>) -> Result<C::CurveExt, E> {
+    fn multi_exp(&self, ctx: &mut Self::Context, points: Vec<Pt<C, E>>, scalars: Vec<Sc<C, E>>) -> Result<Pt<C, E>, E> {
         // observable side effect kept: `Display for MockChipCtx` prints point_list.len()
         ctx.point_list = points.iter().map(|x| format!("{:?}", x)).collect();
         let n = points.len().min(scalars.len());
