@@ -392,8 +392,8 @@ def main():
                 "points_per_msm": n,
                 "window_bits": args.window or "auto",
                 "tail_overlap": not args.no_overlap,
-                "glv": {0: "auto (off here: overlap mode and n >= 2^19; on in the aggregation leg's small MSMs)",
-                        1: "on", -1: "off"}[args.glv] if args.log2n >= 19 and not args.no_overlap else
+                "glv": {0: "auto (off here: overlap mode and n >= 2^20; on in the aggregation leg's small MSMs)",
+                        1: "on", -1: "off"}[args.glv] if args.log2n >= 20 and not args.no_overlap else
                        {0: "auto (on)", 1: "on", -1: "off"}[args.glv],
                 "proofs_per_sec": world * args.steps / dt_max,
                 "exchange": "none (1 GPU)" if world == 1 else "1 all-gather of %d x 96 B + local fold" % world,
