@@ -65,6 +65,7 @@ def load_library():
         "h2agg_describe": (C.c_char_p, [ctxp]),
         "h2agg_fr_batch_op": (i32, [ctxp, i32, u8p, u8p, sz, vp]),
         "h2agg_fr_batch_pow_constant": (i32, [ctxp, u8p, sz, u64, vp]),
+        "h2agg_fr_tape_eval": (i32, [ctxp, u8p, sz, vp, sz, vp, sz, vp]),
         "h2agg_fr_mul_add_accumulate": (i32, [ctxp, u8p, sz, u8p, vp]),
         "h2agg_fr_sum_with_coeff_and_constant": (i32, [ctxp, u8p, u8p, sz, u8p, vp]),
         "h2agg_g1_batch_add": (i32, [ctxp, u8p, u8p, sz, i32, vp]),
@@ -201,6 +202,15 @@ class H2Agg:
         out = C.create_string_buffer(max(32 * n, 1))
         self._check(self._lib.h2agg_fr_batch_pow_constant(self._ctx, a, n, exponent, out))
         return out.raw[:32 * n]
+
+    def fr_tape_eval(self, consts: bytes, ops: Sequence, out_regs: Sequence[int]) -> bytes:
+        """ops: (opcode, a, b) triples (0 = mul, 1 = add, 2 = sub); registers: inputs first, then one per op"""
+        nconst, nops, nout = len(consts) // 32, len(ops), len(out_regs)
+        flat = (C.c_uint32 * max(3 * nops, 1))(*[x for op in ops for x in op])
+        regs = (C.c_uint32 * max(nout, 1))(*out_regs)
+        out = C.create_string_buffer(max(32 * nout, 1))
+        self._check(self._lib.h2agg_fr_tape_eval(self._ctx, consts, nconst, flat, nops, regs, nout, out))
+        return out.raw[:32 * nout]
 
     def fr_mul_add_accumulate(self, v: bytes, b: bytes) -> bytes:
         out = C.create_string_buffer(32)

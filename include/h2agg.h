@@ -227,6 +227,16 @@ const char* h2agg_schema_name(h2agg_schema* s, size_t i);
 size_t h2agg_schema_names_joined(h2agg_schema* s, char* out, size_t cap);
 size_t h2agg_schema_point_list_len(h2agg_schema* s);
 
+/* ---- Fr expression tape ------------------------------------------------------
+ * A straight-line program over Fr, run on the device by the interpreter EvaluationQuerySchema::eval records into:
+ * registers 0 .. nconst-1 are the inputs (canonical, 32 B each), register nconst + k is the result of op k;
+ * ops3 = nops x {opcode, a, b} (u32 each; opcode 0 = mul, 1 = add, 2 = sub; a, b < nconst + k).  Independent ops run in
+ * parallel, a chain costs one multiplication latency per link.  out_regs selects the nout registers returned in `out`
+ * (canonical).  This is the shape of the verifier's scalar-side expressions (halo2-snark-aggregator-api/src/systems/halo2/
+ * {params,lookup,permutation,vanish,lagrange,expression}.rs evaluate such programs through ArithFieldChip). */
+int h2agg_fr_tape_eval(h2agg_ctx* ctx, const uint8_t* consts, size_t nconst, const uint32_t* ops3, size_t nops,
+                       const uint32_t* out_regs, size_t nout, uint8_t* out);
+
 /* ---- tuning / measurement -------------------------------------------------------------------------
  * window_bits: Pippenger window c in [2, 16]; 0 = the measured table (GLV: 8 / 13 / 16 for n <= 2^10 / <= 2^14 / larger;
  * plain: 8 / 15 / 16 for n <= 2^12 / < 2^19 / larger — wide windows with a uniform top window).

@@ -344,3 +344,39 @@ def test_msm_lanes_per_bucket(eng, lanes, glv):
             eng.msm_configure()
             eng.msm_configure_glv(0)
             eng.msm_configure_lanes_per_bucket(0)
+
+
+def test_fr_tape_eval(eng, pkg):
+    """h2agg_fr_tape_eval: random straight-line Fr programs (mul / add / sub DAGs with long chains and wide levels) against
+    exact big-integer evaluation; a lagrange-style expression (x^n - 1) / (n (x - w^i)) numerator chain; error paths."""
+    rng = O.SplitMix64(0x7A9E)
+    for trial in range(6):
+        nconst, nops = 1 + rng.next() % 40, rng.next() % 3000
+        vals = [rng.fr() for _ in range(nconst)]
+        if trial == 0:
+            vals[0] = 0
+        regs = list(vals)
+        ops = []
+        for k in range(nops):
+            op = rng.next() % 3
+            hi = nconst + k
+            a = hi - 1 if (trial % 2 and k) else rng.next() % hi          # odd trials: one long dependency chain
+            b = rng.next() % hi
+            ops.append((op, a, b))
+            regs.append((regs[a] * regs[b], regs[a] + regs[b], regs[a] - regs[b])[op] % O.R)
+        outs = [rng.next() % len(regs) for _ in range(1 + rng.next() % 50)] + [len(regs) - 1]
+        got = eng.fr_tape_eval(fr_bytes(vals), ops, outs)
+        assert got == fr_bytes([regs[i] for i in outs]), trial
+    # x^(2^10) - 1 by repeated squaring, then times a constant: the shape of lagrange.rs / vanish.rs
+    x = rng.fr()
+    ops = [(0, 0, 0)] + [(0, 2 + k, 2 + k) for k in range(9)] + [(2, 11, 1)]
+    assert eng.fr_tape_eval(fr_bytes([x, 1]), ops, [12]) == fr_bytes([(pow(x, 1 << 10, O.R) - 1) % O.R])
+    assert eng.fr_tape_eval(fr_bytes([5]), [], [0]) == fr_bytes([5])
+    with pytest.raises(pkg.H2AggError):
+        eng.fr_tape_eval(fr_bytes([1, 2]), [(0, 0, 2)], [2])               # operand not yet defined
+    with pytest.raises(pkg.H2AggError):
+        eng.fr_tape_eval(fr_bytes([1, 2]), [(7, 0, 1)], [2])               # unknown opcode
+    with pytest.raises(pkg.H2AggError):
+        eng.fr_tape_eval(fr_bytes([1, 2]), [(0, 0, 1)], [3])               # output out of range
+    with pytest.raises(pkg.H2AggError):
+        eng.fr_tape_eval(O.R.to_bytes(32, "little"), [], [0])              # non-canonical input
