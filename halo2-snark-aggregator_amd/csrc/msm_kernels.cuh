@@ -72,7 +72,15 @@ __global__ void __launch_bounds__(BLOCK) k_bases_shift(const uint8_t* __restrict
 // window or skewed scalars can put a large share of all points into a handful of buckets — a 2-bit top
 // window at c = 14 holds n/4 points per bucket).  big_list: 3 words per chunk slot {key, chunk, nchunks};
 // big_keys: 3 words per multi-chunk bucket {key, first slot, nchunks}.
-constexpr uint32_t BIG_CHUNK = 2048;
+constexpr uint32_t BIG_CHUNK = 2048;       // smallest chunk
+constexpr uint32_t BIG_CHUNK_MAX = 16384;  // largest: 64 additions per lane amortise the workgroup's LDS tree (8 levels)
+// chunk size of an over-long bucket: ~64 chunks per bucket (a bucket holding a million entries — all scalars equal — is
+// then 64 workgroups of 64 additions per lane, not 512 workgroups of 8 additions + a tree each)
+FP_INLINE uint32_t big_chunk_size(uint32_t len) {
+    uint32_t cs = len / 64;
+    cs = cs < BIG_CHUNK ? BIG_CHUNK : (cs > BIG_CHUNK_MAX ? BIG_CHUNK_MAX : cs);
+    return cs;
+}
 
 __global__ void __launch_bounds__(BLOCK) k_msm_accumulate(const uint8_t* __restrict__ bases,
                                                           const uint8_t* __restrict__ endo_x,
@@ -95,7 +103,8 @@ __global__ void __launch_bounds__(BLOCK) k_msm_accumulate(const uint8_t* __restr
     const uint32_t len = hist[key];
     if (len > big) {
         if (part != 0) return;
-        const uint32_t nch = (len + BIG_CHUNK - 1) / BIG_CHUNK;
+        const uint32_t cs = big_chunk_size(len);
+        const uint32_t nch = (len + cs - 1) / cs;
         const uint32_t base = atomicAdd(&counters[0], nch);
         for (uint32_t j = 0; j < nch; ++j) {
             big_list[3 * (base + j)] = key;
@@ -155,7 +164,8 @@ __global__ void __launch_bounds__(BLOCK) k_msm_accumulate_big(const uint8_t* __r
     for (uint32_t b = blockIdx.x; b < nslots; b += gridDim.x) {
         const uint32_t key = big_list[3 * b], chunk = big_list[3 * b + 1], nch = big_list[3 * b + 2];
         const uint32_t len = hist[key];
-        const uint32_t lo = chunk * BIG_CHUNK, hi = (lo + BIG_CHUNK < len) ? lo + BIG_CHUNK : len;
+        const uint32_t cs = big_chunk_size(len);
+        const uint32_t lo = chunk * cs, hi = (lo + cs < len) ? lo + cs : len;
         const uint32_t* run = entries + offs[key];
         G1XYZZ acc = G1XYZZ::identity();
 #pragma unroll 1
