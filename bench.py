@@ -217,7 +217,8 @@ def main():
     ap.add_argument("--tile", type=int, default=0)
     ap.add_argument("--glv", type=int, default=0, help="-1: off, 0/1: on (endomorphism split of the scalars)")
     ap.add_argument("--lpb", type=int, default=0, help="lanes per bucket in the accumulate kernel (0 = auto)")
-    ap.add_argument("--cpu-sample", type=int, default=1 << 16)
+    ap.add_argument("--cpu-sample", type=int, default=1 << 17,
+                    help="points of the workload given to the single-thread CPU restatement (~13 s at 2^17)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run the Horner tail in-stream (latency mode)")
     ap.add_argument("--overlap-level", type=int, default=2, help="1: only the Horner tail overlaps; 2: + bucket reduction")
