@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(BLOCK) k_msm_accumulate(const uint8_t* __restr
                                                           uint8_t* __restrict__ buckets, uint32_t* __restrict__ big_list,
                                                           uint32_t* __restrict__ big_keys,
                                                           uint32_t* __restrict__ counters /* [0] chunks, [1] keys */) {
-    const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nbt * lpb) return;
     // buckets sorted by length, longest first: a wave's lanes finish together.  With lpb > 1 each bucket's run
     // is cut into lpb slices handled by adjacent lanes (more, shorter waves: fills the 3072 wave slots when
