@@ -176,19 +176,12 @@ int finish(h2agg_ctx* c) {
 // plain: 254-bit scalars, W*c >= 255; GLV: 127-bit magnitudes, W*c >= 128
 int window_count(int c, bool glv) { return glv ? (128 + c - 1) / c : (255 + c - 1) / c; }
 int top_window_bits(int c, bool glv) { return (glv ? 127 : 254) - c * (window_count(c, glv) - 1); }
-// How much denser the top window's buckets are than the others': it holds `top_window_bits` bits, i.e. 2^t
-// buckets instead of 2^(c-1), for the same number of points.
-double top_window_density(int c, bool glv) {
-    const int t = top_window_bits(c, glv);
-    const int e = (c - 1) - t;
-    return e <= 0 ? 1.0 : (double)((uint64_t)1 << (e > 40 ? 40 : e));
-}
 int choose_window(size_t n, bool glv) {
     // Measured on MI355X (tools/window_sweep.py, profiles/r01_window_sweep_*.txt).  Two things decide it, and the
     // classic "log2(n) - 4" rule sees neither: (1) the tail (bucket reduce -> window sums -> Horner) is a serial
     // chain whose length grows with the number of windows, so below ~2^17 points FEWER, WIDER windows win even
     // though they leave most buckets empty; (2) only widths whose top window is as sparse as the others
-    // (top_window_density ~1: GLV 8/13/16, plain 8/15/16) avoid a dense top window that costs as much as all the
+    // (GLV 8/13/16, plain 8/15/16: top window as sparse as the others) avoid a dense top window that costs as much as all the
     // other windows together.
     if (glv) return n <= ((size_t)1 << 10) ? 8 : n <= ((size_t)1 << 14) ? 13 : 16;
     return n <= ((size_t)1 << 12) ? 8 : n < ((size_t)1 << 19) ? 15 : 16;

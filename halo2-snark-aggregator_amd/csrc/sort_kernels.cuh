@@ -243,6 +243,7 @@ constexpr uint32_t ENT_IDX = 0x3fffffffu;
             /* window of digit w in the key space, base referred to by digit w */       \
             auto WIN = [&](int w_) { return sp.pre_n ? q_ : (uint32_t)w_ + wofs; };     \
             auto BASE = [&](int w_) { return sp.pre_n ? bi + (uint32_t)w_ * sp.pre_n : bi; }; \
+            (void)BASE;                                                                 \
             const uint32_t kn_ = k_ + BLOCK;                                           \
             const size_t in_ = base + kn_;                                             \
             const bool more_ = kn_ < sp.tile && in_ < n;                               \
