@@ -189,10 +189,10 @@ int choose_window(size_t n, bool glv) {
 
 MsmPlan make_plan(const h2agg_ctx* c, size_t n, uint32_t batch = 1) {
     MsmPlan p;
-    // GLV halves the latency-shaped stages (reduction, Horner tail) at the price of ~5 % more work in the
-    // accumulation (beta multiplications): a win whenever those stages are exposed — single-MSM latency mode, or
-    // small / medium MSMs — and a small loss when a large MSM's tail is hidden under the next one's bulk
-    // (profiles/r01_sweeps.txt).  auto = on unless (overlap mode and n >= 2^19).
+    // GLV halves the latency-shaped stages (reduction, Horner tail) at the price of the decomposition pass and the
+    // slice-combine pass of the half-as-many buckets: a win whenever those stages are exposed — single-MSM latency
+    // mode, or small / medium MSMs — and a small loss when a large MSM's tail is hidden under the next one's bulk
+    // (profiles/r01_sweeps.txt).  auto = on unless (overlap mode and n >= 2^20).
     p.glv = c->cfg_glv > 0 || (c->cfg_glv == 0 && !(c->tail_overlap && n >= ((size_t)1 << 20)));
     p.c = c->cfg_c ? c->cfg_c : choose_window(n, p.glv);
     p.W = window_count(p.c, p.glv);
