@@ -19,6 +19,10 @@ namespace h2agg {
 
 #define FQ_MUL(a, b) fp_mul<FqParams>(a, b)
 #define FQ_SQR(a) fp_sqr<FqParams>(a)
+FP_INLINE void fq_fence(Fq& a) {   // no instructions: makes the limbs opaque 32-bit values again
+#pragma unroll
+    for (int i = 0; i < NL; ++i) asm("" : "+v"(a.l[i]));
+}
 #define FQ_ADD(a, b) fp_add<FqParams>(a, b)
 #define FQ_SUB(K, a, b) fp_sub<K, FqParams>(a, b) /* a - b + K*p, needs value(b) <= K*p */
 #define FQ_DBL(a) fp_dbl<FqParams>(a)
@@ -119,6 +123,11 @@ FP_INLINE void xyzz_add_affine(G1XYZZ& acc, const G1Affine& q) {
             return;
         }
     }
+    // Optimiser fence on the limbs that live across the exceptional-case branch above: without it LLVM carries them as
+    // zero-extended 64-bit values through the branch's merge point and then multiplies 64 x 32 bits (an extra mad with a
+    // zero high word, a v_mul_lo / v_add3 and register shuffles per product): -7 % instructions in the mixed addition.
+    fq_fence(p);
+    fq_fence(r);
     Fq pp = FQ_SQR(p);                                  // 100 -> [2]
     Fq ppp = FQ_MUL(p, pp);                             // 20  -> [2]
     Fq qq = FQ_MUL(acc.x, pp);                          // 16  -> [2]
@@ -148,6 +157,8 @@ FP_INLINE G1XYZZ xyzz_add(const G1XYZZ& a, const G1XYZZ& b) {
         }
     }
     G1XYZZ o;
+    fq_fence(p);   // see xyzz_add_affine
+    fq_fence(r);
     Fq pp = FQ_SQR(p);                                  // 16 -> [2]
     Fq ppp = FQ_MUL(p, pp);                             // [2]
     Fq q = FQ_MUL(u1, pp);                              // [2]
