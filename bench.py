@@ -75,7 +75,8 @@ def valu_view(stage_name: str, log2n: int, avg_kernel_s: float):
     the committed PMC pass over the same command (profiles/r01_final_pmc_sq.txt: SQ_INSTS_VALU, GRBM_GUI_ACTIVE summed
     over the 8 XCDs); the duration is this run's live figure.  `ideal` = cycles per wave-instruction per SIMD if the VALU
     never stalled, from the kernel's instruction mix at the measured issue rates (tools/ubench.hip: v_mad_u64_u32,
-    v_mul_lo_u32, v_lshl_add_u64, 64-bit shifts 4 cycles per wave64; 32-bit add / and / cndmask 2): 3.56."""
+    v_mul_lo_u32, v_lshl_add_u64, 64-bit shifts 4 cycles per wave64; 32-bit add / and / cndmask 2): per mixed addition
+    2 316 instructions, 2 039 of them half rate -> 3.76."""
     if not (log2n == 20 and stage_name == "msm_accumulate"):
         return None
     try:
@@ -91,7 +92,7 @@ def valu_view(stage_name: str, log2n: int, avg_kernel_s: float):
         return None
     simds = 256 * 4
     cpi = avg_kernel_s * clk_hz * simds / insts
-    ideal = 3.56
+    ideal = 3.76
     return {"wave_instructions_per_launch": insts, "shader_clock_ghz": clk_hz / 1e9, "simds": simds,
             "cycles_per_instruction_per_simd": cpi, "ideal_cycles_per_instruction": ideal, "issue_frac": ideal / cpi,
             "source": "profiles/r01_final_pmc_sq.txt (rocprofv3 --pmc, same command) + this run's avg_kernel_ms"}
