@@ -192,8 +192,10 @@ MsmPlan make_plan(const h2agg_ctx* c, size_t n, uint32_t batch = 1) {
     // GLV halves the latency-shaped stages (reduction, Horner tail) at the price of the decomposition pass and the
     // slice-combine pass of the half-as-many buckets: a win whenever those stages are exposed — single-MSM latency
     // mode, or small / medium MSMs — and a small loss when a large MSM's tail is hidden under the next one's bulk
-    // (profiles/r01_sweeps.txt).  auto = on unless (overlap mode and n >= 2^20).
-    p.glv = c->cfg_glv > 0 || (c->cfg_glv == 0 && !(c->tail_overlap && n >= ((size_t)1 << 20)));
+    // (profiles/r01_sweeps.txt), or when the tail is a small share anyway.  auto = on unless (overlap mode and n >= 2^20) or
+    // n >= 2^22.
+    p.glv = c->cfg_glv > 0 ||
+            (c->cfg_glv == 0 && !(c->tail_overlap && n >= ((size_t)1 << 20)) && n < ((size_t)1 << 22));
     p.c = c->cfg_c ? c->cfg_c : choose_window(n, p.glv);
     p.W = window_count(p.c, p.glv);
     p.NB = 1u << (p.c - 1);
