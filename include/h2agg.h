@@ -248,7 +248,7 @@ int h2agg_msm_configure(h2agg_ctx* ctx, int window_bits, int reduce_segment, int
  * number of windows — same bucket additions, half the bucket reduction and half the serial doubling chain.
  * beta*x is computed once per base (a 32 B/point column beside the table), so the price is the decomposition pass and
  * the slice-combine pass of the half-as-many buckets: mode 0 = auto turns it on unless the tail is hidden anyway
- * (overlap mode and n >= 2^20); 1 = on, -1 = off (254-bit windows). */
+ * (overlap mode and n >= 2^20) or is a small share of the work (n >= 2^22); 1 = on, -1 = off (254-bit windows). */
 int h2agg_msm_configure_glv(h2agg_ctx* ctx, int mode);
 /* Lanes per bucket in the accumulation kernel (1, 2, 4, 8, 16; 0 = chosen so that ~8192 waves are launched, at most 8
  * and at most the mean bucket occupancy). */
