@@ -133,6 +133,12 @@ def exported_symbols() -> Sequence[str]:
     return load_library()._h2agg_protos
 
 
+def _need(buf, nbytes: int, what: str):
+    """the C side trusts the lengths it is given: a short Python buffer would be read past its end"""
+    if buf is None or len(buf) != nbytes:
+        raise ValueError("%s must be exactly %d bytes (got %s)" % (what, nbytes, "None" if buf is None else len(buf)))
+
+
 class H2Agg:
     """One context = one GPU, single-thread-affine (mirrors `MockEccChip::default()` +
     `MockFieldChip::default()` + `MockChipCtx::default()`, verify_circuit.rs:115-118)."""
@@ -193,12 +199,16 @@ class H2Agg:
     # ------------------------------------------------------------------ Fr
     def fr_batch_op(self, op: int, a: bytes, b: Optional[bytes] = None) -> bytes:
         n = len(a) // 32
+        _need(a, 32 * n, "a")
+        if op in (OP_ADD, OP_SUB, OP_MUL, OP_DIV):
+            _need(b, 32 * n, "b")
         out = C.create_string_buffer(32 * n) if n else C.create_string_buffer(1)
         self._check(self._lib.h2agg_fr_batch_op(self._ctx, op, a, b, n, out))
         return out.raw[:32 * n]
 
     def fr_batch_pow_constant(self, a: bytes, exponent: int) -> bytes:
         n = len(a) // 32
+        _need(a, 32 * n, "a")
         out = C.create_string_buffer(max(32 * n, 1))
         self._check(self._lib.h2agg_fr_batch_pow_constant(self._ctx, a, n, exponent, out))
         return out.raw[:32 * n]
@@ -206,6 +216,7 @@ class H2Agg:
     def fr_tape_eval(self, consts: bytes, ops: Sequence, out_regs: Sequence[int]) -> bytes:
         """ops: (opcode, a, b) triples (0 = mul, 1 = add, 2 = sub); registers: inputs first, then one per op"""
         nconst, nops, nout = len(consts) // 32, len(ops), len(out_regs)
+        _need(consts, 32 * nconst, "consts")
         flat = (C.c_uint32 * max(3 * nops, 1))(*[x for op in ops for x in op])
         regs = (C.c_uint32 * max(nout, 1))(*out_regs)
         out = C.create_string_buffer(max(32 * nout, 1))
@@ -213,11 +224,16 @@ class H2Agg:
         return out.raw[:32 * nout]
 
     def fr_mul_add_accumulate(self, v: bytes, b: bytes) -> bytes:
+        _need(v, 32 * (len(v) // 32), "v")
+        _need(b, 32, "b")
         out = C.create_string_buffer(32)
         self._check(self._lib.h2agg_fr_mul_add_accumulate(self._ctx, v, len(v) // 32, b, out))
         return out.raw
 
     def fr_sum_with_coeff_and_constant(self, x: bytes, coeff: bytes, b: bytes) -> bytes:
+        _need(x, 32 * (len(x) // 32), "x")
+        _need(coeff, len(x), "coeff")
+        _need(b, 32, "b")
         out = C.create_string_buffer(32)
         self._check(self._lib.h2agg_fr_sum_with_coeff_and_constant(self._ctx, x, coeff, len(x) // 32, b, out))
         return out.raw
@@ -225,18 +241,23 @@ class H2Agg:
     # ------------------------------------------------------------------ G1 batch
     def g1_batch_add(self, a_jac: bytes, b_jac: bytes, subtract: bool = False) -> bytes:
         n = len(a_jac) // 96
+        _need(a_jac, 96 * n, "a_jac")
+        _need(b_jac, 96 * n, "b_jac")
         out = C.create_string_buffer(max(96 * n, 1))
         self._check(self._lib.h2agg_g1_batch_add(self._ctx, a_jac, b_jac, n, int(subtract), out))
         return out.raw[:96 * n]
 
     def g1_batch_scalar_mul(self, bases_aff: bytes, scalars: bytes) -> bytes:
         n = len(scalars) // 32
+        _need(scalars, 32 * n, "scalars")
+        _need(bases_aff, 64 * n, "bases_aff")
         out = C.create_string_buffer(max(96 * n, 1))
         self._check(self._lib.h2agg_g1_batch_scalar_mul(self._ctx, bases_aff, scalars, n, out))
         return out.raw[:96 * n]
 
     def g1_batch_to_affine(self, jac: bytes) -> bytes:
         n = len(jac) // 96
+        _need(jac, 96 * n, "jac")
         out = C.create_string_buffer(max(64 * n, 1))
         self._check(self._lib.h2agg_g1_batch_to_affine(self._ctx, jac, n, out))
         return out.raw[:64 * n]
@@ -249,6 +270,7 @@ class H2Agg:
     def g1_batch_decompress(self, data: bytes, with_ok: bool = False):
         """proof wire format -> canonical affine (transcript.rs:63-70); raises BadPoint unless with_ok"""
         n = len(data) // 32
+        _need(data, 32 * n, "data")
         out, ok = C.create_string_buffer(max(64 * n, 1)), C.create_string_buffer(max(n, 1))
         rc = self._lib.h2agg_g1_batch_decompress(self._ctx, data, n, out, ok)
         if with_ok and rc in (OK, ERR_BAD_POINT):
@@ -258,11 +280,13 @@ class H2Agg:
 
     def g1_batch_compress(self, aff: bytes) -> bytes:
         n = len(aff) // 64
+        _need(aff, 64 * n, "aff")
         out = C.create_string_buffer(max(32 * n, 1))
         self._check(self._lib.h2agg_g1_batch_compress(self._ctx, aff, n, out))
         return out.raw[:32 * n]
 
     def g1_sum(self, jac: bytes) -> bytes:
+        _need(jac, 96 * (len(jac) // 96), "jac")
         out = C.create_string_buffer(96)
         self._check(self._lib.h2agg_g1_sum(self._ctx, jac, len(jac) // 96, out))
         return out.raw
@@ -273,6 +297,10 @@ class H2Agg:
         out = C.create_string_buffer(96)
         if n is None:
             n = len(scalars) // 32
+        if isinstance(scalars, (bytes, bytearray)):
+            _need(scalars, 32 * n, "scalars")
+        if isinstance(bases_aff, (bytes, bytearray)):
+            _need(bases_aff, 64 * n, "bases_aff")
         pb = C.cast(bases_aff, C.c_void_p) if isinstance(bases_aff, (bytes, bytearray)) else C.c_void_p(bases_aff)
         ps = C.cast(scalars, C.c_void_p) if isinstance(scalars, (bytes, bytearray)) else C.c_void_p(scalars)
         self._check(self._lib.h2agg_g1_msm(self._ctx, pb, ps, n, out))
@@ -287,11 +315,15 @@ class H2Agg:
         self._check(self._lib.h2agg_host_free(self._ctx, C.c_void_p(ptr)))
 
     def eval_flat(self, pts_aff: bytes, scalars: bytes, has_scalar: bytes) -> bytes:
+        n = len(has_scalar)
+        _need(pts_aff, 64 * n, "pts_aff")
+        _need(scalars, 32 * n, "scalars")
         out = C.create_string_buffer(96)
         self._check(self._lib.h2agg_eval_flat(self._ctx, pts_aff, scalars, has_scalar, len(has_scalar), out))
         return out.raw
 
     def bases_upload(self, bases_aff: bytes) -> int:
+        _need(bases_aff, 64 * (len(bases_aff) // 64), "bases_aff")
         h = C.c_uint64()
         self._check(self._lib.h2agg_bases_upload(self._ctx, bases_aff, len(bases_aff) // 64, C.byref(h)))
         return h.value
@@ -314,11 +346,13 @@ class H2Agg:
         self._check(self._lib.h2agg_bases_free(self._ctx, handle))
 
     def g1_msm_preloaded(self, handle: int, scalars: bytes) -> bytes:
+        _need(scalars, 32 * (len(scalars) // 32), "scalars")
         out = C.create_string_buffer(96)
         self._check(self._lib.h2agg_g1_msm_preloaded(self._ctx, handle, scalars, len(scalars) // 32, out))
         return out.raw
 
     def instance_commitment(self, g_lagrange_handle: int, instance: bytes, max_len: int) -> bytes:
+        _need(instance, 32 * (len(instance) // 32), "instance")
         out = C.create_string_buffer(96)
         self._check(self._lib.h2agg_instance_commitment(self._ctx, g_lagrange_handle, instance, len(instance) // 32,
                                                         max_len, out))
@@ -407,12 +441,15 @@ class SchemaBuilder:
         return EvaluationQuerySchema(self, out.value)
 
     def commit(self, cq: CommitQuery) -> "EvaluationQuerySchema":        # commit!  evaluation.rs:41-46
+        _need(cq.commitment, 64, "commitment")
         return self._node(self._lib.h2agg_schema_node_commitment, cq.key.encode(), cq.commitment)
 
     def evalq(self, cq: CommitQuery) -> "EvaluationQuerySchema":         # eval!    evaluation.rs:48-53
+        _need(cq.eval, 32, "eval")
         return self._node(self._lib.h2agg_schema_node_eval, cq.eval)
 
     def scalar(self, s: bytes) -> "EvaluationQuerySchema":               # scalar!  evaluation.rs:55-60
+        _need(s, 32, "scalar")
         return self._node(self._lib.h2agg_schema_node_scalar, s)
 
     def evaluation_queries(self, keys: Sequence[str], commitments: bytes, evals: bytes, wrap: bool = True):
@@ -420,6 +457,8 @@ class SchemaBuilder:
         wrap=False returns the raw node-id array (accepted by batch_multi_open): a proof has hundreds of
         queries and one Python object per query costs more than the device work."""
         n = len(keys)
+        _need(commitments, 64 * n, "commitments")
+        _need(evals, 32 * n, "evals")
         arr = (C.c_char_p * n)(*[k.encode() for k in keys])
         out = (C.c_uint32 * n)()
         self.eng._check(self._lib.h2agg_schema_evaluation_queries(self._s, n, arr, commitments, evals, out))
@@ -429,12 +468,19 @@ class SchemaBuilder:
 
     def query_set_commitment(self, query_node, point_aff: bytes):
         node = query_node.node if isinstance(query_node, EvaluationQuerySchema) else int(query_node)
+        _need(point_aff, 64, "point_aff")
         self.eng._check(self._lib.h2agg_schema_query_set_commitment(self._s, node, point_aff))
 
     def batch_multi_open(self, key: str, rotations: Sequence[int], points: bytes, query_nodes, w: bytes,
                          v: bytes, u: bytes):
         """multiopen.rs:23-102 in the C++ host layer -> (w_x, w_g) schema nodes."""
         nq = len(rotations)
+        _need(points, 32 * nq, "points")
+        _need(w, 64 * (len(w) // 64), "w")
+        _need(v, 32, "v")
+        _need(u, 32, "u")
+        if len(query_nodes) != nq:
+            raise ValueError("one query node per rotation")
         rot = (C.c_int32 * nq)(*rotations)
         if isinstance(query_nodes, C.Array):
             qn = query_nodes

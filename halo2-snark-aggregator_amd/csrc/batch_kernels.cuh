@@ -10,6 +10,13 @@ enum : uint32_t { FLAG_NONCANONICAL = 1u, FLAG_DIV_ZERO = 2u, FLAG_BAD_POINT = 4
 
 constexpr int BLOCK = 256;
 
+// Start of a synchronous entry point: flags[0] (this call's status) is rolled into flags[2] (sticky: raised by earlier
+// ASYNCHRONOUS calls that nobody has reported yet) instead of being wiped.
+__global__ void k_flags_roll(uint32_t* flags) {
+    flags[2] |= flags[0];
+    flags[0] = 0;
+}
+
 // ------------------------------------------------------------------ block-wide reductions through LDS
 // SoA layout lds[k * BLOCK + tid] (k = limb index) keeps every ds access conflict-free.
 template <int NLIMB>

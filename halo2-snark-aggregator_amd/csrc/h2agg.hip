@@ -62,8 +62,8 @@ struct h2agg_ctx {
 
     // grow-only device workspace
     DevBuf in_a, in_b, in_c, out, tmp_bases;                      // host-buffer entry points
-    DevBuf hist, offs, pmeta, item_idx, item_sub, order, entries, buckets, segsum, wsum, big_list, big_keys, big_part,
-        glv_buf, parts, small, endo_buf, tile_counts;  // MSM
+    DevBuf hist, offs, pmeta, item_idx, item_sub, order, entries, big_list, big_keys, big_part,
+        glv_buf, parts, small, endo_buf, tile_counts;  // MSM (bulk side: main stream only)
     uint32_t* d_flags = nullptr;      // in `small`: [0] status flags, [1] big_count
     uint8_t* d_res_xyzz = nullptr;    // in `small` + 1024 + 144 * slot of the LAST msm_run (see msm_run)
     uint8_t* d_res_jac = nullptr;     // in `small` + 256
@@ -96,6 +96,9 @@ struct h2agg_ctx {
     // tails of consecutive MSMs overlap one another as well as the next MSMs' bulk (small MSMs are otherwise
     // bound by one tail chain: ~0.7 ms per MSM at 2^14 points against 0.5 ms of bulk).
     static constexpr int TAIL_SLOTS = 3;
+    // what a tail reads: one independent allocation per slot, so MSMs with DIFFERENT plans (bucket counts, segment
+    // counts, window counts) in flight on different slots can never alias one another, whatever their sizes
+    DevBuf buckets[TAIL_SLOTS], segsum[TAIL_SLOTS], wsum[TAIL_SLOTS];
     hipStream_t tail_streams[TAIL_SLOTS] = {};
     hipEvent_t ev_bulk[TAIL_SLOTS] = {}, ev_tail[TAIL_SLOTS] = {};
     bool tail_pending[TAIL_SLOTS] = {};
@@ -134,7 +137,11 @@ int fail(h2agg_ctx* c, int code, const std::string& msg) {
 
 int ensure(h2agg_ctx* c, DevBuf& b, size_t bytes) {
     if (bytes <= b.cap) return H2AGG_OK;
-    if (b.p) HIP_TRY(c, hipFree(b.p));
+    if (b.p) {
+        // a grow-only buffer is replaced: nothing queued on ANY stream of the device may still refer to the old one
+        HIP_TRY(c, hipDeviceSynchronize());
+        HIP_TRY(c, hipFree(b.p));
+    }
     b.p = nullptr;
     b.cap = 0;
     size_t want = bytes + bytes / 8 + 256;
@@ -158,18 +165,32 @@ int grid_for(const h2agg_ctx* c, size_t n) {
     return (int)blocks;
 }
 
-int clear_flags(h2agg_ctx* c) { HIP_TRY(c, hipMemsetAsync(c->d_flags, 0, 8, c->stream)); return H2AGG_OK; }
-
-// synchronise and translate device status flags
-int finish(h2agg_ctx* c) {
-    HIP_TRY(c, hipMemcpyAsync(c->h_pinned + 2048, c->d_flags, 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    uint32_t f;
-    memcpy(&f, c->h_pinned + 2048, 4);
-    if (f & FLAG_DIV_ZERO) return fail(c, H2AGG_ERR_DIV_ZERO, "inversion of zero (reference: invert().unwrap() panics)");
-    if (f & FLAG_NONCANONICAL) return fail(c, H2AGG_ERR_NONCANONICAL, "input integer >= modulus");
-    if (f & FLAG_BAD_POINT) return fail(c, H2AGG_ERR_BAD_POINT, "invalid point encoding in proof");
+// d_flags: [0] status of the call in progress, [1] spare, [2] sticky status of earlier asynchronous calls.
+// A synchronous entry point starts with clear_flags (which ROLLS [0] into [2], so a flag raised by a preceding
+// h2agg_g1_msm_device_async / _batch_async is never lost) and ends with finish (which reports both).
+int clear_flags(h2agg_ctx* c) {
+    hipLaunchKernelGGL(k_flags_roll, dim3(1), dim3(1), 0, c->stream, c->d_flags);
     return H2AGG_OK;
+}
+
+int flags_to_status(h2agg_ctx* c, uint32_t f, bool earlier) {
+    const char* pre = earlier ? "an earlier asynchronous call on this context: " : "";
+    if (f & FLAG_DIV_ZERO)
+        return fail(c, H2AGG_ERR_DIV_ZERO, std::string(pre) + "inversion of zero (reference: invert().unwrap() panics)");
+    if (f & FLAG_NONCANONICAL) return fail(c, H2AGG_ERR_NONCANONICAL, std::string(pre) + "input integer >= modulus");
+    if (f & FLAG_BAD_POINT) return fail(c, H2AGG_ERR_BAD_POINT, std::string(pre) + "invalid point encoding in proof");
+    return H2AGG_OK;
+}
+
+// synchronise and translate device status flags (this call's, then any left behind by earlier asynchronous calls)
+int finish(h2agg_ctx* c) {
+    HIP_TRY(c, hipMemcpyAsync(c->h_pinned + 2048, c->d_flags, 12, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    uint32_t f[3];
+    memcpy(f, c->h_pinned + 2048, 12);
+    if (f[2]) HIP_TRY(c, hipMemsetAsync(c->d_flags + 2, 0, 4, c->stream));   // reported once
+    if (f[0]) return flags_to_status(c, f[0], false);
+    return flags_to_status(c, f[2], true);
 }
 
 // bits of the scalar that fall into the top window (a narrow top window means a few huge buckets).
@@ -353,11 +374,13 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     TRY(ensure(c, c->item_idx, nent * 4));
     TRY(ensure(c, c->item_sub, nent * 2));
     TRY(ensure(c, c->entries, nent * 4));
-    // buckets / segsum / wsum are double-buffered: in overlap mode the reduction of MSM k (tail stream)
-    // runs while MSM k+1 fills the other set
-    TRY(ensure(c, c->buckets, h2agg_ctx::TAIL_SLOTS * (size_t)p.NBT * XYZZ_BYTES));
-    TRY(ensure(c, c->segsum, h2agg_ctx::TAIL_SLOTS * (size_t)nseg_total * XYZZ_BYTES));
-    TRY(ensure(c, c->wsum, h2agg_ctx::TAIL_SLOTS * (size_t)WT * XYZZ_BYTES));
+    // buckets / segsum / wsum exist once per tail slot: in overlap mode the reduction of MSM k (tail stream)
+    // runs while MSM k+1 fills the next slot's set.  (They were one allocation cut at par * this-plan's-size: two MSMs
+    // with different plans in flight then overlapped — ADVICE r1.)
+    const int par = c->parity;
+    TRY(ensure(c, c->buckets[par], (size_t)p.NBT * XYZZ_BYTES));
+    TRY(ensure(c, c->segsum[par], (size_t)nseg_total * XYZZ_BYTES));
+    TRY(ensure(c, c->wsum[par], (size_t)WT * XYZZ_BYTES));
     const size_t max_slots = nent / BIG_CHUNK + nent / ((size_t)p.big + 1) + 2;   // chunks of over-long buckets
     const size_t max_keys = nent / ((size_t)p.big + 1) + 2;
     TRY(ensure(c, c->big_list, max_slots * 12));
@@ -372,11 +395,10 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     uint32_t* item_idx = (uint32_t*)c->item_idx.p;
     uint16_t* item_sub = (uint16_t*)c->item_sub.p;
     uint32_t* entries = (uint32_t*)c->entries.p;
-    const int par = c->parity;
     c->d_res_xyzz = (uint8_t*)c->small.p + 1024 + 144 * par;   // each tail slot has its own XYZZ result
-    uint8_t* buckets = (uint8_t*)c->buckets.p + (size_t)par * p.NBT * XYZZ_BYTES;
-    uint8_t* segsum = (uint8_t*)c->segsum.p + (size_t)par * nseg_total * XYZZ_BYTES;
-    uint8_t* wsum = (uint8_t*)c->wsum.p + (size_t)par * WT * XYZZ_BYTES;
+    uint8_t* buckets = (uint8_t*)c->buckets[par].p;
+    uint8_t* segsum = (uint8_t*)c->segsum[par].p;
+    uint8_t* wsum = (uint8_t*)c->wsum[par].p;
     uint32_t* big_list = (uint32_t*)c->big_list.p;
     uint32_t* big_keys = (uint32_t*)c->big_keys.p;
     uint8_t* big_part = (uint8_t*)c->big_part.p;
@@ -623,9 +645,11 @@ void h2agg_destroy(h2agg_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     for (int k = 0; k < h2agg_ctx::TAIL_SLOTS; ++k)
         if (c->tail_streams[k]) hipStreamSynchronize(c->tail_streams[k]);
+    static_assert(h2agg_ctx::TAIL_SLOTS == 3, "the list below names every tail slot's buffers");
     DevBuf* bufs[] = {&c->in_a,  &c->in_b,     &c->in_c,     &c->out,   &c->tmp_bases, &c->hist,
                       &c->offs,  &c->pmeta,    &c->item_idx, &c->item_sub, &c->order,  &c->entries,
-                      &c->buckets, &c->segsum, &c->wsum,     &c->big_list, &c->big_keys, &c->big_part, &c->glv_buf, &c->parts, &c->small, &c->endo_buf, &c->tile_counts,
+                      &c->buckets[0], &c->buckets[1], &c->buckets[2], &c->segsum[0], &c->segsum[1], &c->segsum[2],
+                      &c->wsum[0], &c->wsum[1], &c->wsum[2], &c->big_list, &c->big_keys, &c->big_part, &c->glv_buf, &c->parts, &c->small, &c->endo_buf, &c->tile_counts,
                       &c->sch_regs, &c->sch_in, &c->sch_scalars[0], &c->sch_scalars[1], &c->sch_bases[0], &c->sch_bases[1]};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
@@ -674,8 +698,10 @@ int h2agg_set_stream(h2agg_ctx* c, void* hip_stream) try {
 int h2agg_synchronize(h2agg_ctx* c) try {
     TRY(bind(c));
     TRY(join_tails(c));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return H2AGG_OK;
+    // also the place where status flags raised by asynchronous calls surface (e.g. a scalar >= r handed to
+    // h2agg_g1_msm_device_async -> H2AGG_ERR_NONCANONICAL here)
+    TRY(clear_flags(c));
+    return finish(c);
 } catch (const std::bad_alloc&) {
     return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
 } catch (...) {

@@ -576,6 +576,10 @@ struct Schema {
                 return false;
             }
             int64_t sv = out.v[start].scalar;
+            if (sv < 0) {   // a bare Commitment on the "scalar" side: the reference unwraps None
+                err = "Mul: the scalar side carries no scalar (reference: `s.unwrap()` on None, evaluation.rs:284-288)";
+                return false;
+            }
             out.pop();
             if (scalar >= 0) sv = tape.mul((uint32_t)scalar, (uint32_t)sv);
             return eval_prepare(rem, sv, out, list);
