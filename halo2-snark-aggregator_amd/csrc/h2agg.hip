@@ -188,7 +188,7 @@ int finish(h2agg_ctx* c) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     uint32_t f[3];
     memcpy(f, c->h_pinned + 2048, 12);
-    if (f[2]) HIP_TRY(c, hipMemsetAsync(c->d_flags + 2, 0, 4, c->stream));   // reported once
+    if (f[0] | f[2]) HIP_TRY(c, hipMemsetAsync(c->d_flags, 0, 12, c->stream));   // reported once, here
     if (f[0]) return flags_to_status(c, f[0], false);
     return flags_to_status(c, f[2], true);
 }
