@@ -109,6 +109,9 @@ def load_library():
         "h2agg_g1_batch_to_affine_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p]),
         "h2agg_schema_names_joined": (C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t]),
         "h2agg_schema_point_list_len": (C.c_size_t, [C.c_void_p]),
+        "h2agg_pairing_check": (i32, [ctxp, u8p, u8p, sz, C.POINTER(i32)]),
+        "h2agg_pairing_product": (i32, [ctxp, u8p, u8p, sz, vp]),
+        "h2agg_final_pair_check": (i32, [ctxp, u8p, u8p, u8p, u8p, C.POINTER(i32)]),
         "h2agg_msm_configure": (i32, [ctxp, i32, i32, i32]),
         "h2agg_msm_configure_glv": (i32, [ctxp, i32]),
         "h2agg_msm_configure_lanes_per_bucket": (i32, [ctxp, i32]),
@@ -365,6 +368,34 @@ class H2Agg:
 
     def g1_msm_device_async(self, handle: int, d_scalars_ptr: int, n: int, d_out_ptr: int):
         self._check(self._lib.h2agg_g1_msm_device_async(self._ctx, handle, d_scalars_ptr, n, d_out_ptr))
+
+    # ------------------------------------------------------------------ pairing (host)
+    def pairing_check(self, g1_aff: bytes, g2_aff: bytes) -> bool:
+        """prod e(g1_i, g2_i) == 1  (verify.rs:733-739 / EIP-197); G2 = x.c0 || x.c1 || y.c0 || y.c1"""
+        n = len(g1_aff) // 64
+        _need(g1_aff, 64 * n, "g1_aff")
+        _need(g2_aff, 128 * n, "g2_aff")
+        ok = C.c_int()
+        self._check(self._lib.h2agg_pairing_check(self._ctx, g1_aff, g2_aff, n, C.byref(ok)))
+        return bool(ok.value)
+
+    def pairing_product(self, g1_aff: bytes, g2_aff: bytes) -> bytes:
+        n = len(g1_aff) // 64
+        _need(g1_aff, 64 * n, "g1_aff")
+        _need(g2_aff, 128 * n, "g2_aff")
+        out = C.create_string_buffer(384)
+        self._check(self._lib.h2agg_pairing_product(self._ctx, g1_aff, g2_aff, n, out))
+        return out.raw
+
+    def final_pair_check(self, left_aff: bytes, right_aff: bytes, s_g2: bytes, g2: bytes) -> bool:
+        """e(left, [s]_2) * e(right, -[1]_2) == 1"""
+        _need(left_aff, 64, "left_aff")
+        _need(right_aff, 64, "right_aff")
+        _need(s_g2, 128, "s_g2")
+        _need(g2, 128, "g2")
+        ok = C.c_int()
+        self._check(self._lib.h2agg_final_pair_check(self._ctx, left_aff, right_aff, s_g2, g2, C.byref(ok)))
+        return bool(ok.value)
 
     # ------------------------------------------------------------------ tuning / measurement
     def g1_msm_device_batch_async(self, handle: int, d_scalars_ptr: int, n: int, batch: int, d_out_ptr: int):

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "msm_kernels.cuh"
+#include "pairing.hpp"
 #include "schema.cuh"
 
 using namespace h2agg;
@@ -1445,6 +1446,75 @@ int h2agg_profile_stage_get(h2agg_ctx* c, int i, double* total_ms, uint64_t* lau
     profile_harvest_all(c);
     if (total_ms) *total_ms = c->stage_ms[i];
     if (launches) *launches = c->stage_launches[i];
+    return H2AGG_OK;
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
+}
+
+// ---------------------------------------------------------------- pairing check (host)
+namespace {
+int pairing_load(h2agg_ctx* c, const uint8_t* g1_aff, const uint8_t* g2_aff, size_t n,
+                 std::vector<pairing::G1Affine>& ps, std::vector<pairing::G2Affine>& qs) {
+    if (n && (!g1_aff || !g2_aff)) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    ps.resize(n);
+    qs.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+        const int r1 = pairing::load_g1(g1_aff + 64 * i, ps[i]);
+        if (r1 == 1) return fail(c, H2AGG_ERR_NONCANONICAL, "pairing: G1 coordinate >= p");
+        if (r1) return fail(c, H2AGG_ERR_BAD_POINT, "pairing: G1 point not on the curve");
+        const int r2 = pairing::load_g2(g2_aff + 128 * i, qs[i]);
+        if (r2 == 1) return fail(c, H2AGG_ERR_NONCANONICAL, "pairing: G2 coordinate >= p");
+        if (r2 == 2) return fail(c, H2AGG_ERR_BAD_POINT, "pairing: G2 point not on the twist");
+        if (r2) return fail(c, H2AGG_ERR_BAD_POINT, "pairing: G2 point outside the order-r subgroup");
+    }
+    return H2AGG_OK;
+}
+}  // namespace
+
+int h2agg_pairing_product(h2agg_ctx* c, const uint8_t* g1_aff, const uint8_t* g2_aff, size_t n, uint8_t out_gt[384]) try {
+    if (!out_gt) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    std::vector<pairing::G1Affine> ps;
+    std::vector<pairing::G2Affine> qs;
+    TRY(pairing_load(c, g1_aff, g2_aff, n, ps, qs));
+    pairing::f12_to_bytes(pairing::final_exponentiation(pairing::multi_miller_loop(ps, qs)), out_gt);
+    return H2AGG_OK;
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
+}
+
+int h2agg_pairing_check(h2agg_ctx* c, const uint8_t* g1_aff, const uint8_t* g2_aff, size_t n, int* ok) try {
+    if (!ok) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    *ok = 0;
+    std::vector<pairing::G1Affine> ps;
+    std::vector<pairing::G2Affine> qs;
+    TRY(pairing_load(c, g1_aff, g2_aff, n, ps, qs));
+    *ok = pairing::f12_is_one(pairing::final_exponentiation(pairing::multi_miller_loop(ps, qs))) ? 1 : 0;
+    return H2AGG_OK;
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
+}
+
+// e(left, [s]_2) * e(right, -[1]_2) == 1 ?   (verify.rs:733-739: `n_g2_prepared = -params.g2()`)
+int h2agg_final_pair_check(h2agg_ctx* c, const uint8_t left_aff[64], const uint8_t right_aff[64], const uint8_t s_g2[128],
+                           const uint8_t g2[128], int* ok) try {
+    if (!ok || !left_aff || !right_aff || !s_g2 || !g2) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    *ok = 0;
+    uint8_t g1s[128], g2s[256];
+    memcpy(g1s, left_aff, 64);
+    memcpy(g1s + 64, right_aff, 64);
+    memcpy(g2s, s_g2, 128);
+    memcpy(g2s + 128, g2, 128);
+    std::vector<pairing::G1Affine> ps;
+    std::vector<pairing::G2Affine> qs;
+    TRY(pairing_load(c, g1s, g2s, 2, ps, qs));
+    if (!qs[1].inf) qs[1].y = pairing::f2_neg(qs[1].y);
+    *ok = pairing::f12_is_one(pairing::final_exponentiation(pairing::multi_miller_loop(ps, qs))) ? 1 : 0;
     return H2AGG_OK;
 } catch (const std::bad_alloc&) {
     return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI

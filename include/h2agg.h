@@ -227,6 +227,24 @@ const char* h2agg_schema_name(h2agg_schema* s, size_t i);
 size_t h2agg_schema_names_joined(h2agg_schema* s, char* out, size_t cap);
 size_t h2agg_schema_point_list_len(h2agg_schema* s);
 
+/* ---- pairing check (host arithmetic, no device work) ---------------------------
+ * replaces: `E::multi_miller_loop(&[(&left_v, &s_g2_prepared), (&right_v, &n_g2_prepared)]).final_exponentiation()
+ * .is_identity()` (halo2-snark-aggregator-api/src/systems/halo2/verify.rs:733-739) and the production assert
+ * (halo2-snark-aggregator-circuit/src/verify_circuit.rs:175-199): BN254 optimal-ate pairing, exact final exponentiation.
+ * Encodings: G1 affine as everywhere (64 B); G2 affine = x.c0 || x.c1 || y.c0 || y.c1 (128 B, canonical little-endian,
+ * halo2curves G2Affine { x: Fq2 { c0, c1 }, y }; identity = 128 zero bytes).  Points are validated: coordinate >= p ->
+ * H2AGG_ERR_NONCANONICAL; not on the curve / twist, or a G2 point outside the order-r subgroup -> H2AGG_ERR_BAD_POINT.
+ * `ctx` only receives the error message and may be NULL.
+ * h2agg_pairing_check: *ok = (prod_i e(g1_i, g2_i) == 1), the shape of EIP-197's precompile (n == 0 -> 1).
+ * h2agg_pairing_product: the GT element itself, 12 x 32 B canonical in tower order (c0.c0.c0, c0.c0.c1, c0.c1.c0, ...,
+ *   c1.c2.c1; Fq12 = Fq6[w]/(w^2 - v), Fq6 = Fq2[v]/(v^3 - (9 + u)), Fq2 = Fq[u]/(u^2 + 1)).
+ * h2agg_final_pair_check: *ok = (e(left, s_g2) * e(right, -g2) == 1) — `params.s_g2()`, `params.g2()` as the caller
+ *   holds them (ParamsKZG); the negation of g2 happens inside, as in the reference. */
+int h2agg_pairing_check(h2agg_ctx* ctx, const uint8_t* g1_aff, const uint8_t* g2_aff, size_t n, int* ok);
+int h2agg_pairing_product(h2agg_ctx* ctx, const uint8_t* g1_aff, const uint8_t* g2_aff, size_t n, uint8_t out_gt[384]);
+int h2agg_final_pair_check(h2agg_ctx* ctx, const uint8_t left_aff[64], const uint8_t right_aff[64],
+                           const uint8_t s_g2[128], const uint8_t g2[128], int* ok);
+
 /* ---- Fr expression tape ------------------------------------------------------
  * A straight-line program over Fr, run on the device by the interpreter EvaluationQuerySchema::eval records into:
  * registers 0 .. nconst-1 are the inputs (canonical, 32 B each), register nconst + k is the result of op k;

@@ -1,0 +1,131 @@
+"""The product's pairing check (csrc/pairing.hpp through the C ABI: h2agg_pairing_check / _product / h2agg_final_pair_check)
+against the oracle's independent flat-basis pairing and the public EIP-197 vectors.  Host arithmetic only — no device
+work — so this runs wherever libh2agg.so loads (ctx = NULL is allowed for these entry points)."""
+import ctypes as C
+import json
+import os
+
+import pytest
+
+from oracle import bn254 as O
+from oracle import pairing as E
+from tests.test_oracle_pairing import KATS, parse_pairs
+
+
+@pytest.fixture(scope="module")
+def lib(pkg):
+    return pkg.load_library()
+
+
+def g2b(q):
+    if q is O.INF:
+        return bytes(128)
+    return b"".join(O.fe_to_bytes(v) for v in (q[0][0], q[0][1], q[1][0], q[1][1]))
+
+
+def enc(pairs):
+    return b"".join(O.aff_to_bytes(p) for p, _ in pairs), b"".join(g2b(q) for _, q in pairs)
+
+
+def check(lib, pairs):
+    g1, g2 = enc(pairs)
+    ok = C.c_int(-1)
+    rc = lib.h2agg_pairing_check(None, g1, g2, len(pairs), C.byref(ok))
+    return rc, ok.value
+
+
+def product(lib, pairs):
+    g1, g2 = enc(pairs)
+    out = C.create_string_buffer(384)
+    assert lib.h2agg_pairing_product(None, g1, g2, len(pairs), out) == 0
+    return E.f12_from_tower([int.from_bytes(out.raw[32 * i:32 * i + 32], "little") for i in range(12)])
+
+
+def test_eip197_vectors(lib):
+    for k in KATS["pairing"]:
+        rc, ok = check(lib, parse_pairs(k["input"]))
+        assert rc == 0 and bool(ok) is k["expect"], k["name"]
+
+
+def test_gt_element_equals_oracle(lib):
+    """not only the boolean: the exact final exponentiation makes the GT element the textbook e(P, Q)"""
+    rng = O.SplitMix64(0xE197)
+    e = E.pairing(E.G2, O.G1)
+    assert product(lib, [(O.G1, E.G2)]) == e
+    a, b = rng.fr(), rng.fr()
+    pa, qb = O.scalar_mul(a, O.G1), E.g2_mul(b, E.G2)
+    assert product(lib, [(pa, qb)]) == E.pairing(qb, pa) == E.f12_pow(e, a * b % O.R)
+    # a product of three pairs, one with an identity on each side
+    pairs = [(pa, E.G2), (O.G1, qb), (O.INF, qb), (pa, O.INF)]
+    want = E.final_exponentiation(E.f12_mul(E.miller_loop(E.twist(E.G2), E.cast_g1(pa)),
+                                            E.miller_loop(E.twist(qb), E.cast_g1(O.G1))))
+    assert product(lib, pairs) == want
+
+
+def test_kzg_shaped_check(lib, pkg):
+    """the reference's check (verify.rs:733-739): e(left, [s]_2) * e(right, -[1]_2) == 1 with right = s * left"""
+    s = 0x5EC2E7
+    s_g2 = E.g2_mul(s, E.G2)
+    left = O.scalar_mul(424242, O.G1)
+    right = O.scalar_mul(s, left)
+    ok = C.c_int(-1)
+    assert lib.h2agg_final_pair_check(None, O.aff_to_bytes(left), O.aff_to_bytes(right), g2b(s_g2), g2b(E.G2),
+                                      C.byref(ok)) == 0 and ok.value == 1
+    wrong = O.add(right, O.G1)
+    assert lib.h2agg_final_pair_check(None, O.aff_to_bytes(left), O.aff_to_bytes(wrong), g2b(s_g2), g2b(E.G2),
+                                      C.byref(ok)) == 0 and ok.value == 0
+    assert E.pairing_check([(left, s_g2), (O.neg(right), E.G2)]) and not E.pairing_check([(left, s_g2), (O.neg(wrong), E.G2)])
+
+
+def test_point_validation(lib, pkg):
+    ok = C.c_int()
+    g1, g2 = O.aff_to_bytes(O.G1), g2b(E.G2)
+    bad = bytearray(g2)
+    bad[0] ^= 1                                                   # off the twist
+    assert lib.h2agg_pairing_check(None, g1, bytes(bad), 1, C.byref(ok)) == pkg.ERR_BAD_POINT
+    bad1 = bytearray(g1)
+    bad1[0] ^= 1                                                  # off the curve
+    assert lib.h2agg_pairing_check(None, bytes(bad1), g2, 1, C.byref(ok)) == pkg.ERR_BAD_POINT
+    big = O.P.to_bytes(32, "little") + g1[32:]                    # x = p: not canonical
+    assert lib.h2agg_pairing_check(None, big, g2, 1, C.byref(ok)) == pkg.ERR_NONCANONICAL
+    # a twist point outside the order-r subgroup: the twist has cofactor 2p - r, so a random twist point is (with
+    # overwhelming probability) not in G2
+    x = (5, 7)
+    while True:
+        rhs = E.f2_add(E.f2_mul(E.f2_mul(x, x), x), E.B2)
+        # sqrt in Fq2 via the norm: try candidates y = rhs^((p^2 + 7) / 16)-style is overkill — brute force x instead
+        y = _f2_sqrt(rhs)
+        if y is not None:
+            break
+        x = (x[0] + 1, x[1])
+    q = (x, y)
+    assert E.g2_on_curve(q) and E.g2_mul(O.R, q) is not O.INF
+    assert lib.h2agg_pairing_check(None, g1, g2b(q), 1, C.byref(ok)) == pkg.ERR_BAD_POINT
+    # empty product
+    assert lib.h2agg_pairing_check(None, None, None, 0, C.byref(ok)) == 0 and ok.value == 1
+
+
+def _f2_sqrt(a):
+    """square root in Fq2 = Fq[u]/(u^2 + 1), p = 3 mod 4 (complex method); None if a is not a square"""
+    p = O.P
+    if a == (0, 0):
+        return (0, 0)
+    a0, a1 = a
+    if a1 == 0:
+        r = pow(a0, (p + 1) // 4, p)
+        if r * r % p == a0:
+            return (r, 0)
+        r = pow((-a0) % p, (p + 1) // 4, p)
+        return (0, r) if r * r % p == (-a0) % p else None
+    n = (a0 * a0 + a1 * a1) % p
+    s = pow(n, (p + 1) // 4, p)
+    if s * s % p != n:
+        return None
+    for sign in (1, -1):
+        d = (a0 + sign * s) * pow(2, p - 2, p) % p
+        x0 = pow(d, (p + 1) // 4, p)
+        if x0 * x0 % p == d and x0:
+            x1 = a1 * pow(2 * x0, p - 2, p) % p
+            if E.f2_mul((x0, x1), (x0, x1)) == (a0 % p, a1 % p):
+                return (x0, x1)
+    return None
