@@ -437,11 +437,12 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     if (staged) {
         // LDS-staged sort: keys leave the CU as contiguous runs (n fits the packed item's index field)
         const size_t lds1 = (size_t)(4 * SORT_MAX_PW + STAGE_ITEMS_L1) * 4;
-        const size_t lds2 = (size_t)(SORT_MAX_SB + BLOCK + STAGE_ITEMS) * 4;
+        constexpr int SORT2_TB = 1024;   // level-2 workgroup size (one workgroup per CU: see k_bucket_sort_staged)
+        const size_t lds2 = (size_t)(SORT_MAX_SB + SORT2_TB + STAGE_ITEMS) * 4;
         if (!c->staged_attr_set) {
             HIP_TRY(c, hipFuncSetAttribute((const void*)k_part_scatter_staged,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1));
-            HIP_TRY(c, hipFuncSetAttribute((const void*)k_bucket_sort_staged,
+            HIP_TRY(c, hipFuncSetAttribute((const void*)k_bucket_sort_staged<SORT2_TB>,
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));
             c->staged_attr_set = true;
         }
@@ -456,7 +457,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         }
         {
             StageTimer t(c, ST_BUCKET_SORT);
-            hipLaunchKernelGGL(k_bucket_sort_staged, dim3(sp.PW), dim3(BLOCK), lds2, st, pstart, item_idx, sp, idx_bits,
+            hipLaunchKernelGGL(k_bucket_sort_staged<SORT2_TB>, dim3(sp.PW), dim3(SORT2_TB), lds2, st, pstart, item_idx, sp, idx_bits,
                                p.NB, hist, offs, entries);
         }
     } else {

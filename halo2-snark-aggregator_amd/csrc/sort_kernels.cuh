@@ -215,6 +215,61 @@ FP_INLINE void msm_for_each_digit(U256 s, int c, int W, bool glv, F&& f) {
     }
 }
 
+// The same recoding, four digits at a time: `emit4(w0, nd, bkt[4], neg[4], ok[4], endo)` is called with up to four
+// consecutive windows' digits so that the caller can put FOUR LDS atomics (and then four dependent stores) in flight
+// instead of one: with `#pragma unroll 1` over single digits every returning atomic's latency was exposed, and a level-1
+// workgroup (2 waves per SIMD at tile = 2048) has nobody to hide it behind.
+template <class F>
+FP_INLINE void msm_for_each_digit4(U256 s, int c, int W, bool glv, F&& emit4) {
+    const uint32_t mask = (1u << c) - 1u;
+    const uint32_t half = 1u << (c - 1);
+    const int nh = glv ? 2 : 1;
+#pragma unroll 1
+    for (int h = 0; h < nh; ++h) {
+        uint32_t m[8];
+        bool sgn = false;
+        if (glv) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) m[i] = s.w[4 * h + i];
+#pragma unroll
+            for (int i = 4; i < 8; ++i) m[i] = 0;
+            sgn = (m[3] >> 31) != 0;
+            m[3] &= 0x7fffffffu;
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) m[i] = s.w[i];
+        }
+        uint32_t carry = 0;
+#pragma unroll 1
+        for (int w0 = 0; w0 < W; w0 += 4) {
+            uint32_t bkt[4];
+            bool neg[4], ok[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint32_t raw = (m[0] & mask) + carry;
+                if (glv) {
+                    m[0] = (m[0] >> c) | (m[1] << (32 - c));
+                    m[1] = (m[1] >> c) | (m[2] << (32 - c));
+                    m[2] = (m[2] >> c) | (m[3] << (32 - c));
+                    m[3] >>= c;
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 7; ++i) m[i] = (m[i] >> c) | (m[i + 1] << (32 - c));
+                    m[7] >>= c;
+                }
+                const bool ng = raw > half;
+                const bool in = w0 + j < W;      // past the top window everything is zero: raw = carry = 0
+                carry = (ng && in) ? 1u : 0u;
+                const uint32_t mag = ng ? ((1u << c) - raw) : raw;
+                ok[j] = in && mag != 0;
+                bkt[j] = mag - 1u;
+                neg[j] = ng != sgn;
+            }
+            emit4(w0, bkt, neg, ok, h != 0);
+        }
+    }
+}
+
 // packed level-1 sort item (32 bits): [ sub-bucket | neg | endo (only when glv) | idx : idx_bits ]
 FP_INLINE uint32_t pack_item(uint32_t sub, bool neg, bool endo, uint32_t idx, int idx_bits, bool glv) {
     const int fb = glv ? 2 : 1;
@@ -529,40 +584,48 @@ __global__ void __launch_bounds__(BLOCK) k_part_scatter_packed(const uint8_t* __
     __syncthreads();
     const uint32_t submask = sp.SB - 1u;
     TILE_SCALARS_BEGIN(threadIdx.x)
-        msm_for_each_digit(s, c, W, sp.glv, [&](int w, uint32_t b, bool neg, bool endo) {
-            const uint32_t p = WIN(w) * sp.ppw + (b >> sp.sub_bits);
-            const uint32_t pos = basep[p] + atomicAdd(&cnt[p], 1u);
-            items[pos] = pack_item(b & submask, neg, endo, BASE(w), idx_bits, sp.glv);
+        msm_for_each_digit4(s, c, W, sp.glv, [&](int w0, const uint32_t (&b)[4], const bool (&neg)[4], const bool (&ok)[4], bool endo) {
+            uint32_t p[4], r[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) p[j] = ok[j] ? WIN(w0 + j) * sp.ppw + (b[j] >> sp.sub_bits) : 0u;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) r[j] = ok[j] ? basep[p[j]] + atomicAdd(&cnt[p[j]], 1u) : 0u;   // four in flight
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (ok[j]) items[r[j]] = pack_item(b[j] & submask, neg[j], endo, BASE(w0 + j), idx_bits, sp.glv);
         });
     TILE_SCALARS_END
 }
 
-__global__ void __launch_bounds__(BLOCK) k_bucket_sort_staged(const uint32_t* __restrict__ pstart,
+// TB threads per workgroup: the 128-KiB stage allows ONE workgroup per CU, so its size is the CU's whole occupancy —
+// 256 threads left one wave per SIMD to hide the item loads and the LDS atomics' round trips behind (round 2: 1024).
+template <int TB>
+__global__ void __launch_bounds__(TB) k_bucket_sort_staged(const uint32_t* __restrict__ pstart,
                                                               const uint32_t* __restrict__ items, SortPlan sp,
                                                               int idx_bits, uint32_t NB, uint32_t* __restrict__ hist,
                                                               uint32_t* __restrict__ offs,
                                                               uint32_t* __restrict__ entries) {
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* h = smem;                         // [SORT_MAX_SB]
-    uint32_t* scan = smem + SORT_MAX_SB;        // [BLOCK]
-    uint32_t* sorted = smem + SORT_MAX_SB + BLOCK;  // [STAGE_ITEMS]
+    uint32_t* scan = smem + SORT_MAX_SB;        // [TB]
+    uint32_t* sorted = smem + SORT_MAX_SB + TB;  // [STAGE_ITEMS]
     const uint32_t p = blockIdx.x;
     const uint32_t start = pstart[p], end = pstart[p + 1], total = end - start;
     const int tid = threadIdx.x;
     const uint32_t idxmask = (1u << idx_bits) - 1u;
     const int fb = sp.glv ? 2 : 1;  // flag bits between the index and the sub-bucket: neg, and endo under GLV
-    for (uint32_t s = tid; s < sp.SB; s += BLOCK) h[s] = 0;
+    for (uint32_t s = tid; s < sp.SB; s += TB) h[s] = 0;
     __syncthreads();
-    for (uint32_t k0 = start + tid; k0 < end; k0 += 8 * BLOCK) {  // 8 independent loads in flight
+    for (uint32_t k0 = start + tid; k0 < end; k0 += 8 * TB) {  // 8 independent loads in flight
         uint32_t it[8];  // every 32-bit pattern is a legal item (sub = max, negative, last index): no sentinel
 #pragma unroll
-        for (int j = 0; j < 8; ++j) it[j] = (k0 + j * BLOCK < end) ? items[k0 + j * BLOCK] : 0u;
+        for (int j = 0; j < 8; ++j) it[j] = (k0 + j * TB < end) ? items[k0 + j * TB] : 0u;
 #pragma unroll
         for (int j = 0; j < 8; ++j)
-            if (k0 + j * BLOCK < end) atomicAdd(&h[it[j] >> (idx_bits + fb)], 1u);
+            if (k0 + j * TB < end) atomicAdd(&h[it[j] >> (idx_bits + fb)], 1u);
     }
     __syncthreads();
-    const uint32_t per = (sp.SB + BLOCK - 1) / BLOCK;
+    const uint32_t per = (sp.SB + TB - 1) / TB;
     const uint32_t lo = tid * per;
     uint32_t mine = 0;
     for (uint32_t j = 0; j < per; ++j)
@@ -570,7 +633,7 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_sort_staged(const uint32_t* __
     scan[tid] = mine;
     __syncthreads();
 #pragma unroll 1
-    for (int d = 1; d < BLOCK; d <<= 1) {
+    for (int d = 1; d < TB; d <<= 1) {
         uint32_t t = (tid >= d) ? scan[tid - d] : 0u;
         __syncthreads();
         scan[tid] += t;
@@ -591,14 +654,14 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_sort_staged(const uint32_t* __
     }
     __syncthreads();
     const bool staged = total <= (uint32_t)STAGE_ITEMS;
-    for (uint32_t k0 = start + tid; k0 < end; k0 += 8 * BLOCK) {
+    for (uint32_t k0 = start + tid; k0 < end; k0 += 8 * TB) {
         uint32_t itv[8];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) itv[j] = (k0 + j * BLOCK < end) ? items[k0 + j * BLOCK] : 0u;
+        for (int j = 0; j < 8; ++j) itv[j] = (k0 + j * TB < end) ? items[k0 + j * TB] : 0u;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const uint32_t it = itv[j];
-            if (k0 + j * BLOCK >= end) continue;
+            if (k0 + j * TB >= end) continue;
             const uint32_t r = atomicAdd(&h[it >> (idx_bits + fb)], 1u);
             const uint32_t e = (it & idxmask) | ((sp.glv ? ((it >> idx_bits) & 1u) : 0u) << 30) |
                                (((it >> (idx_bits + fb - 1)) & 1u) << 31);
@@ -608,7 +671,7 @@ __global__ void __launch_bounds__(BLOCK) k_bucket_sort_staged(const uint32_t* __
     }
     if (staged) {
         __syncthreads();
-        for (uint32_t k = tid; k < total; k += BLOCK) entries[start + k] = sorted[k];
+        for (uint32_t k = tid; k < total; k += TB) entries[start + k] = sorted[k];
     }
 }
 
