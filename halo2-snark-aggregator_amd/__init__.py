@@ -109,6 +109,12 @@ def load_library():
         "h2agg_g1_batch_to_affine_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p]),
         "h2agg_schema_names_joined": (C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t]),
         "h2agg_schema_point_list_len": (C.c_size_t, [C.c_void_p]),
+        "h2agg_comm_unique_id": (i32, [vp]),
+        "h2agg_comm_init_rank": (i32, [ctxp, u8p, i32, i32]),
+        "h2agg_comm_create": (i32, [C.POINTER(i32), i32, C.POINTER(ctxp)]),
+        "h2agg_comm_size": (i32, [ctxp]),
+        "h2agg_comm_rank": (i32, [ctxp]),
+        "h2agg_allgather_add_points": (i32, [C.POINTER(ctxp), i32, u8p, sz, vp]),
         "h2agg_pairing_check": (i32, [ctxp, u8p, u8p, sz, C.POINTER(i32)]),
         "h2agg_pairing_product": (i32, [ctxp, u8p, u8p, sz, vp]),
         "h2agg_final_pair_check": (i32, [ctxp, u8p, u8p, u8p, u8p, C.POINTER(i32)]),
@@ -369,6 +375,33 @@ class H2Agg:
     def g1_msm_device_async(self, handle: int, d_scalars_ptr: int, n: int, d_out_ptr: int):
         self._check(self._lib.h2agg_g1_msm_device_async(self._ctx, handle, d_scalars_ptr, n, d_out_ptr))
 
+    # ------------------------------------------------------------------ multi-GPU exchange (RCCL inside the C ABI)
+    @staticmethod
+    def comm_unique_id() -> bytes:
+        """rank 0: the 128-byte RCCL id every rank passes to comm_init_rank"""
+        out = C.create_string_buffer(128)
+        rc = load_library().h2agg_comm_unique_id(out)
+        if rc != OK:
+            raise H2AggError(rc, "h2agg_comm_unique_id failed (RCCL not available?)")
+        return out.raw
+
+    def comm_init_rank(self, unique_id: bytes, rank: int, nranks: int):
+        _need(unique_id, 128, "unique_id")
+        self._check(self._lib.h2agg_comm_init_rank(self._ctx, unique_id, rank, nranks))
+
+    def comm_size(self) -> int:
+        return self._lib.h2agg_comm_size(self._ctx)
+
+    def allgather_add_points(self, partial_jac: bytes) -> bytes:
+        """this rank's partial accumulators (96 B each) -> affine sums over all ranks (64 B each), same on every rank:
+        the one collective of the sharded aggregation (all-gather over RCCL + local EC adds)"""
+        npts = len(partial_jac) // 96
+        _need(partial_jac, 96 * npts, "partial_jac")
+        out = C.create_string_buffer(max(64 * npts, 1))
+        arr = (C.c_void_p * 1)(self._ctx)
+        self._check(self._lib.h2agg_allgather_add_points(arr, 1, partial_jac, npts, out))
+        return out.raw[:64 * npts]
+
     # ------------------------------------------------------------------ pairing (host)
     def pairing_check(self, g1_aff: bytes, g2_aff: bytes) -> bool:
         """prod e(g1_i, g2_i) == 1  (verify.rs:733-739 / EIP-197); G2 = x.c0 || x.c1 || y.c0 || y.c1"""
@@ -434,6 +467,46 @@ class H2Agg:
             self._check(self._lib.h2agg_profile_stage_get(self._ctx, i, C.byref(ms), C.byref(cnt)))
             out[self._lib.h2agg_profile_stage_name(self._ctx, i).decode()] = (ms.value, cnt.value)
         return out
+
+
+class H2AggGroup:
+    """One process driving several GPUs: h2agg_comm_create = a context per device + ncclCommInitAll."""
+
+    def __init__(self, devices: Sequence[int]):
+        lib = load_library()
+        n = len(devices)
+        devs = (C.c_int * n)(*devices)
+        ctxs = (C.c_void_p * n)()
+        rc = lib.h2agg_comm_create(devs, n, ctxs)
+        if rc != OK:
+            msg = (lib.h2agg_last_error(ctxs[0]) or b"").decode() if ctxs[0] else "RCCL or a device is not available"
+            for cx in ctxs:
+                if cx:
+                    lib.h2agg_destroy(cx)
+            raise H2AggError(rc, "h2agg_comm_create: " + msg)
+        self._lib, self._ctxs = lib, ctxs
+        self.engines = []
+        for i, d in enumerate(devices):          # wrap the contexts so the whole H2Agg surface is usable per device
+            e = H2Agg.__new__(H2Agg)
+            e._lib, e._ctx, e.device = lib, C.c_void_p(ctxs[i]), d
+            self.engines.append(e)
+
+    def allgather_add_points(self, partials: Sequence[bytes]) -> bytes:
+        """partials[rank] = that rank's npts Jacobian points -> npts affine sums"""
+        n = len(self.engines)
+        if len(partials) != n:
+            raise ValueError("one partial buffer per device")
+        npts = len(partials[0]) // 96
+        for p in partials:
+            _need(p, 96 * npts, "partial")
+        out = C.create_string_buffer(max(64 * npts, 1))
+        self.engines[0]._check(self._lib.h2agg_allgather_add_points(self._ctxs, n, b"".join(partials), npts, out))
+        return out.raw[:64 * npts]
+
+    def close(self):
+        for e in self.engines:
+            e.close()
+        self.engines = []
 
 
 # ---------------------------------------------------------------------------------------------------

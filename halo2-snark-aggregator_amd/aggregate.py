@@ -117,13 +117,21 @@ class GpuBackend:
         return self.eng.g1_batch_to_affine(self.eng.g1_sum(jac))
 
 
-def aggregate_sharded(backend, build_local_proofs, n_total: int, lam: bytes, dist=None, device=None):
+def aggregate_sharded(backend, build_local_proofs, n_total: int, lam: bytes, dist=None, device=None, comm=None,
+                      rank_world=None):
     """Returns the final pair (left_aff, right_aff), identical on every rank.
 
     build_local_proofs(builder, indices) -> list of MultiOpenProof for those global proof indices.
-    dist: torch.distributed (initialised) or None for a single process."""
-    world = dist.get_world_size() if dist is not None else 1
-    rank = dist.get_rank() if dist is not None else 0
+    dist: torch.distributed (initialised) or None for a single process.
+    comm: an H2Agg engine holding an RCCL communicator (comm_init_rank): the exchange then happens INSIDE the C ABI
+          (h2agg_allgather_add_points: all-gather over RCCL + local EC adds) — what a non-Python host binds; rank / world
+          come from `rank_world` or, if that is None, from the communicator / dist."""
+    if comm is not None:
+        world = comm.comm_size()
+        rank = rank_world[0] if rank_world is not None else (dist.get_rank() if dist is not None else 0)
+    else:
+        world = dist.get_world_size() if dist is not None else 1
+        rank = dist.get_rank() if dist is not None else 0
     idx = shard_indices(n_total, world, rank)
     b = backend.new_builder()
     proofs = build_local_proofs(b, idx)
@@ -132,6 +140,11 @@ def aggregate_sharded(backend, build_local_proofs, n_total: int, lam: bytes, dis
         left, right = IDENTITY_AFF, IDENTITY_AFF
     else:
         left, right = backend.evaluate(b, local)
+    if comm is not None:
+        one = (1).to_bytes(32, "little")
+        jac = b"".join((p + one) if p != IDENTITY_AFF else (bytes(32) + one + bytes(32)) for p in (left, right))
+        out = comm.allgather_add_points(jac)                          # the only collective: 192 B per rank
+        return out[:64], out[64:]
     if dist is None:
         return left, right
     import torch

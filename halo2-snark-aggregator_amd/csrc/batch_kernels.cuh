@@ -383,6 +383,26 @@ __global__ void __launch_bounds__(BLOCK) k_g1_sum(const uint8_t* __restrict__ in
     if (threadIdx.x == 0) jac_store_canonical(out, jac_from_xyzz(tot));
 }
 
+// out_aff[k] = to_affine( sum_r in[(r * npts + k)] ), r < world: the local fold after the all-gather of the ranks' partial
+// accumulators (one workgroup per output point; arithmetic = MockEccChip::add + to_value, mock/arith/ecc.rs:30-37,64-66)
+__global__ void __launch_bounds__(BLOCK) k_g1_sum_strided_affine(const uint8_t* __restrict__ in, size_t world, size_t npts,
+                                                                 uint8_t* __restrict__ out_aff, uint32_t* flags) {
+    __shared__ uint32_t lds[XYZZ_WORDS * BLOCK];
+    const size_t k = blockIdx.x;
+    G1XYZZ acc = G1XYZZ::identity();
+    for (size_t r = threadIdx.x; r < world; r += BLOCK) {
+        const uint8_t* p = in + 96 * (r * npts + k);
+        if (jac_noncanonical(p)) atomicOr(flags, FLAG_NONCANONICAL);
+        acc = xyzz_add(acc, xyzz_from_jac(jac_load_canonical(p)));
+    }
+    G1XYZZ tot = block_sum_xyzz(acc, lds);
+    if (threadIdx.x == 0) {
+        const G1Affine a = affine_from_xyzz(tot);
+        fp_store<FqParams>(out_aff + 64 * k, fp_from_mont<FqParams>(a.x));
+        fp_store<FqParams>(out_aff + 64 * k + 32, fp_from_mont<FqParams>(a.y));
+    }
+}
+
 // ------------------------------------------------------------------ base tables (device resident, Montgomery)
 __global__ void __launch_bounds__(BLOCK) k_bases_to_mont(const uint8_t* __restrict__ in, size_t n,
                                                          uint8_t* __restrict__ out, uint32_t* flags) {

@@ -84,10 +84,15 @@ struct h2agg_ctx {
     std::map<uint64_t, Table> tables;
     uint64_t next_handle = 1;
 
+    // multi-GPU: this context's rank in an RCCL communicator (csrc/comm.inc); ncclComm_t kept opaque here
+    void* comm = nullptr;
+    int comm_rank = 0, comm_size = 0;
+
     // tuning
     int cfg_c = 0, cfg_seg = 0, cfg_big = 0, cfg_sub_bits = 0, cfg_tile = 0;
     int cfg_glv = 0;   // 0 = auto, 1 = on, -1 = off
-    int cfg_lpb = 0;   // lanes per bucket in the accumulate kernel: 0 = auto, 1 / 2 / 4
+    int cfg_lpb = 0;   // lanes per bucket in the accumulate kernel: 0 = auto, 1 / 2 / 4 / 8 / 16
+    uint32_t acc_slots = 0;   // one-wave workgroups of k_msm_accumulate the chip holds at once (occupancy x CUs)
     bool cfg_no_stage = false, cfg_stage_l1 = false, staged_attr_set = false;
 
     // optional overlap of the serial tail (k_msm_final) of MSM k with the bulk of MSM k+1
@@ -501,15 +506,36 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         TRY(ensure(c, c->parts, (size_t)p.NBT * lpb * XYZZ_BYTES));
         acc_out = (uint8_t*)c->parts.p;
     }
+    // wave-quantisation fill (see k_msm_accumulate): split the K longest buckets in two so that the one-wave workgroups
+    // come to a whole number of rounds of the chip's wave slots.  Worth it while K general additions (the combine) cost
+    // less than the idle slots of the last round: K <= NBT / 4 and runs long enough to halve.
+    constexpr int acc_block = 64;
+    uint32_t split_k = 0;
+    static const int split_env = getenv("H2AGG_SPLIT") ? atoi(getenv("H2AGG_SPLIT")) : 1;
+    if (split_env && lpb == 1 && ordered && nent >= (size_t)16 * p.NBT) {
+        if (!c->acc_slots) {
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_msm_accumulate, acc_block, 0) != hipSuccess ||
+                per_cu < 1)
+                per_cu = 12;
+            c->acc_slots = (uint32_t)per_cu * (uint32_t)c->cu_count;
+        }
+        const uint64_t lanes_per_round = (uint64_t)c->acc_slots * acc_block;
+        const uint64_t rounds = ((uint64_t)p.NBT + lanes_per_round - 1) / lanes_per_round;
+        const uint64_t k = rounds * lanes_per_round - p.NBT;
+        if (k > 0 && k <= p.NBT / 4) {
+            split_k = (uint32_t)k;
+            TRY(ensure(c, c->parts, (size_t)2 * split_k * XYZZ_BYTES));
+        }
+    }
     {
         StageTimer t(c, ST_ACCUM);
         // one-wave workgroups: a 4-wave workgroup needs a free slot on all four SIMDs of a CU at once and its waves retire
         // at different times; single waves fill any slot as it frees up (2^20 points: 1.74 -> 1.67 ms/step)
-        constexpr int acc_block = 64;
-        hipLaunchKernelGGL(k_msm_accumulate, dim3((unsigned)(((size_t)p.NBT * lpb + acc_block - 1) / acc_block)), dim3(acc_block), 0,
+        const size_t lanes = split_k ? (size_t)p.NBT + split_k : (size_t)p.NBT * lpb;
+        hipLaunchKernelGGL(k_msm_accumulate, dim3((unsigned)((lanes + acc_block - 1) / acc_block)), dim3(acc_block), 0,
                            st, d_bases, d_endo_x, entries, offs, hist, ordered ? order : (uint32_t*)nullptr, p.NBT, p.big, lpb, acc_out,
-                           big_list, big_keys,
-                           big_count);
+                           big_list, big_keys, big_count, split_k, (uint8_t*)c->parts.p);
     }
     {
         StageTimer t(c, ST_ACCUM_BIG);
@@ -521,6 +547,9 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         size_t gk = max_keys < cap ? max_keys : cap;
         hipLaunchKernelGGL(k_msm_big_combine, dim3((unsigned)gk), dim3(BLOCK), 0, st, big_part, big_keys, big_count,
                            acc_out, lpb);
+        if (split_k)
+            hipLaunchKernelGGL(k_msm_split_combine, dim3((split_k + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st,
+                               (const uint8_t*)c->parts.p, (const uint32_t*)order, (const uint32_t*)hist, p.big, split_k, buckets);
         if (lpb > 1)
             hipLaunchKernelGGL(k_msm_bucket_combine, dim3((p.NBT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st,
                                (const uint8_t*)acc_out, hist, p.NBT, p.big, lpb, buckets);
@@ -641,9 +670,15 @@ int h2agg_create(int device_ordinal, h2agg_ctx** out) try {
     return H2AGG_ERR_INVALID;
 }
 
+}  // extern "C"
+namespace {
+void comm_release(h2agg_ctx* c);   // csrc/comm.inc
+}
+extern "C" {
 void h2agg_destroy(h2agg_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
+    comm_release(c);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (int k = 0; k < h2agg_ctx::TAIL_SLOTS; ++k)
         if (c->tail_streams[k]) hipStreamSynchronize(c->tail_streams[k]);
@@ -1526,3 +1561,4 @@ int h2agg_final_pair_check(h2agg_ctx* c, const uint8_t left_aff[64], const uint8
 }  // extern "C"
 
 #include "schema_api.inc"
+#include "comm.inc"

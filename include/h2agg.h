@@ -227,6 +227,26 @@ const char* h2agg_schema_name(h2agg_schema* s, size_t i);
 size_t h2agg_schema_names_joined(h2agg_schema* s, char* out, size_t cap);
 size_t h2agg_schema_point_list_len(h2agg_schema* s);
 
+/* ---- multi-GPU exchange -----------------------------------------------------------
+ * The one collective of a sharded aggregation: every rank holds partial accumulators (the sharded form of the fold
+ * `acc = acc * lambda + proof`, halo2-snark-aggregator-api/src/systems/halo2/verify.rs:926-938, evaluated per shard);
+ * they are all-gathered over RCCL / xGMI and summed with the group law on every rank (RCCL has no reduction over group
+ * elements), for the caller halo2-snark-aggregator-circuit/src/verify_circuit.rs:114-201.  RCCL is dlopen'ed at the
+ * first call.
+ *   one process per GPU : rank 0 calls h2agg_comm_unique_id and hands the 128 bytes to the other ranks by the host's own
+ *                         means; every rank calls h2agg_comm_init_rank on its context; then
+ *                         h2agg_allgather_add_points(&ctx, 1, my_partials, npts, out).
+ *   one process, N GPUs : h2agg_comm_create(devices, n, ctxs) creates the N contexts and their communicator
+ *                         (ncclCommInitAll); h2agg_allgather_add_points(ctxs, n, partials[rank][npts], npts, out).
+ * partial_jac: canonical Jacobian points (96 B); out_aff[64 * k] = to_affine(sum over ranks of point k), identical on
+ * every rank.  The communicator is released by h2agg_destroy. */
+int h2agg_comm_unique_id(uint8_t out[128]);
+int h2agg_comm_init_rank(h2agg_ctx* ctx, const uint8_t id[128], int rank, int nranks);
+int h2agg_comm_create(const int* devices, int ndev, h2agg_ctx** ctxs_out);
+int h2agg_comm_size(h2agg_ctx* ctx);   /* 0 = no communicator */
+int h2agg_comm_rank(h2agg_ctx* ctx);
+int h2agg_allgather_add_points(h2agg_ctx** ctxs, int nctx, const uint8_t* partial_jac, size_t npts, uint8_t* out_aff);
+
 /* ---- pairing check (host arithmetic, no device work) ---------------------------
  * replaces: `E::multi_miller_loop(&[(&left_v, &s_g2_prepared), (&right_v, &n_g2_prepared)]).final_exponentiation()
  * .is_identity()` (halo2-snark-aggregator-api/src/systems/halo2/verify.rs:733-739) and the production assert
