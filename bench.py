@@ -57,45 +57,69 @@ def cpu_baseline(bases_aff: bytes, scalars: bytes, sample: int):
     return sample / dt, dt, out
 
 
-def measured_traffic(stage_name: str, log2n: int):
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (profiles/r01_traffic.json:
-    rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, collected separately); null when no measurement matches this run."""
+def csrc_sha() -> str:
+    """hash of the kernel sources: committed PMC evidence is only valid for the sources it was collected on"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(entry.PKG_DIR, "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".cuh", ".hip", ".inc", ".hpp")):
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(name.encode() + b"\0" + f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_evidence(stage_name: str, log2n: int):
+    """HBM-side bytes per launch (FETCH_SIZE / WRITE_SIZE) and the VALU view (SQ_INSTS_VALU, shader clock) of the dominant
+    kernel from the committed rocprofv3 --pmc passes (tools/profile_round.sh -> tools/make_traffic_json.py ->
+    profiles/r02_traffic.json).  The counters cannot be collected inside this process, so the file carries the hash of
+    the kernel sources it was measured on: a mismatch (kernel changed since) yields null + "stale" instead of silently
+    reporting old numbers."""
+    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_traffic.json")) as f:
+        with open(path) as f:
             t = json.load(f)
-        if log2n == 20 and stage_name == "msm_accumulate" and t["kernel"] == "k_msm_accumulate":
-            return t["bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
-    return None
-
-
-def valu_view(stage_name: str, log2n: int, avg_kernel_s: float):
-    """The roofline that actually bounds the dominant kernel: VALU issue.  Instruction count and shader clock come from
-    the committed PMC pass over the same command (profiles/r01_final_pmc_sq.txt: SQ_INSTS_VALU, GRBM_GUI_ACTIVE summed
-    over the 8 XCDs); the duration is this run's live figure.  `ideal` = cycles per wave-instruction per SIMD if the VALU
-    never stalled, from the kernel's instruction mix at the measured issue rates (tools/ubench.hip: v_mad_u64_u32,
-    v_mul_lo_u32, v_lshl_add_u64, 64-bit shifts 4 cycles per wave64; 32-bit add / and / cndmask 2): per mixed addition
-    2 316 instructions, 2 039 of them half rate -> 3.76."""
-    if not (log2n == 20 and stage_name == "msm_accumulate"):
-        return None
-    try:
-        vals = {}
-        with open(os.path.join(ROOT, "profiles", "r01_final_pmc_sq.txt")) as f:
-            for line in f:
-                p = line.split()
-                if len(p) == 5 and p[0] == "h2agg::k_msm_accumulate":
-                    vals[p[1]] = (float(p[3]), float(p[4]))
-        insts, dur_us = vals["SQ_INSTS_VALU"]
-        clk_hz = vals["GRBM_GUI_ACTIVE"][0] / 8.0 / (dur_us * 1e-6)
-    except (OSError, KeyError, ValueError):
-        return None
+    except (OSError, ValueError):
+        return None, None, "no PMC evidence file"
+    if not (t.get("log2n") == log2n and stage_name == "msm_accumulate" and t.get("kernel") == "k_msm_accumulate"):
+        return None, None, "PMC evidence is for a different workload"
+    if t.get("csrc_sha") != csrc_sha():
+        return None, None, "stale: kernel sources changed since profiles/r02_traffic.json was collected (csrc_sha %s != %s)" % (
+            t.get("csrc_sha"), csrc_sha())
     simds = 256 * 4
-    cpi = avg_kernel_s * clk_hz * simds / insts
-    ideal = 3.76
-    return {"wave_instructions_per_launch": insts, "shader_clock_ghz": clk_hz / 1e9, "simds": simds,
-            "cycles_per_instruction_per_simd": cpi, "ideal_cycles_per_instruction": ideal, "issue_frac": ideal / cpi,
-            "source": "profiles/r01_final_pmc_sq.txt (rocprofv3 --pmc, same command) + this run's avg_kernel_ms"}
+    # cycles per wave-instruction per SIMD from ONE run: the PMC pass's own duration and clock
+    cpi = t["duration_us"] * 1e-6 * t["shader_clock_hz"] * simds / t["valu_insts"]
+    valu = {"wave_instructions_per_launch": t["valu_insts"], "shader_clock_ghz": t["shader_clock_hz"] / 1e9, "simds": simds,
+            "pmc_run_kernel_ms": t["duration_us"] / 1e3, "cycles_per_instruction_per_simd": cpi,
+            "ideal_cycles_per_instruction": t["ideal_cpi"], "issue_frac": t["ideal_cpi"] / cpi,
+            "source": "profiles/r02_traffic.json (rocprofv3 --pmc passes of this command; instruction count, clock AND "
+                      "duration from the same pass)"}
+    return t["bytes_per_launch"], valu, "csrc_sha " + t["csrc_sha"]
+
+
+def check_pair_second_path(eng, pkg, agg, mo, syn, specs, lam, commits, pair):
+    """The aggregate leg's final pair recomputed along a DIFFERENT route through the product: every proof evaluated on
+    its own (N separate evaluate_multiopen_proof calls: other tapes, other MSM sizes and plans), the N pairs then folded
+    with lambda^(N-1-i) by the windowed scalar-mul kernel and k_g1_sum — no folded schema, no lambda nodes, no Pippenger
+    over the aggregated scalars.  (The oracle-backed parity of the same shapes lives in tests/test_gpu_configs.py.)"""
+    n = len(specs)
+    lam_i = int.from_bytes(lam, "little")
+    lefts, rights = [], []
+    for i, spec in enumerate(specs):
+        b = pkg.SchemaBuilder(eng)
+        proof, q0 = syn.build_proof(b, mo.MultiOpenProof, spec)
+        if commits is not None:
+            b.query_set_commitment(q0, commits[i])
+        l, r, _names = b.evaluate_multiopen_proof(proof.w_x, proof.w_g)
+        lefts.append(l)
+        rights.append(r)
+        b.close()
+    weights = b"".join(pow(lam_i, n - 1 - i, R_MOD).to_bytes(32, "little") for i in range(n))
+    out = []
+    for side in (lefts, rights):
+        jac = eng.g1_batch_scalar_mul(b"".join(side), weights)
+        out.append(eng.g1_batch_to_affine(eng.g1_sum(jac)))
+    return (out[0], out[1]) == (pair[0], pair[1])
 
 
 def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
@@ -106,30 +130,12 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
     dev, coll_dev = devs if isinstance(devs, tuple) else (devs, devs)
     agg = importlib.import_module(entry.PKG_NAME + ".aggregate")
     mo = importlib.import_module(entry.PKG_NAME + ".multiopen")
+    syn = importlib.import_module(entry.PKG_NAME + ".synthetic")
     backend = agg.GpuBackend(pkg, eng)
     n_total = args.agg_proofs * world
-    rng = np.random.Generator(np.random.PCG64(0xA66))
-
-    def fr():
-        return (int.from_bytes(rng.bytes(64), "little") % R_MOD).to_bytes(32, "little")
-
-    # a pool of valid points: k*G from the scalar-mul kernel (commitment values are irrelevant to the cost)
-    pool_n = 256
-    g_aff = (1).to_bytes(32, "little") + (2).to_bytes(32, "little")
-    pool_j = eng.g1_batch_scalar_mul(g_aff * pool_n, b"".join(fr() for _ in range(pool_n)))
-    pool = eng.g1_batch_to_affine(pool_j)
-    pts = [pool[64 * i:64 * i + 64] for i in range(pool_n)]
-    lam = fr()
-    # per-proof data generated once (same on every rank: seeded), building the schemas is inside the timed region
-    specs = []
-    for i in range(n_total):
-        x, xw, xl = fr(), fr(), fr()
-        qs = [(0, "p%d_instance_commitments0" % i, x)]
-        qs += [(0, "p%d_advice_commitments%d" % (i, c), x) for c in range(args.agg_commitments)]
-        qs += [(1, "p%d_advice_commitments%d" % (i, c), xw) for c in range(0, args.agg_commitments, 7)]
-        qs += [(-6, "p%d_perm%d" % (i, c), xl) for c in range(3)]
-        spec = [(rot, key, z, pts[(i * 131 + k) % pool_n], fr()) for k, (rot, key, z) in enumerate(qs)]
-        specs.append((spec, [pts[(i + 1) % pool_n], pts[(i + 2) % pool_n], pts[(i + 3) % pool_n]], fr(), fr()))
+    # per-proof data generated once (same on every rank: seeded); building the schemas is inside the timed region
+    pool = syn.point_pool(eng, 0xA66)
+    specs, lam = syn.make_proofs(pool, n_total, args.agg_commitments)
 
     # assign_instance_commitment (verify.rs:574-649): every proof's instance column is committed against the fixed
     # g_lagrange table with an MSM of 2^k - (blinding_factors + 1) scalars (k = 17, l = 6).
@@ -148,12 +154,7 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
             d_inst[j] = torch.randint(0, 256, (n_inst, 32), dtype=torch.uint8, device=dev, generator=gen)
         d_inst[:, :, 31] &= 0x1F                               # < 2^253 < r: canonical
         d_inst_out = torch.zeros((len(my_idx), 96), dtype=torch.uint8, device=dev)
-
-    packed = []
-    for spec, w, v, u in specs:      # byte-level packing of the proof data (what a transcript reader hands over)
-        packed.append(([k for _r, k, _z, _c, _e in spec], b"".join(c for *_x, c, _e in spec),
-                       b"".join(e for *_x, e in spec), [r for r, *_x in spec], b"".join(z for _r, _k, z, _c, _e in spec),
-                       b"".join(w), v, u))
+    last_commits = {}
 
     def build(b, idx):
         """per proof: n x EvaluationQuery::new + batch_multi_open_proofs, both in the C++ host layer"""
@@ -164,29 +165,43 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
             eng.g1_msm_device_batch_async(g_table, d_inst.data_ptr(), n_inst, len(idx), d_inst_out.data_ptr())
         first = []
         for i in idx:
-            keys, commitments, evals, rots, zs, wbytes, v, u = packed[i]
-            qnodes = b.evaluation_queries(keys, commitments, evals, wrap=False)
-            first.append(qnodes[0])
-            w_x, w_g = b.batch_multi_open("p%d" % i, rots, zs, qnodes, wbytes, v, u)
-            out.append(mo.MultiOpenProof(w_x, w_g))
+            proof, q0 = syn.build_proof(b, mo.MultiOpenProof, specs[i])
+            first.append(q0)
+            out.append(proof)
         if n_inst and idx:
             aff = eng.g1_batch_to_affine_device(d_inst_out.data_ptr(), len(idx))
             for j, q in enumerate(first):
                 b.query_set_commitment(q, aff[64 * j:64 * j + 64])
+                last_commits[idx[j]] = aff[64 * j:64 * j + 64]
         return out
 
-    agg.aggregate_sharded(backend, build, n_total, lam, dist=dist, device=coll_dev)     # warm-up
+    pair = agg.aggregate_sharded(backend, build, n_total, lam, dist=dist, device=coll_dev)     # warm-up
+    # ---- what is about to be timed must be right: refuse to report a rate for a pair that a second route through the
+    # product does not reproduce (single rank: every proof is local, so the whole fold can be recomputed here)
+    verified = None
+    if world == 1 and n_total <= 16:
+        commits = [last_commits[i] for i in range(n_total)] if n_inst else None
+        if commits is not None and args.agg_instance_log2 <= 18:
+            # the batched / fixed-base instance commitments against the plain single-MSM entry point
+            one = eng.g1_batch_to_affine(eng.g1_msm_device(g_table, d_inst[0].data_ptr(), n_inst))
+            if one != commits[0]:
+                raise SystemExit("aggregate leg: batched instance commitment differs from the single MSM — refusing to report")
+        if not check_pair_second_path(eng, pkg, agg, mo, syn, specs, lam, commits, pair):
+            raise SystemExit("aggregate leg: final pair not reproduced by the per-proof route — refusing to report")
+        verified = "per-proof evaluate_multiopen_proof + lambda-weighted fold (scalar-mul kernel + g1_sum) reproduces the pair"
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     reps = 3
     for _ in range(reps):
-        pair = agg.aggregate_sharded(backend, build, n_total, lam, dist=dist, device=coll_dev)
+        pair2 = agg.aggregate_sharded(backend, build, n_total, lam, dist=dist, device=coll_dev)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
     dt = (time.perf_counter() - t0) / reps
+    if pair2 != pair:
+        raise SystemExit("aggregate leg: the timed repetitions do not reproduce the verified pair — refusing to report")
     t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -195,10 +210,12 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
         "proofs_per_sec": n_total / dt,
         "proofs": n_total,
         "seconds_per_aggregation": dt,
-        "commitments_per_proof": len(specs[0][0]),
+        "commitments_per_proof": specs[0].nq,
         "instance_msm_points_per_proof": n_inst,
         "instance_msm_fixed_base_levels": bool(n_inst and args.agg_instance_log2 <= 18 and not args.no_fixed_base),
         "final_pair_sha": __import__("hashlib").sha256(pair[0] + pair[1]).hexdigest()[:16],
+        "verified": verified if verified else "sharded run: every rank's timed repetitions reproduce the warm-up pair "
+                                              "(the single-rank run of the same proofs is cross-checked per proof)",
         "note": "synthetic shape-faithful schemas; per proof: the instance-column commitment MSM against the fixed "
                 "g_lagrange table (instance scalars resident in HBM), host-side schema construction (Python + C++) "
                 "underneath it; then the device Fr tape, the two multi_exps, +/- e*G, to_affine, and the all-gather + "
@@ -374,6 +391,7 @@ def main():
         dom_ms, dom_cnt = eng.profile_stages()[dom_name]          # measured inside the timed region
         dom_avg_s = dom_ms / max(dom_cnt, 1) * 1e-3
         achieved = ALGO_BYTES_PER_POINT * n / dom_avg_s / 1e9
+        pmc = pmc_evidence(dom_name, args.log2n)
         value = world * n * args.steps / dt_max
         out = {
             "metric": "BN254 G1 MSM points/sec",
@@ -409,8 +427,9 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": measured_traffic(dom_name, args.log2n),
-                "valu": valu_view(dom_name, args.log2n, dom_avg_s),
+                "traffic": pmc[0],
+                "valu": pmc[1],
+                "pmc_evidence": pmc[2],
                 "avg_kernel_ms": dom_avg_s * 1e3,
                 "note": "MSM is integer-VALU-bound (v_mad_u64_u32 chains), not HBM-bound: the algorithmic "
                         "96 B/point is a tiny fraction of peak by construction (SURVEY.md \u00a78d).  The bound that "
@@ -423,7 +442,49 @@ def main():
         }
         if agg_info is not None:
             out["aggregate"] = agg_info
+        if world == 1:
+            # PCIe-inclusive rate: what a host that hands over HOST buffers sees (the drop-in's multi_exp call marshals
+            # points / scalars into page-locked buffers from h2agg_host_alloc): h2agg_g1_msm, 96 B/point over PCIe per
+            # call, bases converted to Montgomery form on the device, slices crossing PCIe under the previous slice's
+            # compute.  Never `value` (inputs resident in HBM), reported beside it.
+            import ctypes
+            hb = eng.host_alloc(64 * n)
+            hs = eng.host_alloc(32 * n)
+            try:
+                ctypes.memmove(hb, eng.bases_download(table, 0, n), 64 * n)
+                ctypes.memmove(hs, bytes(s_np.tobytes()), 32 * n)
+                eng.msm_set_tail_overlap(0)
+                r0 = eng.g1_msm(hb, hs, n)
+                t0 = time.perf_counter()
+                reps_h = 5
+                for _ in range(reps_h):
+                    r1 = eng.g1_msm(hb, hs, n)
+                t_h = (time.perf_counter() - t0) / reps_h
+                same = eng.g1_batch_to_affine(r1) == eng.g1_batch_to_affine(bytes(d_out[0].cpu().numpy().tobytes()))
+            finally:
+                eng.host_free(hb)
+                eng.host_free(hs)
+                if not args.no_overlap:
+                    eng.msm_set_tail_overlap(args.overlap_level)
+            out["pcie_inclusive"] = {"value": n / t_h, "unit": "points/s", "ms_per_msm": t_h * 1e3, "matches_resident": same,
+                                     "note": "h2agg_g1_msm from page-locked host buffers, synchronous call, 96 B/point "
+                                             "host->device per call (not `value`: that one has inputs resident in HBM)"}
         if world == 1 and not args.no_cpu_baseline:
+            import shutil
+            import subprocess
+            tool = {}
+            for exe in ("cargo", "rustc"):                      # probe, do not assume
+                path = shutil.which(exe)
+                ver = None
+                if path:
+                    try:
+                        ver = subprocess.run([path, "--version"], capture_output=True, text=True, timeout=20).stdout.strip()
+                    except (OSError, subprocess.SubprocessError):
+                        ver = "present but not runnable"
+                tool[exe] = ver
+            ref_note = ("cargo / rustc probed on this box: %s — the reference (Rust nightly-2022-08-23 + unvendored git "
+                        "dependencies, no network) cannot run here" % (
+                            ", ".join("%s: %s" % (k, v or "not found") for k, v in tool.items())))
             sample = min(args.cpu_sample, n)
             bases_aff = eng.bases_download(table, 0, sample)
             rate, secs, cpu_out = cpu_baseline(bases_aff, bytes(s_np[:sample].tobytes()), sample)
@@ -435,22 +496,26 @@ def main():
                 "kind": "port",
                 "sample": "first %d points of the same workload, oracle/bn254_ref.c oracle_multi_exp_naive "
                           "(restated reference algorithm: n double-and-add scalar muls, 1 thread), %.1f s; "
-                          "host has %d cores; cargo/rustc absent so the reference itself cannot run" % (
-                              sample, secs, os.cpu_count() or 0),
+                          "host has %d cores; %s" % (sample, secs, os.cpu_count() or 0, ref_note),
+                "reference_toolchain": tool,
                 "matches_gpu": cpu_out == gpu_same,
             }
-            # BASELINE.md "B1": not the reference's algorithm — a multi-threaded CPU Pippenger (oracle/, one thread
-            # per window) on the FULL workload, so the headline is not only compared with the naive loop
+            # BASELINE.md "B1": not the reference's algorithm — a multi-threaded CPU Pippenger (oracle/) on the FULL
+            # workload and on ALL host cores ((window, point-range) jobs from a shared counter), so the headline is not only
+            # compared with the naive loop
             from oracle import cref
             full_bases = eng.bases_download(table, 0, n)
+            threads = os.cpu_count() or 1
+            c_cpu = 13 if n >= (1 << 18) else 10
             t0 = time.perf_counter()
-            b1 = cref.msm_pippenger(full_bases, bytes(s_np.tobytes()), n, 16, 16)
+            b1 = cref.msm_pippenger(full_bases, bytes(s_np.tobytes()), n, c_cpu, threads)
             t_b1 = time.perf_counter() - t0
             out["cpu_baseline"]["fair_cpu_pippenger"] = {
-                "value": n / t_b1, "unit": "points/s", "threads": 16, "seconds": t_b1,
+                "value": n / t_b1, "unit": "points/s", "threads": threads, "seconds": t_b1,
                 "matches_gpu": b1 == eng.g1_batch_to_affine(bytes(d_out[0].cpu().numpy().tobytes())),
-                "note": "oracle_msm_pippenger, unsigned 16-bit windows, 16 threads (one per window), full 2^%d points; "
-                        "NOT the reference algorithm" % args.log2n,
+                "note": "oracle_msm_pippenger, unsigned %d-bit windows, %d threads over (window, point-range) jobs, full "
+                        "2^%d points, 4 x 64-bit Montgomery + Jacobian mixed additions; NOT the reference algorithm" % (
+                            c_cpu, threads, args.log2n),
             }
         print(json.dumps(out))
     if dist is not None:

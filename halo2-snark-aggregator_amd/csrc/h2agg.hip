@@ -14,7 +14,7 @@
 #include <string>
 #include <vector>
 
-#include "msm_kernels.cuh"
+#include "scalar_mul_kernels.cuh"
 #include "pairing.hpp"
 #include "schema.cuh"
 
@@ -63,6 +63,8 @@ struct h2agg_ctx {
 
     // grow-only device workspace
     DevBuf in_a, in_b, in_c, out, tmp_bases;                      // host-buffer entry points
+    DevBuf comb;                                                  // fixed-base comb table of the generator (k_comb_table_build)
+    bool comb_ready = false;
     DevBuf hist, offs, pmeta, item_idx, item_sub, order, entries, big_list, big_keys, big_part,
         glv_buf, parts, small, endo_buf, tile_counts;  // MSM (bulk side: main stream only)
     uint32_t* d_flags = nullptr;      // in `small`: [0] status flags, [1] big_count
@@ -92,7 +94,6 @@ struct h2agg_ctx {
     int cfg_c = 0, cfg_seg = 0, cfg_big = 0, cfg_sub_bits = 0, cfg_tile = 0;
     int cfg_glv = 0;   // 0 = auto, 1 = on, -1 = off
     int cfg_lpb = 0;   // lanes per bucket in the accumulate kernel: 0 = auto, 1 / 2 / 4 / 8 / 16
-    uint32_t acc_slots = 0;   // one-wave workgroups of k_msm_accumulate the chip holds at once (occupancy x CUs)
     bool cfg_no_stage = false, cfg_stage_l1 = false, staged_attr_set = false;
 
     // optional overlap of the serial tail (k_msm_final) of MSM k with the bulk of MSM k+1
@@ -506,36 +507,14 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         TRY(ensure(c, c->parts, (size_t)p.NBT * lpb * XYZZ_BYTES));
         acc_out = (uint8_t*)c->parts.p;
     }
-    // wave-quantisation fill (see k_msm_accumulate): split the K longest buckets in two so that the one-wave workgroups
-    // come to a whole number of rounds of the chip's wave slots.  Worth it while K general additions (the combine) cost
-    // less than the idle slots of the last round: K <= NBT / 4 and runs long enough to halve.
     constexpr int acc_block = 64;
-    uint32_t split_k = 0;
-    static const int split_env = getenv("H2AGG_SPLIT") ? atoi(getenv("H2AGG_SPLIT")) : 1;
-    if (split_env && lpb == 1 && ordered && nent >= (size_t)16 * p.NBT) {
-        if (!c->acc_slots) {
-            int per_cu = 0;
-            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)k_msm_accumulate, acc_block, 0) != hipSuccess ||
-                per_cu < 1)
-                per_cu = 12;
-            c->acc_slots = (uint32_t)per_cu * (uint32_t)c->cu_count;
-        }
-        const uint64_t lanes_per_round = (uint64_t)c->acc_slots * acc_block;
-        const uint64_t rounds = ((uint64_t)p.NBT + lanes_per_round - 1) / lanes_per_round;
-        const uint64_t k = rounds * lanes_per_round - p.NBT;
-        if (k > 0 && k <= p.NBT / 4) {
-            split_k = (uint32_t)k;
-            TRY(ensure(c, c->parts, (size_t)2 * split_k * XYZZ_BYTES));
-        }
-    }
     {
         StageTimer t(c, ST_ACCUM);
         // one-wave workgroups: a 4-wave workgroup needs a free slot on all four SIMDs of a CU at once and its waves retire
         // at different times; single waves fill any slot as it frees up (2^20 points: 1.74 -> 1.67 ms/step)
-        const size_t lanes = split_k ? (size_t)p.NBT + split_k : (size_t)p.NBT * lpb;
-        hipLaunchKernelGGL(k_msm_accumulate, dim3((unsigned)((lanes + acc_block - 1) / acc_block)), dim3(acc_block), 0,
+        hipLaunchKernelGGL(k_msm_accumulate, dim3((unsigned)(((size_t)p.NBT * lpb + acc_block - 1) / acc_block)), dim3(acc_block), 0,
                            st, d_bases, d_endo_x, entries, offs, hist, ordered ? order : (uint32_t*)nullptr, p.NBT, p.big, lpb, acc_out,
-                           big_list, big_keys, big_count, split_k, (uint8_t*)c->parts.p);
+                           big_list, big_keys, big_count);
     }
     {
         StageTimer t(c, ST_ACCUM_BIG);
@@ -547,9 +526,6 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         size_t gk = max_keys < cap ? max_keys : cap;
         hipLaunchKernelGGL(k_msm_big_combine, dim3((unsigned)gk), dim3(BLOCK), 0, st, big_part, big_keys, big_count,
                            acc_out, lpb);
-        if (split_k)
-            hipLaunchKernelGGL(k_msm_split_combine, dim3((split_k + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st,
-                               (const uint8_t*)c->parts.p, (const uint32_t*)order, (const uint32_t*)hist, p.big, split_k, buckets);
         if (lpb > 1)
             hipLaunchKernelGGL(k_msm_bucket_combine, dim3((p.NBT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st,
                                (const uint8_t*)acc_out, hist, p.NBT, p.big, lpb, buckets);
@@ -683,7 +659,7 @@ void h2agg_destroy(h2agg_ctx* c) {
     for (int k = 0; k < h2agg_ctx::TAIL_SLOTS; ++k)
         if (c->tail_streams[k]) hipStreamSynchronize(c->tail_streams[k]);
     static_assert(h2agg_ctx::TAIL_SLOTS == 3, "the list below names every tail slot's buffers");
-    DevBuf* bufs[] = {&c->in_a,  &c->in_b,     &c->in_c,     &c->out,   &c->tmp_bases, &c->hist,
+    DevBuf* bufs[] = {&c->in_a,  &c->in_b,     &c->in_c,     &c->out,   &c->tmp_bases, &c->comb, &c->hist,
                       &c->offs,  &c->pmeta,    &c->item_idx, &c->item_sub, &c->order,  &c->entries,
                       &c->buckets[0], &c->buckets[1], &c->buckets[2], &c->segsum[0], &c->segsum[1], &c->segsum[2],
                       &c->wsum[0], &c->wsum[1], &c->wsum[2], &c->big_list, &c->big_keys, &c->big_part, &c->glv_buf, &c->parts, &c->small, &c->endo_buf, &c->tile_counts,
@@ -863,8 +839,19 @@ int h2agg_g1_batch_scalar_mul(h2agg_ctx* c, const uint8_t* bases, const uint8_t*
     HIP_TRY(c, hipMemcpyAsync(c->in_a.p, bases, 64 * n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->in_b.p, scalars, 32 * n, hipMemcpyHostToDevice, c->stream));
     TRY(clear_flags(c));
-    hipLaunchKernelGGL(k_g1_batch_scalar_mul, dim3(grid_for(c, n)), dim3(BLOCK), 0, c->stream,
-                       (const uint8_t*)c->in_a.p, (const uint8_t*)c->in_b.p, n, (uint8_t*)c->out.p, c->d_flags);
+    // GLV + signed window-4 ladder, four lanes per point (csrc/scalar_mul_kernels.cuh); H2AGG_SCALAR_MUL=ladder selects the
+    // round-1 bit-serial kernel for A/B measurements
+    static const bool ladder = getenv("H2AGG_SCALAR_MUL") && !strcmp(getenv("H2AGG_SCALAR_MUL"), "ladder");
+    if (ladder) {
+        hipLaunchKernelGGL(k_g1_batch_scalar_mul, dim3(grid_for(c, n)), dim3(BLOCK), 0, c->stream,
+                           (const uint8_t*)c->in_a.p, (const uint8_t*)c->in_b.p, n, (uint8_t*)c->out.p, c->d_flags);
+    } else {
+        size_t groups = (n + SM_GROUPS - 1) / SM_GROUPS;
+        const size_t cap = (size_t)c->cu_count * 16;
+        if (groups > cap) groups = cap;
+        hipLaunchKernelGGL(k_g1_batch_scalar_mul_w4, dim3((unsigned)groups), dim3(SM_THREADS), 0, c->stream,
+                           (const uint8_t*)c->in_a.p, (const uint8_t*)c->in_b.p, n, (uint8_t*)c->out.p, c->d_flags);
+    }
     HIP_TRY(c, hipMemcpyAsync(out, c->out.p, 96 * n, hipMemcpyDeviceToHost, c->stream));
     return finish(c);
 } catch (const std::bad_alloc&) {
@@ -1000,10 +987,27 @@ int h2agg_bases_generate(h2agg_ctx* c, const void* d_k, size_t n, uint64_t* hand
     if (hipMalloc((void**)&t.d, 64 * n) != hipSuccess) return fail(c, H2AGG_ERR_NOMEM, "hipMalloc(base table)");
     int rc = clear_flags(c);
     if (rc == H2AGG_OK) {
+        static const bool ladder = getenv("H2AGG_SCALAR_MUL") && !strcmp(getenv("H2AGG_SCALAR_MUL"), "ladder");
         size_t blocks = (n + BLOCK - 1) / BLOCK;
-        hipLaunchKernelGGL(k_bases_generate, dim3((unsigned)(blocks > 65535 * 16 ? 65535 * 16 : blocks)), dim3(BLOCK), 0,
-                           c->stream, (const uint8_t*)d_k, n, t.d, c->d_flags);
-        rc = finish(c);
+        if (blocks > 65535 * 16) blocks = 65535 * 16;
+        if (ladder) {
+            hipLaunchKernelGGL(k_bases_generate, dim3((unsigned)blocks), dim3(BLOCK), 0, c->stream, (const uint8_t*)d_k, n, t.d,
+                               c->d_flags);
+        } else {
+            // fixed-base comb: d * 2^(8w) * G for every byte position, built once per context (32 x 255 points, 510 KiB)
+            if (!c->comb_ready) {
+                rc = ensure(c, c->comb, (size_t)COMB_WINDOWS * COMB_ROW * 64);
+                if (rc == H2AGG_OK) {
+                    hipLaunchKernelGGL(k_comb_table_build, dim3((COMB_WINDOWS * COMB_ROW + SM_GROUPS - 1) / SM_GROUPS),
+                                       dim3(SM_THREADS), 0, c->stream, (uint8_t*)c->comb.p, c->d_flags);
+                    c->comb_ready = true;
+                }
+            }
+            if (rc == H2AGG_OK)
+                hipLaunchKernelGGL(k_bases_generate_comb, dim3((unsigned)blocks), dim3(BLOCK), 0, c->stream, (const uint8_t*)d_k, n,
+                                   (const uint8_t*)c->comb.p, t.d, c->d_flags);
+        }
+        if (rc == H2AGG_OK) rc = finish(c);
     }
     if (rc != H2AGG_OK) {
         hipFree(t.d);

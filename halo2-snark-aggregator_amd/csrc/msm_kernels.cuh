@@ -91,40 +91,15 @@ __global__ void __launch_bounds__(BLOCK) k_msm_accumulate(const uint8_t* __restr
                                                           uint32_t lpb /* lanes per bucket: 1, 2 or 4 */,
                                                           uint8_t* __restrict__ buckets, uint32_t* __restrict__ big_list,
                                                           uint32_t* __restrict__ big_keys,
-                                                          uint32_t* __restrict__ counters /* [0] chunks, [1] keys */,
-                                                          uint32_t split_k, uint8_t* __restrict__ split_out) {
+                                                          uint32_t* __restrict__ counters /* [0] chunks, [1] keys */) {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t part, key;
-    uint8_t* dst;
-    if (split_k) {
-        // Wave-quantisation fill (round 2): the launch would be ceil(nbt / 64) one-wave workgroups over S = 3 x 4 x CUs wave
-        // slots — 8192 over 3072 at 2^20 points, i.e. two full rounds and a third with two waves per SIMD, and two
-        // waves do not saturate the VALU.  The split_k LONGEST buckets are cut in two (lanes at the end, half the work
-        // each) so that the launch is a whole number of rounds; k_msm_split_combine adds the halves.
-        const uint32_t nun = nbt - split_k;               // unsplit buckets: ranks split_k .. nbt-1 of `order`
-        if (t >= nun + 2u * split_k) return;
-        if (t < nun) {
-            key = order[split_k + t];
-            part = 0;
-            lpb = 1;
-            dst = buckets + XYZZ_BYTES * (size_t)key;
-        } else {
-            const uint32_t u = t - nun;
-            key = order[u >> 1];
-            part = u & 1u;
-            lpb = 2;
-            dst = split_out + XYZZ_BYTES * (size_t)u;
-        }
-    } else {
-        if (t >= nbt * lpb) return;
-        // buckets sorted by length, longest first: a wave's lanes finish together.  With lpb > 1 each bucket's run
-        // is cut into lpb slices handled by adjacent lanes (more, shorter waves: fills the 3072 wave slots when
-        // there are few buckets — GLV halves their number); the slices' partial sums go to buckets[key*lpb + part]
-        // and are folded by k_msm_bucket_combine.
-        part = t % lpb;
-        key = order ? order[t / lpb] : t / lpb;   // (small MSMs skip the ordering pass)
-        dst = buckets + XYZZ_BYTES * ((size_t)key * lpb + part);
-    }
+    if (t >= nbt * lpb) return;
+    // buckets sorted by length, longest first: a wave's lanes finish together.  With lpb > 1 each bucket's run
+    // is cut into lpb slices handled by adjacent lanes (more, shorter waves: fills the 3072 wave slots when
+    // there are few buckets — GLV halves their number); the slices' partial sums go to buckets[key*lpb + part]
+    // and are folded by k_msm_bucket_combine.
+    const uint32_t part = t % lpb;
+    const uint32_t key = order ? order[t / lpb] : t / lpb;   // (small MSMs skip the ordering pass)
     const uint32_t len = hist[key];
     if (len > big) {
         if (part != 0) return;
@@ -156,22 +131,7 @@ __global__ void __launch_bounds__(BLOCK) k_msm_accumulate(const uint8_t* __restr
             xyzz_add_affine(acc, cur);
         }
     }
-    xyzz_store(dst, acc);
-}
-
-// buckets[order[r]] = halves[2r] + halves[2r + 1] for the split_k longest buckets (see k_msm_accumulate); over-long
-// buckets went through the chunk path, which wrote buckets[key] itself
-__global__ void __launch_bounds__(BLOCK) k_msm_split_combine(const uint8_t* __restrict__ halves,
-                                                             const uint32_t* __restrict__ order,
-                                                             const uint32_t* __restrict__ hist, uint32_t big,
-                                                             uint32_t split_k, uint8_t* __restrict__ buckets) {
-    const uint32_t r = blockIdx.x * BLOCK + threadIdx.x;
-    if (r >= split_k) return;
-    const uint32_t key = order[r];
-    if (hist[key] > big) return;
-    const G1XYZZ a = xyzz_load(halves + XYZZ_BYTES * (size_t)(2 * r));
-    const G1XYZZ b = xyzz_load(halves + XYZZ_BYTES * (size_t)(2 * r + 1));
-    xyzz_store(buckets + XYZZ_BYTES * (size_t)key, xyzz_add(a, b));
+    xyzz_store(buckets + XYZZ_BYTES * ((size_t)key * lpb + part), acc);
 }
 
 // buckets[key] = sum of the lpb slice sums written by k_msm_accumulate (skipped for over-long buckets, whose

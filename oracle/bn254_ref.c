@@ -418,11 +418,15 @@ int oracle_eval_flat(const uint8_t *pts_aff, const uint8_t *scalars, const uint8
 }
 
 /* ------------------------------------------------------------------ baseline B1: fair CPU Pippenger
- * (NOT the reference algorithm; BASELINE.md §3 "B1").  Unsigned c-bit windows, one thread per
- * window group, running-sum bucket reduction. */
+ * (NOT the reference algorithm; BASELINE.md section 3 "B1").  Unsigned c-bit windows, running-sum bucket reduction.
+ * Work is cut into (window, point-range) jobs pulled from a shared counter by `nthreads` workers, so that ALL host cores
+ * are used whatever the window count (round-1 verdict: one thread per window capped the "fair" baseline at 16 threads on
+ * a 256-core host).  Each job owns a bucket set; a window's partial sums over the point ranges are added at the end. */
 typedef struct {
-    const g1a *bases; const uint8_t *scalars; size_t n; int c; int w_lo, w_hi; g1 *wsum;
-} pip_job;
+    const g1a *bases; const uint8_t *scalars; size_t n; int c; int W, S;   /* S point ranges per window */
+    g1 *parts;                                                             /* [W][S] partial window sums */
+    volatile long *next;                                                   /* shared job counter */
+} pip_shared;
 
 static unsigned get_window(const uint8_t *s, int bit, int c) {
     unsigned v = 0;
@@ -433,12 +437,17 @@ static unsigned get_window(const uint8_t *s, int bit, int c) {
     return v;
 }
 static void *pip_worker(void *arg) {
-    pip_job *J = (pip_job *)arg;
+    pip_shared *J = (pip_shared *)arg;
     size_t nb = (size_t)1 << J->c;
     g1 *buckets = (g1 *)malloc(nb * sizeof(g1));
-    for (int w = J->w_lo; w < J->w_hi; ++w) {
+    const long njobs = (long)J->W * J->S;
+    for (;;) {
+        const long job = __sync_fetch_and_add(J->next, 1);
+        if (job >= njobs) break;
+        const int w = (int)(job / J->S), sidx = (int)(job % J->S);
+        const size_t lo = J->n * (size_t)sidx / (size_t)J->S, hi = J->n * (size_t)(sidx + 1) / (size_t)J->S;
         for (size_t b = 0; b < nb; ++b) g1_set_inf(&buckets[b]);
-        for (size_t i = 0; i < J->n; ++i) {
+        for (size_t i = lo; i < hi; ++i) {
             unsigned d = get_window(J->scalars + 32 * i, w * J->c, J->c);
             if (d && !J->bases[i].inf) g1_add_aff(&buckets[d], &buckets[d], &J->bases[i]);
         }
@@ -449,7 +458,7 @@ static void *pip_worker(void *arg) {
             g1_add(&run, &run, &buckets[b]);
             g1_add(&sum, &sum, &run);
         }
-        J->wsum[w] = sum;
+        J->parts[job] = sum;
     }
     free(buckets);
     return NULL;
@@ -460,27 +469,27 @@ int oracle_msm_pippenger(const uint8_t *bases_aff, const uint8_t *scalars, size_
     if (c < 1 || c > 20) return 1;
     if (nthreads < 1) nthreads = 1;
     int W = (254 + c - 1) / c;
+    int S = (nthreads + W - 1) / W;                 /* point ranges per window: W * S >= nthreads jobs */
+    if ((size_t)S > n) S = (int)n;
     g1a *bases = (g1a *)malloc(n * sizeof(g1a));
     for (size_t i = 0; i < n; ++i) aff_from_bytes(&bases[i], bases_aff + 64 * i);
-    g1 *wsum = (g1 *)malloc((size_t)W * sizeof(g1));
-    if (nthreads > W) nthreads = W;
+    g1 *parts = (g1 *)malloc((size_t)W * S * sizeof(g1));
+    volatile long next = 0;
+    pip_shared sh = {bases, scalars, n, c, W, S, parts, &next};
+    if (nthreads > W * S) nthreads = W * S;
     pthread_t *th = (pthread_t *)malloc((size_t)nthreads * sizeof(pthread_t));
-    pip_job *jobs = (pip_job *)malloc((size_t)nthreads * sizeof(pip_job));
-    for (int t = 0; t < nthreads; ++t) {
-        jobs[t] = (pip_job){bases, scalars, n, c, (int)((long)W * t / nthreads), (int)((long)W * (t + 1) / nthreads), wsum};
-        pthread_create(&th[t], NULL, pip_worker, &jobs[t]);
-    }
+    for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, pip_worker, &sh);
     for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
     g1 acc;
     g1_set_inf(&acc);
     for (int w = W - 1; w >= 0; --w) {
         for (int k = 0; k < c; ++k) g1_double(&acc, &acc);
-        g1_add(&acc, &acc, &wsum[w]);
+        for (int sidx = 0; sidx < S; ++sidx) g1_add(&acc, &acc, &parts[(size_t)w * S + sidx]);
     }
     g1a r;
     g1_to_aff(&r, &acc);
     aff_to_bytes(out_aff, &r);
-    free(bases); free(wsum); free(th); free(jobs);
+    free(bases); free(parts); free(th);
     return 0;
 }
 

@@ -20,6 +20,7 @@ for ctrs in "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_
   i=$((i+1))
 done
 cd $root
+python tools/make_traffic_json.py $out/${tag} > $out/${tag}_traffic.json 2>> $out/${tag}_traffic.err
 # full-size aggregation path trace
 cd /tmp && rm -rf /tmp/prof_agg && rocprofv3 --kernel-trace --stats -d /tmp/prof_agg -o agg -- python $root/tools/agg_phases.py --reps 10 > $out/${tag}_agg_phases.txt 2>/dev/null
 python $root/tools/rocpd_summary.py /tmp/prof_agg/agg_results.db > $out/${tag}_agg_kernel_stats.txt 2>&1
