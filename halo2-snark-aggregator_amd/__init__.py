@@ -109,6 +109,8 @@ def load_library():
         "h2agg_g1_batch_to_affine_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p]),
         "h2agg_schema_names_joined": (C.c_size_t, [C.c_void_p, C.c_char_p, C.c_size_t]),
         "h2agg_schema_point_list_len": (C.c_size_t, [C.c_void_p]),
+        "h2agg_poseidon_squeeze_batch": (i32, [ctxp, u8p, sz, sz, C.POINTER(C.c_uint32), sz, vp]),
+        "h2agg_transcript_read_batch": (i32, [ctxp, u8p, sz, sz, C.c_char_p, sz, u8p, sz, u8p, sz, vp, vp]),
         "h2agg_comm_unique_id": (i32, [vp]),
         "h2agg_comm_init_rank": (i32, [ctxp, u8p, i32, i32]),
         "h2agg_comm_create": (i32, [C.POINTER(i32), i32, C.POINTER(ctxp)]),
@@ -374,6 +376,34 @@ class H2Agg:
 
     def g1_msm_device_async(self, handle: int, d_scalars_ptr: int, n: int, d_out_ptr: int):
         self._check(self._lib.h2agg_g1_msm_device_async(self._ctx, handle, d_scalars_ptr, n, d_out_ptr))
+
+    # ------------------------------------------------------------------ transcript side
+    def poseidon_squeeze_batch(self, elems: bytes, nproofs: int, upto: Sequence[int]) -> bytes:
+        """nproofs sponges (T=9, RATE=8, R_F=8, R_P=63): elems [nproofs][nelem] canonical Fr -> [nproofs][len(upto)] challenges"""
+        nelem = (len(elems) // 32) // max(nproofs, 1)
+        _need(elems, 32 * nelem * nproofs, "elems")
+        nsq = len(upto)
+        arr = (C.c_uint32 * max(nsq, 1))(*upto)
+        out = C.create_string_buffer(max(32 * nproofs * nsq, 1))
+        self._check(self._lib.h2agg_poseidon_squeeze_batch(self._ctx, elems, nproofs, nelem, arr, nsq, out))
+        return out.raw[:32 * nproofs * nsq]
+
+    def transcript_read_batch(self, proofs: Sequence[bytes], script: str, consts: bytes = b"", ext_points_aff: bytes = b""):
+        """PoseidonTranscriptRead over same-layout proofs -> (points [proof] bytes, challenges [proof] bytes)"""
+        nproofs = len(proofs)
+        plen = 32 * (script.count("P") + script.count("S"))
+        for p in proofs:
+            _need(p, plen, "proof")
+        npts, nsq, nx = script.count("P"), script.count("Q"), script.count("X")
+        _need(consts, 32 * script.count("C"), "consts")
+        _need(ext_points_aff, 64 * nx * nproofs, "ext_points_aff")
+        pts = C.create_string_buffer(max(64 * npts * nproofs, 1))
+        ch = C.create_string_buffer(max(32 * nsq * nproofs, 1))
+        sb = script.encode()
+        self._check(self._lib.h2agg_transcript_read_batch(self._ctx, b"".join(proofs), plen, nproofs, sb, len(sb), consts,
+                                                          len(consts) // 32, ext_points_aff, nx, pts, ch))
+        return ([pts.raw[64 * npts * i:64 * npts * (i + 1)] for i in range(nproofs)],
+                [ch.raw[32 * nsq * i:32 * nsq * (i + 1)] for i in range(nproofs)])
 
     # ------------------------------------------------------------------ multi-GPU exchange (RCCL inside the C ABI)
     @staticmethod

@@ -318,37 +318,43 @@ FP_INLINE Fq fq_sqrt_candidate(const Fq& a) {   // a^((p+1)/4), Montgomery in / 
     }
     return acc;
 }
+// one 32-byte encoding -> canonical affine coordinates (zeros for the identity and for an invalid encoding); false = invalid
+FP_INLINE bool g1_decompress_one(U256 w, Fq& ox, Fq& oy) {
+    const uint32_t ysign = w.w[7] >> 31;
+    w.w[7] &= 0x7fffffffu;
+    Fq x = fp_unpack<FqParams>(w.w);
+    bool good = fp_is_canonical<FqParams>(x);
+    ox = Fq::zero();
+    oy = Fq::zero();
+    if (good && !(x.is_zero_int() && !ysign)) {
+        const Fq xm = fp_to_mont<FqParams>(x);
+        Fq three;
+#pragma unroll
+        for (int k = 0; k < NL; ++k) three.l[k] = 0;
+        three.l[0] = 3;
+        const Fq rhs = FQ_ADD(FQ_MUL(FQ_SQR(xm), xm), fp_to_mont<FqParams>(three));   // x^3 + 3, [4]
+        const Fq y = fq_sqrt_candidate(rhs);
+        good = fp_is_zero_mod<8, FqParams>(FQ_SUB(4, FQ_SQR(y), rhs));               // y^2 == rhs
+        Fq yc = fp_from_mont<FqParams>(y);                                             // canonical
+        if ((yc.l[0] & 1u) != ysign) {                                                 // take the other root: p - y
+            int32_t d[NL];
+#pragma unroll
+            for (int k = 0; k < NL; ++k) d[k] = (int32_t)FqParams::MOD[k] - (int32_t)yc.l[k];
+            yc = fp_normalize<FqParams>(d);                                            // y != 0 here (3 is a non-residue)
+        }
+        if (good) {
+            ox = x;
+            oy = yc;
+        }
+    }
+    return good;
+}
 __global__ void __launch_bounds__(BLOCK) k_g1_batch_decompress(const uint8_t* __restrict__ in, size_t n,
                                                                uint8_t* __restrict__ out_aff, uint8_t* __restrict__ ok,
                                                                uint32_t* flags) {
     for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
-        U256 w = u256_load(in + 32 * i);
-        const uint32_t ysign = w.w[7] >> 31;
-        w.w[7] &= 0x7fffffffu;
-        Fq x = fp_unpack<FqParams>(w.w);
-        bool good = fp_is_canonical<FqParams>(x);
-        Fq ox = Fq::zero(), oy = Fq::zero();
-        if (good && !(x.is_zero_int() && !ysign)) {
-            const Fq xm = fp_to_mont<FqParams>(x);
-            Fq three;
-#pragma unroll
-            for (int k = 0; k < NL; ++k) three.l[k] = 0;
-            three.l[0] = 3;
-            const Fq rhs = FQ_ADD(FQ_MUL(FQ_SQR(xm), xm), fp_to_mont<FqParams>(three));   // x^3 + 3, [4]
-            const Fq y = fq_sqrt_candidate(rhs);
-            good = fp_is_zero_mod<8, FqParams>(FQ_SUB(4, FQ_SQR(y), rhs));               // y^2 == rhs
-            Fq yc = fp_from_mont<FqParams>(y);                                             // canonical
-            if ((yc.l[0] & 1u) != ysign) {                                                 // take the other root: p - y
-                int32_t d[NL];
-#pragma unroll
-                for (int k = 0; k < NL; ++k) d[k] = (int32_t)FqParams::MOD[k] - (int32_t)yc.l[k];
-                yc = fp_normalize<FqParams>(d);                                            // y != 0 here (3 is a non-residue)
-            }
-            if (good) {
-                ox = x;
-                oy = yc;
-            }
-        }
+        Fq ox, oy;
+        const bool good = g1_decompress_one(u256_load(in + 32 * i), ox, oy);
         if (!good) atomicOr(flags, FLAG_BAD_POINT);
         if (ok) ok[i] = good ? 1 : 0;
         fp_store<FqParams>(out_aff + 64 * i, ox);

@@ -16,7 +16,8 @@
 
 #include "scalar_mul_kernels.cuh"
 #include "pairing.hpp"
-#include "schema.cuh"
+#include "poseidon_host.hpp"
+#include "poseidon_kernels.cuh"
 
 using namespace h2agg;
 
@@ -65,6 +66,10 @@ struct h2agg_ctx {
     DevBuf in_a, in_b, in_c, out, tmp_bases;                      // host-buffer entry points
     DevBuf comb;                                                  // fixed-base comb table of the generator (k_comb_table_build)
     bool comb_ready = false;
+    // transcript side (csrc/transcript.inc): Poseidon constants as device registers; staging of proofs / items; the
+    // decompressed points, element streams and challenges of the last transcript batch
+    DevBuf psd_spec, tr_in, tr_points, tr_elems, tr_chal;
+    bool psd_ready = false;
     DevBuf hist, offs, pmeta, item_idx, item_sub, order, entries, big_list, big_keys, big_part,
         glv_buf, parts, small, endo_buf, tile_counts;  // MSM (bulk side: main stream only)
     uint32_t* d_flags = nullptr;      // in `small`: [0] status flags, [1] big_count
@@ -659,7 +664,7 @@ void h2agg_destroy(h2agg_ctx* c) {
     for (int k = 0; k < h2agg_ctx::TAIL_SLOTS; ++k)
         if (c->tail_streams[k]) hipStreamSynchronize(c->tail_streams[k]);
     static_assert(h2agg_ctx::TAIL_SLOTS == 3, "the list below names every tail slot's buffers");
-    DevBuf* bufs[] = {&c->in_a,  &c->in_b,     &c->in_c,     &c->out,   &c->tmp_bases, &c->comb, &c->hist,
+    DevBuf* bufs[] = {&c->in_a,  &c->in_b,     &c->in_c,     &c->out,   &c->tmp_bases, &c->comb, &c->psd_spec, &c->tr_in, &c->tr_points, &c->tr_elems, &c->tr_chal, &c->hist,
                       &c->offs,  &c->pmeta,    &c->item_idx, &c->item_sub, &c->order,  &c->entries,
                       &c->buckets[0], &c->buckets[1], &c->buckets[2], &c->segsum[0], &c->segsum[1], &c->segsum[2],
                       &c->wsum[0], &c->wsum[1], &c->wsum[2], &c->big_list, &c->big_keys, &c->big_part, &c->glv_buf, &c->parts, &c->small, &c->endo_buf, &c->tile_counts,
@@ -1565,4 +1570,5 @@ int h2agg_final_pair_check(h2agg_ctx* c, const uint8_t left_aff[64], const uint8
 }  // extern "C"
 
 #include "schema_api.inc"
+#include "transcript.inc"
 #include "comm.inc"

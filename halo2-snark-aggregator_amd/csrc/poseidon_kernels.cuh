@@ -1,0 +1,216 @@
+// Poseidon sponge + transcript on the device.
+//
+// Stands behind
+//   PoseidonChip::{update, squeeze, permutation}   halo2-snark-aggregator-api/src/hash/poseidon.rs:167-230
+//       absorb_with_pre_constants :45-86 (padding one), x_power5_with_constant :9-19, apply_mds :88-110,
+//       apply_sparse_mds :112-141
+//   PoseidonEncode::{encode_point, encode_scalar}  halo2-snark-aggregator-api/src/mock/transcript_encode.rs:28-63
+//   PoseidonTranscriptRead::{read_point, read_scalar, common_point, common_scalar, squeeze_challenge_scalar}
+//                                                  halo2-snark-aggregator-api/src/systems/halo2/transcript.rs:56-179
+// with T = 9, RATE = 8, R_F = 8, R_P = 63 (halo2-snark-aggregator-circuit/src/verify_circuit.rs:127-135).
+//
+// A transcript is a strictly sequential chain (state_{k+1} = permutation(state_k + chunk_k)); what is parallel is the
+// batch: every proof of an aggregation has its own sponge.  One group of 16 lanes per proof (lanes 0..8 hold the nine
+// state words, Montgomery, < 2r), four proofs per 64-lane workgroup; all proofs of a launch share the layout, so control
+// flow is uniform and the lanes of a group exchange words through LDS with workgroup barriers.  The reader's interleaved
+// "read, absorb, squeeze" becomes: the host lays out the element stream once per circuit (which proof items are points,
+// which scalars, after how many elements each challenge is squeezed), one kernel builds every proof's elements from the
+// decompressed points and the raw scalars, and one kernel runs the sponges.
+//
+// Constants: csrc/poseidon_host.hpp (Grain LFSR + optimized schedule), uploaded once per context as 9-limb registers:
+//   START(k, i) k < 5 | PARTIAL(k) k < 63 | END(k, i) k < 3 | MDS(i, j) | PRE(i, j) | SROW(k, j) | SCOL(k, j) j < 8
+#pragma once
+#include "schema.cuh"
+
+namespace h2agg {
+
+constexpr int PSD_T = 9, PSD_RF = 8, PSD_RP = 63, PSD_H = PSD_RF / 2;
+constexpr uint32_t PSD_START = 0, PSD_PARTIAL = PSD_START + (PSD_H + 1) * PSD_T, PSD_END = PSD_PARTIAL + PSD_RP,
+                   PSD_MDS = PSD_END + (PSD_H - 1) * PSD_T, PSD_PRE = PSD_MDS + PSD_T * PSD_T,
+                   PSD_SROW = PSD_PRE + PSD_T * PSD_T, PSD_SCOL = PSD_SROW + PSD_RP * PSD_T,
+                   PSD_NCONST = PSD_SCOL + PSD_RP * (PSD_T - 1);
+constexpr int PSD_GROUP = 16, PSD_BLOCK = 64, PSD_PER_BLOCK = PSD_BLOCK / PSD_GROUP;
+
+FP_INLINE Fr fr_add2r(const Fr& a, const Fr& b) { return fr_fold_2r(fp_add<FrParams>(a, b)); }   // < 2r + < 2r -> < 2r
+FP_INLINE Fr fr_pow5_plus(const Fr& x, const Fr& c) {   // x^5 + c  (x_power5_with_constant, poseidon.rs:9-19)
+    const Fr x2 = fp_sqr<FrParams>(x);
+    const Fr x4 = fp_sqr<FrParams>(x2);
+    return fr_add2r(fp_mul<FrParams>(x4, x), c);
+}
+
+struct PsdLds {
+    uint32_t w[PSD_PER_BLOCK][PSD_T + 1][NL];   // slots 0..8: one word per lane; slot 9: the broadcast s0 of a partial round
+};
+FP_INLINE void psd_put(PsdLds& x, int g, int i, const Fr& v) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) x.w[g][i][k] = v.l[k];
+}
+FP_INLINE Fr psd_get(const PsdLds& x, int g, int i) {
+    Fr v;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) v.l[k] = x.w[g][i][k];
+    return v;
+}
+// s <- M s for a dense T x T matrix at spec[base ..]: every lane publishes its word, then forms its row's dot product
+FP_INLINE Fr psd_dense(const uint32_t* __restrict__ spec, uint32_t base, PsdLds& x, int g, int l, int lc, const Fr& s) {
+    if (l < PSD_T) psd_put(x, g, l, s);
+    __syncthreads();
+    Fr acc = fp_mul<FrParams>(reg_load(spec, base + lc * PSD_T), psd_get(x, g, 0));
+#pragma unroll 1
+    for (int j = 1; j < PSD_T; ++j) acc = fr_add2r(acc, fp_mul<FrParams>(reg_load(spec, base + lc * PSD_T + j), psd_get(x, g, j)));
+    __syncthreads();
+    return acc;
+}
+
+// PoseidonChip::permutation (poseidon.rs:193-230) on the group's state; `inp` = this lane's absorbed input (Montgomery;
+// zero on lanes without one), nin = inputs in this chunk (< T)
+FP_INLINE Fr psd_permute(const uint32_t* __restrict__ spec, PsdLds& x, int g, int l, int lc, Fr s, const Fr& inp, uint32_t nin) {
+    // absorb_with_pre_constants: s[0] += pc[0]; s[1 ..= nin] += input + pc; s[nin + 1] += pc + 1; the rest += pc
+    s = fr_add2r(s, reg_load(spec, PSD_START + lc));
+    s = fr_add2r(s, inp);
+    if ((uint32_t)l == nin + 1) s = fr_add2r(s, Fr::one());
+#pragma unroll 1
+    for (int k = 1; k < PSD_H; ++k) {
+        s = fr_pow5_plus(s, reg_load(spec, PSD_START + k * PSD_T + lc));
+        s = psd_dense(spec, PSD_MDS, x, g, l, lc, s);
+    }
+    s = fr_pow5_plus(s, reg_load(spec, PSD_START + PSD_H * PSD_T + lc));
+    s = psd_dense(spec, PSD_PRE, x, g, l, lc, s);
+#pragma unroll 1
+    for (int k = 0; k < PSD_RP; ++k) {
+        // sbox_part: only s[0]; apply_sparse_mds: s0' = row . s, s_i' = col_hat[i-1] * s0 + s_i (s0 = the value AFTER the S-box)
+        const Fr sb = fr_pow5_plus(s, reg_load(spec, PSD_PARTIAL + k));
+        if (l == 0) s = sb;
+        const Fr u = fp_mul<FrParams>(reg_load(spec, PSD_SROW + k * PSD_T + lc), s);   // row[l] * s_l
+        if (l < PSD_T) psd_put(x, g, l, u);
+        if (l == 0) psd_put(x, g, PSD_T, s);                   // broadcast the post-S-box s0
+        __syncthreads();
+        Fr sum = psd_get(x, g, 0);
+#pragma unroll 1
+        for (int j = 1; j < PSD_T; ++j) sum = fr_add2r(sum, psd_get(x, g, j));
+        const Fr s0 = psd_get(x, g, PSD_T);
+        __syncthreads();
+        const Fr upd = fr_add2r(fp_mul<FrParams>(reg_load(spec, PSD_SCOL + k * (PSD_T - 1) + (lc ? lc - 1 : 0)), s0), s);
+        s = (l == 0) ? sum : upd;
+    }
+#pragma unroll 1
+    for (int k = 0; k < PSD_H - 1; ++k) {
+        s = fr_pow5_plus(s, reg_load(spec, PSD_END + k * PSD_T + lc));
+        s = psd_dense(spec, PSD_MDS, x, g, l, lc, s);
+    }
+    s = fr_pow5_plus(s, Fr::zero());
+    return psd_dense(spec, PSD_MDS, x, g, l, lc, s);
+}
+
+// One sponge per proof.  elems: canonical Fr (32 B) at elems[p * elem_stride + 32 * i]; upto[q] = number of elements
+// absorbed before squeeze q (non-decreasing; equal consecutive values = squeeze again without absorbing); out[p][q] =
+// challenge q, canonical.  PoseidonChip::squeeze (poseidon.rs:171-191): pending elements in chunks of RATE, one more
+// permutation of the empty chunk when the last chunk was full or there was nothing to absorb.
+__global__ void __launch_bounds__(PSD_BLOCK) k_poseidon_transcript(const uint32_t* __restrict__ spec,
+                                                                   const uint8_t* __restrict__ elems, size_t elem_stride,
+                                                                   const uint32_t* __restrict__ upto, uint32_t nsq,
+                                                                   uint32_t nproofs, uint8_t* __restrict__ out,
+                                                                   uint32_t* flags) {
+    __shared__ PsdLds x;
+    const int g = threadIdx.x / PSD_GROUP, l = threadIdx.x % PSD_GROUP, lc = l < PSD_T ? l : PSD_T - 1;
+    const uint32_t p = blockIdx.x * PSD_PER_BLOCK + g;
+    const bool live = p < nproofs;
+    const uint8_t* my = elems + (size_t)(live ? p : nproofs - 1) * elem_stride;
+    Fr s = Fr::zero();
+    if (l == 0) {   // poseidon::State::default(): (2^64, 0, ..., 0)
+        Fr v = Fr::zero();
+        v.l[2] = 1u << 6;   // 2^64 = 2^(2*29 + 6)
+        s = fp_to_mont<FrParams>(v);
+    }
+    uint32_t pos = 0, bad = 0;
+#pragma unroll 1
+    for (uint32_t q = 0; q < nsq; ++q) {
+        const uint32_t end = upto[q];
+        uint32_t padding_offset = 0;
+        bool any = false;
+#pragma unroll 1
+        while (pos < end) {
+            const uint32_t nin = (end - pos < (uint32_t)(PSD_T - 1)) ? end - pos : (uint32_t)(PSD_T - 1);
+            Fr inp = Fr::zero();
+            if (l >= 1 && (uint32_t)l <= nin) {
+                const Fr c = fp_load<FrParams>(my + 32 * (size_t)(pos + l - 1));
+                bad |= !fp_is_canonical<FrParams>(c);
+                inp = fp_to_mont<FrParams>(c);
+            }
+            s = psd_permute(spec, x, g, l, lc, s, inp, nin);
+            padding_offset = (uint32_t)(PSD_T - 1) - nin;
+            pos += nin;
+            any = true;
+        }
+        if (!any || padding_offset == 0) s = psd_permute(spec, x, g, l, lc, s, Fr::zero(), 0);
+        if (live && l == 1) fp_store<FrParams>(out + 32 * ((size_t)p * nsq + q), fp_from_mont<FrParams>(s));
+    }
+    if (bad && live) atomicOr(flags, FLAG_NONCANONICAL);
+}
+
+// ---- the element stream of a proof's transcript -----------------------------------------------------------------------
+// item kinds of a layout entry
+enum : uint32_t { TR_CONST = 0, TR_POINT_EXT = 1, TR_POINT = 2, TR_SCALAR = 3 };
+struct TrItem {
+    uint32_t kind;   // TR_*
+    uint32_t src;    // CONST: index into consts; POINT_EXT: index into the proof's external points (instance commitments);
+                     // POINT / SCALAR: byte offset of the 32-byte item inside the proof
+    uint32_t dst;    // first element index written (points write two)
+    uint32_t pidx;   // POINT: index of the decompressed point among the proof's points
+};
+FP_INLINE Fr fq_int_mod_r(const Fq& a) {   // canonical integer < p  ->  canonical integer mod r  (p < 2r)
+    int32_t d[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) d[i] = (int32_t)a.l[i] - (int32_t)FrParams::MOD[i];
+    Fr t = fp_normalize<FrParams>(d);
+    const bool neg = (int32_t)t.l[8] < 0;
+    Fr r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) r.l[i] = neg ? a.l[i] : t.l[i];
+    return r;
+}
+// decompress the proofs' points (C::from_bytes, transcript.rs:63-70) and lay out every proof's element stream:
+// PoseidonEncode: a point -> (x mod r, y mod r), identity -> (0, 0); a scalar -> itself (Fr::from_repr rejects >= r:
+// "invalid field element encoding in proof" -> FLAG_NONCANONICAL).  One lane per (proof, item).
+__global__ void __launch_bounds__(BLOCK) k_transcript_elements(const uint8_t* __restrict__ proofs, size_t proof_stride,
+                                                               const uint8_t* __restrict__ ext_points, uint32_t n_ext,
+                                                               const uint8_t* __restrict__ consts,
+                                                               const TrItem* __restrict__ items, uint32_t nitems,
+                                                               uint32_t nproofs, uint32_t npoints,
+                                                               uint8_t* __restrict__ points_out /* [proof][npoints][64] */,
+                                                               uint8_t* __restrict__ elems, size_t elem_stride,
+                                                               uint32_t* flags) {
+    const size_t total = (size_t)nproofs * nitems;
+    for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (size_t)gridDim.x * BLOCK) {
+        const uint32_t p = (uint32_t)(t / nitems);
+        const TrItem it = items[t % nitems];
+        uint8_t* e = elems + (size_t)p * elem_stride + 32 * (size_t)it.dst;
+        if (it.kind == TR_CONST) {
+            const Fr c = fp_load<FrParams>(consts + 32 * (size_t)it.src);
+            if (!fp_is_canonical<FrParams>(c)) atomicOr(flags, FLAG_NONCANONICAL);
+            fp_store<FrParams>(e, c);
+        } else if (it.kind == TR_SCALAR) {
+            const Fr c = fp_load<FrParams>(proofs + (size_t)p * proof_stride + it.src);
+            if (!fp_is_canonical<FrParams>(c)) atomicOr(flags, FLAG_NONCANONICAL);
+            fp_store<FrParams>(e, c);
+        } else {
+            Fq ox, oy;
+            if (it.kind == TR_POINT_EXT) {
+                const uint8_t* src = ext_points + 64 * ((size_t)p * n_ext + it.src);
+                ox = fp_load<FqParams>(src);
+                oy = fp_load<FqParams>(src + 32);
+                if (!fp_is_canonical<FqParams>(ox) | !fp_is_canonical<FqParams>(oy)) atomicOr(flags, FLAG_NONCANONICAL);
+            } else {
+                const bool good = g1_decompress_one(u256_load(proofs + (size_t)p * proof_stride + it.src), ox, oy);
+                if (!good) atomicOr(flags, FLAG_BAD_POINT);
+                uint8_t* po = points_out + 64 * ((size_t)p * npoints + it.pidx);
+                fp_store<FqParams>(po, ox);
+                fp_store<FqParams>(po + 32, oy);
+            }
+            fp_store<FrParams>(e, fq_int_mod_r(ox));
+            fp_store<FrParams>(e + 32, fq_int_mod_r(oy));
+        }
+    }
+}
+
+}  // namespace h2agg

@@ -227,6 +227,25 @@ const char* h2agg_schema_name(h2agg_schema* s, size_t i);
 size_t h2agg_schema_names_joined(h2agg_schema* s, char* out, size_t cap);
 size_t h2agg_schema_point_list_len(h2agg_schema* s);
 
+/* ---- transcript side: Poseidon sponge, PoseidonEncode, PoseidonTranscriptRead ------------
+ * replaces: PoseidonChip::{update, squeeze} (halo2-snark-aggregator-api/src/hash/poseidon.rs:167-191, permutation :193-230)
+ * with T = 9, RATE = 8, R_F = 8, R_P = 63 (halo2-snark-aggregator-circuit/src/verify_circuit.rs:127-135), for `nproofs`
+ * independent sponges at once (a sponge is a sequential chain; the batch is what runs in parallel).  elems: [nproofs][nelem]
+ * canonical Fr; upto[q] = number of elements absorbed before squeeze q (non-decreasing, <= nelem; equal consecutive values
+ * squeeze again without absorbing); out: [nproofs][nsq] challenges.  An element >= r -> H2AGG_ERR_NONCANONICAL. */
+int h2agg_poseidon_squeeze_batch(h2agg_ctx* ctx, const uint8_t* elems, size_t nproofs, size_t nelem, const uint32_t* upto,
+                                 size_t nsq, uint8_t* out);
+/* replaces: PoseidonTranscriptRead (halo2-snark-aggregator-api/src/systems/halo2/transcript.rs:10-179) + PoseidonEncode
+ * (mock/transcript_encode.rs:28-74) over `nproofs` proofs of ONE layout.  `script` is the sequence of calls the reader
+ * receives, one character each: 'P' read_point, 'S' read_scalar, 'Q' squeeze_challenge_scalar, 'C' common_scalar(the next
+ * of `consts`), 'X' common_point(the next of this proof's `ext_points_aff`, e.g. its instance commitments, verify.rs:77-97).
+ * proof_len must equal 32 x (number of 'P' and 'S'): the reader's read_exact.  points_out: [nproofs][#P] decoded points
+ * (canonical affine); challenges_out: [nproofs][#Q].  A point that does not decode -> H2AGG_ERR_BAD_POINT ("invalid point
+ * encoding in proof"), a scalar >= r -> H2AGG_ERR_NONCANONICAL ("invalid field element encoding in proof"). */
+int h2agg_transcript_read_batch(h2agg_ctx* ctx, const uint8_t* proofs, size_t proof_len, size_t nproofs, const char* script,
+                                size_t script_len, const uint8_t* consts, size_t nconsts, const uint8_t* ext_points_aff,
+                                size_t next, uint8_t* points_out, uint8_t* challenges_out);
+
 /* ---- multi-GPU exchange -----------------------------------------------------------
  * The one collective of a sharded aggregation: every rank holds partial accumulators (the sharded form of the fold
  * `acc = acc * lambda + proof`, halo2-snark-aggregator-api/src/systems/halo2/verify.rs:926-938, evaluated per shard);

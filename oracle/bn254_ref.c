@@ -423,9 +423,10 @@ int oracle_eval_flat(const uint8_t *pts_aff, const uint8_t *scalars, const uint8
  * are used whatever the window count (round-1 verdict: one thread per window capped the "fair" baseline at 16 threads on
  * a 256-core host).  Each job owns a bucket set; a window's partial sums over the point ranges are added at the end. */
 typedef struct {
-    const g1a *bases; const uint8_t *scalars; size_t n; int c; int W, S;   /* S point ranges per window */
+    g1a *bases; const uint8_t *scalars; size_t n; int c; int W, S;         /* S point ranges per window */
     g1 *parts;                                                             /* [W][S] partial window sums */
     volatile long *next;                                                   /* shared job counter */
+    const uint8_t *bases_aff; volatile long *next_conv;                    /* phase 0: bytes -> Montgomery, in 4096-point blocks */
 } pip_shared;
 
 static unsigned get_window(const uint8_t *s, int bit, int c) {
@@ -435,6 +436,17 @@ static unsigned get_window(const uint8_t *s, int bit, int c) {
         if (b < 256) v |= (unsigned)((s[b >> 3] >> (b & 7)) & 1) << k;
     }
     return v;
+}
+static void *pip_convert(void *arg) {
+    pip_shared *J = (pip_shared *)arg;
+    const long nblk = (long)((J->n + 4095) / 4096);
+    for (;;) {
+        const long b = __sync_fetch_and_add(J->next_conv, 1);
+        if (b >= nblk) break;
+        const size_t lo = (size_t)b * 4096, hi = lo + 4096 < J->n ? lo + 4096 : J->n;
+        for (size_t i = lo; i < hi; ++i) aff_from_bytes(&J->bases[i], J->bases_aff + 64 * i);
+    }
+    return NULL;
 }
 static void *pip_worker(void *arg) {
     pip_shared *J = (pip_shared *)arg;
@@ -472,12 +484,13 @@ int oracle_msm_pippenger(const uint8_t *bases_aff, const uint8_t *scalars, size_
     int S = (nthreads + W - 1) / W;                 /* point ranges per window: W * S >= nthreads jobs */
     if ((size_t)S > n) S = (int)n;
     g1a *bases = (g1a *)malloc(n * sizeof(g1a));
-    for (size_t i = 0; i < n; ++i) aff_from_bytes(&bases[i], bases_aff + 64 * i);
     g1 *parts = (g1 *)malloc((size_t)W * S * sizeof(g1));
-    volatile long next = 0;
-    pip_shared sh = {bases, scalars, n, c, W, S, parts, &next};
+    volatile long next = 0, next_conv = 0;
+    pip_shared sh = {bases, scalars, n, c, W, S, parts, &next, bases_aff, &next_conv};
     if (nthreads > W * S) nthreads = W * S;
     pthread_t *th = (pthread_t *)malloc((size_t)nthreads * sizeof(pthread_t));
+    for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, pip_convert, &sh);   /* every core converts bases */
+    for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
     for (int t = 0; t < nthreads; ++t) pthread_create(&th[t], NULL, pip_worker, &sh);
     for (int t = 0; t < nthreads; ++t) pthread_join(th[t], NULL);
     g1 acc;
