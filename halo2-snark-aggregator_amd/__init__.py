@@ -111,6 +111,9 @@ def load_library():
         "h2agg_schema_point_list_len": (C.c_size_t, [C.c_void_p]),
         "h2agg_poseidon_squeeze_batch": (i32, [ctxp, u8p, sz, sz, C.POINTER(C.c_uint32), sz, vp]),
         "h2agg_transcript_read_batch": (i32, [ctxp, u8p, sz, sz, C.c_char_p, sz, u8p, sz, u8p, sz, vp, vp]),
+        "h2agg_vk_create": (i32, [ctxp, u8p, sz, C.POINTER(C.c_void_p)]),
+        "h2agg_vk_destroy": (None, [C.c_void_p]),
+        "h2agg_verify_aggregation": (i32, [ctxp, vp, sz, u8p, u8p, vp, vp, vp, C.POINTER(i32)]),   # see verifier.py
         "h2agg_comm_unique_id": (i32, [vp]),
         "h2agg_comm_init_rank": (i32, [ctxp, u8p, i32, i32]),
         "h2agg_comm_create": (i32, [C.POINTER(i32), i32, C.POINTER(ctxp)]),

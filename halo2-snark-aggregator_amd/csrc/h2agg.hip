@@ -9,7 +9,9 @@
 #include <cstdlib>
 #include <cstdio>
 #include <cstring>
+#include <algorithm>
 #include <map>
+#include <memory>
 #include <new>
 #include <string>
 #include <vector>
@@ -70,6 +72,8 @@ struct h2agg_ctx {
     // decompressed points, element streams and challenges of the last transcript batch
     DevBuf psd_spec, tr_in, tr_points, tr_elems, tr_chal;
     bool psd_ready = false;
+    // verifier pipeline (csrc/verifier.inc): instance values / commitments of a circuit's proofs, the aggregation transcript
+    DevBuf inst_vals, inst_jac, inst_aff, agg_elems;
     DevBuf hist, offs, pmeta, item_idx, item_sub, order, entries, big_list, big_keys, big_part,
         glv_buf, parts, small, endo_buf, tile_counts;  // MSM (bulk side: main stream only)
     uint32_t* d_flags = nullptr;      // in `small`: [0] status flags, [1] big_count
@@ -664,7 +668,7 @@ void h2agg_destroy(h2agg_ctx* c) {
     for (int k = 0; k < h2agg_ctx::TAIL_SLOTS; ++k)
         if (c->tail_streams[k]) hipStreamSynchronize(c->tail_streams[k]);
     static_assert(h2agg_ctx::TAIL_SLOTS == 3, "the list below names every tail slot's buffers");
-    DevBuf* bufs[] = {&c->in_a,  &c->in_b,     &c->in_c,     &c->out,   &c->tmp_bases, &c->comb, &c->psd_spec, &c->tr_in, &c->tr_points, &c->tr_elems, &c->tr_chal, &c->hist,
+    DevBuf* bufs[] = {&c->in_a,  &c->in_b,     &c->in_c,     &c->out,   &c->tmp_bases, &c->comb, &c->psd_spec, &c->tr_in, &c->tr_points, &c->tr_elems, &c->tr_chal, &c->inst_vals, &c->inst_jac, &c->inst_aff, &c->agg_elems, &c->hist,
                       &c->offs,  &c->pmeta,    &c->item_idx, &c->item_sub, &c->order,  &c->entries,
                       &c->buckets[0], &c->buckets[1], &c->buckets[2], &c->segsum[0], &c->segsum[1], &c->segsum[2],
                       &c->wsum[0], &c->wsum[1], &c->wsum[2], &c->big_list, &c->big_keys, &c->big_part, &c->glv_buf, &c->parts, &c->small, &c->endo_buf, &c->tile_counts,
@@ -1571,4 +1575,5 @@ int h2agg_final_pair_check(h2agg_ctx* c, const uint8_t left_aff[64], const uint8
 
 #include "schema_api.inc"
 #include "transcript.inc"
+#include "verifier.inc"
 #include "comm.inc"

@@ -29,7 +29,7 @@
 namespace h2agg {
 
 // ------------------------------------------------------------------ device side: Fr tape
-enum : uint32_t { TAPE_MUL = 0, TAPE_ADD = 1, TAPE_SUB = 2 };
+enum : uint32_t { TAPE_MUL = 0, TAPE_ADD = 1, TAPE_SUB = 2, TAPE_INV = 3 };   // INV: dst = 1 / a (b unused); 1 / 0 raises FLAG_DIV_ZERO
 struct TapeOp {
     uint32_t dst, a, b, op;
 };
@@ -58,6 +58,20 @@ FP_INLINE Fr fr_fold_2r(const Fr& a) {
     return r;
 }
 
+// one tape operation: MockFieldChip::mul / add / sub  (mock/arith/field.rs:98-105, 39-55); INV = the `b.invert().unwrap()`
+// of MockFieldChip::div (:107-114: inversion of zero panics -> FLAG_DIV_ZERO)
+FP_INLINE Fr tape_exec(const TapeOp& op, const uint32_t* regs, uint32_t* flags) {
+    const Fr a = reg_load(regs, op.a);
+    if (op.op == TAPE_INV) {
+        if (fp_is_zero_mod<2, FrParams>(a)) atomicOr(flags, FLAG_DIV_ZERO);
+        return fp_inv<FrParams>(a);
+    }
+    const Fr b = reg_load(regs, op.b);
+    if (op.op == TAPE_MUL) return fp_mul<FrParams>(a, b);                   // 4/169 + 1 -> < 2r
+    if (op.op == TAPE_ADD) return fr_fold_2r(fp_add<FrParams>(a, b));      // < 4r -> < 2r
+    return fr_fold_2r(fp_sub<2, FrParams>(a, b));                          // a - b + 2r < 4r -> < 2r
+}
+
 // constants: canonical 32-byte integers -> Montgomery registers [0, n)
 __global__ void __launch_bounds__(BLOCK) k_tape_load_consts(const uint8_t* __restrict__ consts, uint32_t n,
                                                             uint32_t* __restrict__ regs, uint32_t* flags) {
@@ -70,16 +84,11 @@ __global__ void __launch_bounds__(BLOCK) k_tape_load_consts(const uint8_t* __res
 // one dependency level of the tape: every op's inputs were produced by earlier levels
 // MockFieldChip::mul / add / sub  (mock/arith/field.rs:98-105, 39-55)
 __global__ void __launch_bounds__(BLOCK) k_tape_level(const TapeOp* __restrict__ ops, uint32_t n,
-                                                      uint32_t* __restrict__ regs) {
+                                                      uint32_t* __restrict__ regs, uint32_t* flags) {
     const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
     if (i >= n) return;
     const TapeOp op = ops[i];
-    const Fr a = reg_load(regs, op.a), b = reg_load(regs, op.b);
-    Fr r;
-    if (op.op == TAPE_MUL) r = fp_mul<FrParams>(a, b);                       // 4/169 + 1 -> < 2r
-    else if (op.op == TAPE_ADD) r = fr_fold_2r(fp_add<FrParams>(a, b));     // < 4r -> < 2r
-    else r = fr_fold_2r(fp_sub<2, FrParams>(a, b));                         // a - b + 2r < 4r -> < 2r
-    reg_store(regs, op.dst, r);
+    reg_store(regs, op.dst, tape_exec(op, regs, flags));
 }
 // The whole tape in ONE launch: a single 1024-lane workgroup walks the dependency levels with a barrier
 // in between.  Horner chains make tapes deep and narrow (hundreds of levels of a few operations), which is
@@ -87,19 +96,14 @@ __global__ void __launch_bounds__(BLOCK) k_tape_level(const TapeOp* __restrict__
 constexpr int TAPE_THREADS = 1024;
 __global__ void __launch_bounds__(TAPE_THREADS) k_tape_run(const TapeOp* __restrict__ ops,
                                                            const uint32_t* __restrict__ level_start,
-                                                           uint32_t nlevels, uint32_t* __restrict__ regs) {
+                                                           uint32_t nlevels, uint32_t* __restrict__ regs, uint32_t* flags) {
 #pragma unroll 1
     for (uint32_t l = 0; l < nlevels; ++l) {
         const uint32_t lo = level_start[l], hi = level_start[l + 1];
 #pragma unroll 1
         for (uint32_t i = lo + threadIdx.x; i < hi; i += TAPE_THREADS) {
             const TapeOp op = ops[i];
-            const Fr a = reg_load(regs, op.a), b = reg_load(regs, op.b);
-            Fr r;
-            if (op.op == TAPE_MUL) r = fp_mul<FrParams>(a, b);
-            else if (op.op == TAPE_ADD) r = fr_fold_2r(fp_add<FrParams>(a, b));
-            else r = fr_fold_2r(fp_sub<2, FrParams>(a, b));
-            reg_store(regs, op.dst, r);
+            reg_store(regs, op.dst, tape_exec(op, regs, flags));
         }
         __syncthreads();  // workgroup-scope release/acquire: the next level reads these registers
     }
@@ -384,6 +388,16 @@ struct Schema {
         nodes.push_back(n);
         return (uint32_t)nodes.size() - 1;
     }
+    // a Scalar / Eval leaf whose value is an existing tape register (a constant, or the result of recorded operations:
+    // the verifier pipeline computes evaluation points, expected_h_eval, ... on the tape itself)
+    uint32_t add_leaf_reg(SchemaNode::Kind k, uint32_t reg) {
+        SchemaNode n;
+        n.kind = k;
+        n.has_commitment = false;
+        n.reg = reg;
+        nodes.push_back(n);
+        return (uint32_t)nodes.size() - 1;
+    }
     bool valid(uint32_t id) const { return id < nodes.size(); }
     uint32_t add_binary(SchemaNode::Kind k, uint32_t l, uint32_t r) {
         SchemaNode n;
@@ -409,10 +423,28 @@ struct Schema {
     bool batch_multi_open(const char* key, size_t nq, const int32_t* rotation, const uint8_t* points /*32 B each*/,
                           const uint32_t* qnodes, size_t nw, const uint8_t* w /*64 B each*/, const uint8_t v[32],
                           const uint8_t u[32], uint32_t& w_x_out, uint32_t& w_g_out) {
+        return batch_multi_open_impl(key, nq, rotation, points, nullptr, qnodes, nw, w, v, u, 0, 0, w_x_out, w_g_out);
+    }
+    // the same with the evaluation points and v, u given as tape registers
+    bool batch_multi_open_regs(const char* key, size_t nq, const int32_t* rotation, const uint32_t* point_regs,
+                               const uint32_t* qnodes, size_t nw, const uint8_t* w, uint32_t v_reg, uint32_t u_reg,
+                               uint32_t& w_x_out, uint32_t& w_g_out) {
+        return batch_multi_open_impl(key, nq, rotation, nullptr, point_regs, qnodes, nw, w, nullptr, nullptr, v_reg, u_reg,
+                                     w_x_out, w_g_out);
+    }
+    bool batch_multi_open_impl(const char* key, size_t nq, const int32_t* rotation, const uint8_t* points,
+                               const uint32_t* point_regs, const uint32_t* qnodes, size_t nw, const uint8_t* w,
+                               const uint8_t* v, const uint8_t* u, uint32_t v_reg, uint32_t u_reg, uint32_t& w_x_out,
+                               uint32_t& w_g_out) {
         struct Group {
             int32_t rot;
-            const uint8_t* point;
+            size_t first;   // index of the group's first query: its evaluation point is the group's
             std::vector<uint32_t> schemas;
+        };
+        auto leaf_v = [&] { return v ? add_leaf_scalar(SchemaNode::SCALAR, v) : add_leaf_reg(SchemaNode::SCALAR, v_reg); };
+        auto leaf_u = [&] { return u ? add_leaf_scalar(SchemaNode::SCALAR, u) : add_leaf_reg(SchemaNode::SCALAR, u_reg); };
+        auto leaf_point = [&](size_t i) {
+            return points ? add_leaf_scalar(SchemaNode::SCALAR, points + 32 * i) : add_leaf_reg(SchemaNode::SCALAR, point_regs[i]);
         };
         std::vector<Group> groups;
         for (size_t i = 0; i < nq; ++i) {                                     // :33-43
@@ -423,7 +455,7 @@ struct Schema {
             size_t g = 0;
             for (; g < groups.size(); ++g)
                 if (groups[g].rot == rotation[i]) break;
-            if (g == groups.size()) groups.push_back({rotation[i], points + 32 * i, {}});
+            if (g == groups.size()) groups.push_back({rotation[i], i, {}});
             groups[g].schemas.push_back(qnodes[i]);
         }
         if (nw != groups.size()) {
@@ -436,7 +468,7 @@ struct Schema {
             const std::vector<uint32_t>& sc = groups[g].schemas;
             uint32_t acc = sc.back();
             for (size_t k = sc.size() - 1; k-- > 0;) {
-                const uint32_t vn = add_leaf_scalar(SchemaNode::SCALAR, v);
+                const uint32_t vn = leaf_v();
                 acc = add_binary(SchemaNode::ADD, add_binary(SchemaNode::MUL, vn, acc), sc[k]);
             }
             s_of[g] = acc;
@@ -447,15 +479,14 @@ struct Schema {
             const std::string wkey = std::string(key) + "_w" + std::to_string(gi);
             const uint32_t wid = intern(wkey.c_str());
             const uint32_t cw = add_commitment_id(wid, w + 64 * gi);
-            const uint32_t zc = add_binary(SchemaNode::MUL, add_leaf_scalar(SchemaNode::SCALAR, groups[gi].point),
-                                           add_commitment_id(wid, w + 64 * gi));
+            const uint32_t zc = add_binary(SchemaNode::MUL, leaf_point(groups[gi].first), add_commitment_id(wid, w + 64 * gi));
             if (!have) {
                 w_x = cw;
                 w_g = add_binary(SchemaNode::ADD, zc, s_of[gi]);
                 have = true;
             } else {
-                w_x = add_binary(SchemaNode::ADD, add_binary(SchemaNode::MUL, add_leaf_scalar(SchemaNode::SCALAR, u), w_x), cw);
-                const uint32_t uw = add_binary(SchemaNode::MUL, add_leaf_scalar(SchemaNode::SCALAR, u), w_g);
+                w_x = add_binary(SchemaNode::ADD, add_binary(SchemaNode::MUL, leaf_u(), w_x), cw);
+                const uint32_t uw = add_binary(SchemaNode::MUL, leaf_u(), w_g);
                 w_g = add_binary(SchemaNode::ADD, add_binary(SchemaNode::ADD, uw, zc), s_of[gi]);
             }
         }

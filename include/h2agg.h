@@ -246,6 +246,55 @@ int h2agg_transcript_read_batch(h2agg_ctx* ctx, const uint8_t* proofs, size_t pr
                                 size_t script_len, const uint8_t* consts, size_t nconsts, const uint8_t* ext_points_aff,
                                 size_t next, uint8_t* points_out, uint8_t* challenges_out);
 
+/* ---- verifier-params pipeline + aggregation driver (SURVEY.md 8(f) row 1 and the caller of the hot path) ----------
+ * replaces, for the pure-calculation context: VerifierParamsBuilder::build_params (halo2-snark-aggregator-api/src/systems/
+ * halo2/verify.rs:342-571), VerifierParams::queries (params.rs:74-224) with lagrange.rs / expression.rs / permutation.rs /
+ * lookup.rs / vanish.rs, assign_instance_commitment (verify.rs:574-649), verify_aggregation_proofs_in_chip (verify.rs:
+ * 835-942) and the pairing of calc_verify_circuit_final_pair (halo2-snark-aggregator-circuit/src/verify_circuit.rs:114-201).
+ * The host replays the reference's control flow; every field / group operation runs on the device (instance MSMs, point
+ * decompression, one Poseidon sponge per proof, ONE Fr tape for all expressions and eval_prepare scalars, the two
+ * multi_exps).
+ *
+ * h2agg_vk: what the path reads of halo2_proofs' VerifyingKey / ConstraintSystem (unvendored), serialized little-endian:
+ *   u32 magic 0x4B563248 ("H2VK"), u32 version 1,
+ *   u32 k, num_advice_columns, num_instance_columns, num_challenges, degree (cs.degree()), blinding_factors,
+ *   advice_column_phase: num_advice bytes; challenge_phase: num_challenges bytes           (each padded to 4 bytes)
+ *   advice_queries, instance_queries, fixed_queries: u32 count, then (u32 column, i32 rotation) each
+ *   permutation columns: u32 count, then (u32 kind: 0 advice / 1 fixed / 2 instance, u32 index) each
+ *   fixed commitments: u32 count + 64 B each; permutation commitments: u32 count + 64 B each   (canonical affine)
+ *   vk transcript scalar: 32 B  (from_bytes_wide(blake2b("Halo2-Verify-Key", pinned vk)), verify.rs:57-70)
+ *   gates: u32 count; per gate u32 polys; per poly an expression;  lookups: u32 count; per lookup: u32 n + input
+ *   expressions, u32 n + table expressions
+ *   expression = u32 byte length + postfix bytecode (padded to 4): 0 CONST(32 B) 1 FIXED(u32 query index) 2 ADVICE(u32)
+ *   3 INSTANCE(u32) 4 CHALLENGE(u32) 5 NEG 6 SUM 7 PRODUCT 8 SCALED(32 B)   (halo2_proofs::plonk::Expression; selectors
+ *   are gone after keygen: expression.rs:33-35)
+ * h2agg_circuit_proofs = CircuitProof (verify.rs:769-783): one verifying key with its proofs; every proof carries ONE
+ * inner proof (instances[i] = that proof's instance columns back to back, instance_lens[i * num_instance_columns + col]
+ * values each); all transcripts of a circuit have one length.  name: CircuitProof::name (keys are "{name}_p{i}").
+ * g_lagrange: a base-table handle holding params.g_lagrange (h2agg_bases_upload; h2agg_bases_precompute speeds it up).
+ * Outputs: the final pair (W_x, W_g) as fs.rs:187-190 lays it out; lambda_out (optional) = the aggregation challenge;
+ * with s_g2 / g2 (both or none) *pairing_ok = e(W_x, s_g2) * e(W_g, -g2) == 1.
+ * Errors: a proof point that does not decode -> H2AGG_ERR_BAD_POINT; a scalar >= r -> H2AGG_ERR_NONCANONICAL; a proof whose
+ * length does not fit the key, a W count different from the number of rotation groups (multiopen.rs:48), an instance
+ * column longer than n - (blinding_factors + 1) (verify.rs:601-603) -> H2AGG_ERR_INVALID; inversion of zero in the
+ * Lagrange / vanishing terms -> H2AGG_ERR_DIV_ZERO (the reference's invert().unwrap()). */
+typedef struct h2agg_vk h2agg_vk;
+int h2agg_vk_create(h2agg_ctx* ctx, const uint8_t* blob, size_t len, h2agg_vk** out);
+void h2agg_vk_destroy(h2agg_vk* vk);
+typedef struct {
+    const h2agg_vk* vk;
+    const char* name;
+    uint64_t g_lagrange;
+    size_t nproofs;
+    const uint8_t* const* transcripts;
+    const size_t* transcript_lens;
+    const uint8_t* const* instances;
+    const uint32_t* instance_lens;
+} h2agg_circuit_proofs;
+int h2agg_verify_aggregation(h2agg_ctx* ctx, const h2agg_circuit_proofs* circuits, size_t ncircuits, const uint8_t* s_g2,
+                             const uint8_t* g2, uint8_t left_aff[64], uint8_t right_aff[64], uint8_t lambda_out[32],
+                             int* pairing_ok);
+
 /* ---- multi-GPU exchange -----------------------------------------------------------
  * The one collective of a sharded aggregation: every rank holds partial accumulators (the sharded form of the fold
  * `acc = acc * lambda + proof`, halo2-snark-aggregator-api/src/systems/halo2/verify.rs:926-938, evaluated per shard);
@@ -287,7 +336,7 @@ int h2agg_final_pair_check(h2agg_ctx* ctx, const uint8_t left_aff[64], const uin
 /* ---- Fr expression tape ------------------------------------------------------
  * A straight-line program over Fr, run on the device by the interpreter EvaluationQuerySchema::eval records into:
  * registers 0 .. nconst-1 are the inputs (canonical, 32 B each), register nconst + k is the result of op k;
- * ops3 = nops x {opcode, a, b} (u32 each; opcode 0 = mul, 1 = add, 2 = sub; a, b < nconst + k).  Independent ops run in
+ * ops3 = nops x {opcode, a, b} (u32 each; opcode 0 = mul, 1 = add, 2 = sub, 3 = inverse of a (b ignored; 1/0 -> H2AGG_ERR_DIV_ZERO, the `invert().unwrap()` of MockFieldChip::div); a, b < nconst + k).  Independent ops run in
  * parallel, a chain costs one multiplication latency per link.  out_regs selects the nout registers returned in `out`
  * (canonical).  This is the shape of the verifier's scalar-side expressions (halo2-snark-aggregator-api/src/systems/halo2/
  * {params,lookup,permutation,vanish,lagrange,expression}.rs evaluate such programs through ArithFieldChip). */
