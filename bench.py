@@ -57,6 +57,21 @@ def cpu_baseline(bases_aff: bytes, scalars: bytes, sample: int):
     return sample / dt, dt, out
 
 
+def usable_cores():
+    """host cores this process can actually burn: the scheduler affinity capped by the cgroup CPU quota (the GPU boxes
+    show 256 logical CPUs but run the container under `cpu.max = 1600000 100000`, i.e. 16 cores' worth of time)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()
+            if q != "max":
+                quota = float(q) / float(per)
+    except (OSError, ValueError):
+        pass
+    return n, quota, max(1, int(min(n, quota) if quota else n))
+
+
 def csrc_sha() -> str:
     """hash of the kernel sources: committed PMC evidence is only valid for the sources it was collected on"""
     import hashlib
@@ -496,7 +511,8 @@ def main():
                 "kind": "port",
                 "sample": "first %d points of the same workload, oracle/bn254_ref.c oracle_multi_exp_naive "
                           "(restated reference algorithm: n double-and-add scalar muls, 1 thread), %.1f s; "
-                          "host has %d cores; %s" % (sample, secs, os.cpu_count() or 0, ref_note),
+                          "host shows %d logical CPUs, %d usable under the container's CPU quota; %s" % (
+                              sample, secs, usable_cores()[0], usable_cores()[2], ref_note),
                 "reference_toolchain": tool,
                 "matches_gpu": cpu_out == gpu_same,
             }
@@ -505,17 +521,23 @@ def main():
             # compared with the naive loop
             from oracle import cref
             full_bases = eng.bases_download(table, 0, n)
-            threads = os.cpu_count() or 1
-            c_cpu = 13 if n >= (1 << 18) else 10
-            t0 = time.perf_counter()
-            b1 = cref.msm_pippenger(full_bases, bytes(s_np.tobytes()), n, c_cpu, threads)
-            t_b1 = time.perf_counter() - t0
+            logical, quota, usable = usable_cores()
+            out["cpu_baseline"]["host"] = {"logical_cpus": logical, "cgroup_cpu_quota_cores": quota, "usable_cores": usable}
+            gpu_aff = eng.g1_batch_to_affine(bytes(d_out[0].cpu().numpy().tobytes()))
+            tries = []
+            for c_cpu, threads in ((16, usable), (13, 2 * usable), (13, logical)):   # best of: one window per core / finer jobs / every logical CPU
+                t0 = time.perf_counter()
+                b1 = cref.msm_pippenger(full_bases, bytes(s_np.tobytes()), n, c_cpu, threads)
+                tries.append({"window_bits": c_cpu, "threads": threads, "seconds": time.perf_counter() - t0,
+                              "matches_gpu": b1 == gpu_aff})
+            best = min(tries, key=lambda t: t["seconds"])
             out["cpu_baseline"]["fair_cpu_pippenger"] = {
-                "value": n / t_b1, "unit": "points/s", "threads": threads, "seconds": t_b1,
-                "matches_gpu": b1 == eng.g1_batch_to_affine(bytes(d_out[0].cpu().numpy().tobytes())),
-                "note": "oracle_msm_pippenger, unsigned %d-bit windows, %d threads over (window, point-range) jobs, full "
-                        "2^%d points, 4 x 64-bit Montgomery + Jacobian mixed additions; NOT the reference algorithm" % (
-                            c_cpu, threads, args.log2n),
+                "value": n / best["seconds"], "unit": "points/s", "threads": best["threads"], "seconds": best["seconds"],
+                "matches_gpu": all(t["matches_gpu"] for t in tries), "tried": tries,
+                "note": "oracle_msm_pippenger on ALL the cores this container may use (%d: %d logical CPUs under a cgroup "
+                        "quota of %s), (window, point-range) jobs from a shared counter, full 2^%d points, 4 x 64-bit "
+                        "Montgomery + Jacobian mixed additions; the best of the configurations tried; NOT the reference "
+                        "algorithm" % (usable, logical, quota, args.log2n),
             }
         print(json.dumps(out))
     if dist is not None:
