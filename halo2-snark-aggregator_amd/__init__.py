@@ -121,6 +121,7 @@ def load_library():
         "h2agg_comm_rank": (i32, [ctxp]),
         "h2agg_allgather_add_points": (i32, [C.POINTER(ctxp), i32, u8p, sz, vp]),
         "h2agg_pairing_check": (i32, [ctxp, u8p, u8p, sz, C.POINTER(i32)]),
+        "h2agg_g2_batch_decompress": (i32, [ctxp, u8p, sz, vp]),
         "h2agg_pairing_product": (i32, [ctxp, u8p, u8p, sz, vp]),
         "h2agg_final_pair_check": (i32, [ctxp, u8p, u8p, u8p, u8p, C.POINTER(i32)]),
         "h2agg_msm_configure": (i32, [ctxp, i32, i32, i32]),
@@ -452,6 +453,14 @@ class H2Agg:
         out = C.create_string_buffer(384)
         self._check(self._lib.h2agg_pairing_product(self._ctx, g1_aff, g2_aff, n, out))
         return out.raw
+
+    def g2_batch_decompress(self, data: bytes) -> bytes:
+        """64-byte compressed G2 points (ParamsKZG::write's g2 / s_g2) -> 128-byte affine"""
+        n = len(data) // 64
+        _need(data, 64 * n, "data")
+        out = C.create_string_buffer(max(128 * n, 1))
+        self._check(self._lib.h2agg_g2_batch_decompress(self._ctx, data, n, out))
+        return out.raw[:128 * n]
 
     def final_pair_check(self, left_aff: bytes, right_aff: bytes, s_g2: bytes, g2: bytes) -> bool:
         """e(left, [s]_2) * e(right, -[1]_2) == 1"""

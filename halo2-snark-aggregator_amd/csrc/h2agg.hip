@@ -1549,6 +1549,24 @@ int h2agg_pairing_check(h2agg_ctx* c, const uint8_t* g1_aff, const uint8_t* g2_a
     return H2AGG_ERR_INVALID;
 }
 
+// ParamsKZG's g2 / s_g2 as stored by ParamsKZG::write (fs.rs:40-55 reads them back through halo2_proofs): 64-byte
+// compressed G2 points -> the 128-byte affine form the pairing entry points take
+int h2agg_g2_batch_decompress(h2agg_ctx* c, const uint8_t* in, size_t n, uint8_t* out_aff) try {
+    if (n && (!in || !out_aff)) return fail(c, H2AGG_ERR_INVALID, "null buffer");
+    for (size_t i = 0; i < n; ++i) {
+        pairing::G2Affine q;
+        const int r = pairing::g2_decompress(in + 64 * i, q);
+        if (r == 1) return fail(c, H2AGG_ERR_NONCANONICAL, "G2 coordinate >= p");
+        if (r) return fail(c, H2AGG_ERR_BAD_POINT, "invalid G2 point encoding (x^3 + b is not a square)");
+        pairing::g2_to_bytes(q, out_aff + 128 * i);
+    }
+    return H2AGG_OK;
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
+}
+
 // e(left, [s]_2) * e(right, -[1]_2) == 1 ?   (verify.rs:733-739: `n_g2_prepared = -params.g2()`)
 int h2agg_final_pair_check(h2agg_ctx* c, const uint8_t left_aff[64], const uint8_t right_aff[64], const uint8_t s_g2[128],
                            const uint8_t g2[128], int* ok) try {

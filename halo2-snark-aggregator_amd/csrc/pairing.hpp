@@ -486,6 +486,81 @@ static inline int load_g2(const uint8_t* b, G2Affine& q) {
     if (nseen < 4) ++nseen;
     return 0;
 }
+// square root in Fq2 = Fq[u]/(u^2 + 1) for p = 3 mod 4 ("complex method"): a = a0 + a1 u; with n = sqrt(a0^2 + a1^2) and
+// d = (a0 +- n) / 2 a square, the root is x0 + x1 u, x0 = sqrt(d), x1 = a1 / (2 x0).  false if `a` is not a square.
+static inline bool fq_sqrt(const Fq& a, Fq& out) {   // a^((p+1)/4), checked
+    static const uint64_t E[4] = {0x4f082305b61f3f52ull, 0x65e05aa45a1c72a3ull, 0x6e14116da0605617ull, 0x0c19139cb84c680aull};
+    const Fq r = fq_pow(a, E);
+    if (!fq_eq(fq_sqr(r), a)) return false;
+    out = r;
+    return true;
+}
+static inline bool f2_sqrt(const Fq2& a, Fq2& out) {
+    if (f2_is_zero(a)) {
+        out = f2_zero();
+        return true;
+    }
+    static const Fq half = fq_inv(fq_from_u64(2));
+    if (fq_is_zero(a.c1)) {
+        Fq r;
+        if (fq_sqrt(a.c0, r)) {
+            out = Fq2{r, fq_zero()};
+            return true;
+        }
+        if (fq_sqrt(fq_neg(a.c0), r)) {   // sqrt(-1) = u
+            out = Fq2{fq_zero(), r};
+            return true;
+        }
+        return false;
+    }
+    Fq n;
+    if (!fq_sqrt(fq_add(fq_sqr(a.c0), fq_sqr(a.c1)), n)) return false;
+    for (int sign = 0; sign < 2; ++sign) {
+        const Fq d = fq_mul(sign ? fq_sub(a.c0, n) : fq_add(a.c0, n), half);
+        Fq x0;
+        if (!fq_sqrt(d, x0) || fq_is_zero(x0)) continue;
+        const Fq x1 = fq_mul(a.c1, fq_inv(fq_dbl(x0)));
+        const Fq2 cand = {x0, x1};
+        if (f2_eq(f2_sqr(cand), a)) {
+            out = cand;
+            return true;
+        }
+    }
+    return false;
+}
+// G2Affine::from_bytes of halo2curves 0.2.1 (the 64-byte compressed form ParamsKZG::write stores g2 / s_g2 in; recalled
+// from upstream, the crate is not vendored): x.c0 || x.c1 little-endian, bit 7 of the last byte = parity of y.c0
+// (`y.to_bytes()[0] & 1`), identity = zeros.  0 ok, 1 non-canonical coordinate, 2 not on the twist.
+static inline int g2_decompress(const uint8_t in[64], G2Affine& q) {
+    uint8_t t[64];
+    memcpy(t, in, 64);
+    const int ysign = t[63] >> 7;
+    t[63] &= 0x7f;
+    if (!fq_from_bytes(t, q.x.c0) || !fq_from_bytes(t + 32, q.x.c1)) return 1;
+    q.inf = false;
+    if (f2_is_zero(q.x) && !ysign) {
+        q.inf = true;
+        q.y = f2_zero();
+        return 0;
+    }
+    Fq2 y;
+    if (!f2_sqrt(f2_add(f2_mul(f2_sqr(q.x), q.x), twist_b()), y)) return 2;
+    uint8_t yb[32];
+    fq_to_bytes(y.c0, yb);
+    if ((yb[0] & 1) != ysign) y = f2_neg(y);
+    q.y = y;
+    return 0;
+}
+static inline void g2_to_bytes(const G2Affine& q, uint8_t out[128]) {
+    if (q.inf) {
+        memset(out, 0, 128);
+        return;
+    }
+    fq_to_bytes(q.x.c0, out);
+    fq_to_bytes(q.x.c1, out + 32);
+    fq_to_bytes(q.y.c0, out + 64);
+    fq_to_bytes(q.y.c1, out + 96);
+}
 static inline void f12_to_bytes(const Fq12& a, uint8_t* out) {   // 12 x 32 B: c0.c0.c0, c0.c0.c1, c0.c1.c0, ..., c1.c2.c1
     const Fq2* cs[6] = {&a.c0.c0, &a.c0.c1, &a.c0.c2, &a.c1.c0, &a.c1.c1, &a.c1.c2};
     for (int i = 0; i < 6; ++i) {

@@ -329,6 +329,10 @@ int h2agg_allgather_add_points(h2agg_ctx** ctxs, int nctx, const uint8_t* partia
  * h2agg_final_pair_check: *ok = (e(left, s_g2) * e(right, -g2) == 1) — `params.s_g2()`, `params.g2()` as the caller
  *   holds them (ParamsKZG); the negation of g2 happens inside, as in the reference. */
 int h2agg_pairing_check(h2agg_ctx* ctx, const uint8_t* g1_aff, const uint8_t* g2_aff, size_t n, int* ok);
+/* 64-byte compressed G2 points (how ParamsKZG::write stores `g2` / `s_g2`; read back at halo2-snark-aggregator-circuit/
+ * src/fs.rs:49-55 through halo2_proofs) -> the 128-byte affine form above.  Encoding recalled from halo2curves 0.2.1:
+ * x.c0 || x.c1 little-endian, bit 7 of byte 63 = parity of y.c0, identity = zeros.  Host arithmetic; ctx may be NULL. */
+int h2agg_g2_batch_decompress(h2agg_ctx* ctx, const uint8_t* in, size_t n, uint8_t* out_aff);
 int h2agg_pairing_product(h2agg_ctx* ctx, const uint8_t* g1_aff, const uint8_t* g2_aff, size_t n, uint8_t out_gt[384]);
 int h2agg_final_pair_check(h2agg_ctx* ctx, const uint8_t left_aff[64], const uint8_t right_aff[64],
                            const uint8_t s_g2[128], const uint8_t g2[128], int* ok);

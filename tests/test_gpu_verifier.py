@@ -106,3 +106,53 @@ def test_vk_blob_validation(eng, pkg):
     for bad in (blob[:-4], blob + b"\0\0\0\0", b"XXXX" + blob[4:], blob[:8] + (99).to_bytes(4, "little") + blob[12:]):
         with pytest.raises(pkg.H2AggError):
             ver.VerifyingKey(eng, bad)
+
+
+def test_verify_run_from_the_reference_files(eng, pkg, tmp_path):
+    """The SDK's `verify_run` in the pure-calculation context (sdk/src/lib.rs:129-148 -> verify_circuit.rs:898-1009 ->
+    calc_verify_circuit_final_pair), from the files the reference's earlier commands leave in --folder-path (fs.rs:40-160)
+    to verify_circuit_final_pair.data (fs.rs:182-195): params decoded on the device, proofs replayed, pairing accepted."""
+    from tests import toy_prover as T
+    from tests.test_fs import _g2_compress
+    ver = importlib.import_module(entry.PKG_NAME + ".verifier")
+    fs = importlib.import_module(entry.PKG_NAME + ".fs")
+    rng = O.SplitMix64(0xF11E)
+    dlogs = {}
+    k = 5
+    setup = T.Setup(k, rng.fr(), 1 << k)
+    cs = T.make_constraint_system(rng, dlogs=dlogs, **SHAPES[0])
+    g = [O.scalar_mul(pow(setup.tau, i, O.R), O.G1) for i in range(1 << k)]
+    params = fs.KzgParams(k, b"".join(O.compress(p) for p in g), b"".join(O.compress(p) for p in setup.g_lagrange),
+                          _g2_compress(setup.g2), _g2_compress(setup.s_g2))
+    (tmp_path / fs.target_circuit_params_name("simple")).write_bytes(fs.write_params(params))
+    nproofs = 2
+    all_inst = []
+    for i in range(nproofs):
+        inst = [[[rng.fr() for _ in range(4)]]]
+        all_inst.append(inst)
+        proof = T.prove(cs, setup, rng, inst, dlogs, "simple_p%d" % i)
+        (tmp_path / fs.target_circuit_proof_name("simple", i)).write_bytes(proof)
+        (tmp_path / fs.target_circuit_instance_name("simple", i)).write_bytes(b"".join(O.fe_to_bytes(v) for v in inst[0][0]))
+    # ---- what verify_run does, on the GPU backend
+    folder = str(tmp_path)
+    p = fs.load_target_circuit_params(folder, "simple")
+    table = fs.upload_g_lagrange(eng, p)
+    vk = ver.VerifyingKey(eng, ver.encode_vk(cs, O.aff_to_bytes))
+    try:
+        s_g2, g2 = fs.pairing_g2(eng, p)
+        proofs = [(fs.load_instances(fs.load_target_circuit_instance(folder, "simple", i))[0:1] and
+                   [b"".join(fs.load_instances(fs.load_target_circuit_instance(folder, "simple", i))[0])],
+                   fs.load_target_circuit_proof(folder, "simple", i)) for i in range(nproofs)]
+        left, right, lam, ok = ver.verify_aggregation(eng, [(vk, "simple", table, proofs)], s_g2, g2)
+        assert ok is True
+        flat_inst = [O.fe_to_bytes(v) for inst in all_inst for v in inst[0][0]]
+        fs.write_verify_circuit_final_pair(folder, left, right, flat_inst)
+        fs.write_verify_circuit_instance(folder, fs.final_pair_to_instances(left, right, flat_inst))
+    finally:
+        vk.close()
+        eng.bases_free(table)
+    # the oracle agrees on every byte of the output file
+    circuits = [V.CircuitProofs("simple", cs, setup.g_lagrange, [(all_inst[i], (tmp_path / fs.target_circuit_proof_name("simple", i)).read_bytes())
+                                                                  for i in range(nproofs)])]
+    wl, wr, plain, _c, _lam = V.verify_aggregation_proofs_in_chip(S.OracleEccChip(), circuits)
+    assert (tmp_path / "verify_circuit_final_pair.data").read_bytes() == S.final_pair_bytes(wl, wr, plain)
