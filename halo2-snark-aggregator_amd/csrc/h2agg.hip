@@ -1391,8 +1391,8 @@ int h2agg_eval_flat(h2agg_ctx* c, const uint8_t* pts, const uint8_t* scalars, co
 // ---------------------------------------------------------------- tuning / measurement
 int h2agg_msm_configure(h2agg_ctx* c, int window_bits, int reduce_segment, int big_bucket_threshold) try {
     if (!c) return H2AGG_ERR_INVALID;
-    if (window_bits != 0 && (window_bits < 2 || window_bits > 16))
-        return fail(c, H2AGG_ERR_INVALID, "window_bits must be 0 or in [2, 16]");
+    if (window_bits != 0 && (window_bits < 2 || window_bits > 20))
+        return fail(c, H2AGG_ERR_INVALID, "window_bits must be 0 or in [2, 20]");
     if (reduce_segment < 0 || (reduce_segment & (reduce_segment - 1)))
         return fail(c, H2AGG_ERR_INVALID, "reduce_segment must be 0 or a power of two");
     if (big_bucket_threshold < 0) return fail(c, H2AGG_ERR_INVALID, "big_bucket_threshold must be >= 0");

@@ -77,3 +77,61 @@ def build_proof(builder, MultiOpenProof, spec: ProofSpec):
     qnodes = builder.evaluation_queries(spec.keys, spec.commitments, spec.evals, wrap=False)
     w_x, w_g = builder.batch_multi_open(spec.key, spec.rotations, spec.points, qnodes, spec.w, spec.v, spec.u)
     return MultiOpenProof(w_x, w_g), qnodes[0]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# A synthetic verifying-key shape + well-formed random transcripts for the WHOLE pipeline (h2agg_verify_aggregation):
+# transcript replay (Poseidon), expressions, queries, fold, both multi_exps, pairing.  The transcripts are not proofs of
+# anything (no prover here): every byte decodes, every challenge is derived, the pairing check runs and rejects.
+class CircuitShape:
+    """the fields of the "H2VK" description (include/h2agg.h); names follow halo2's accessors"""
+
+    def __init__(self, k: int, n_advice: int, pool: Sequence[bytes], seed: int = 0x5AFE, n_lookups: int = 1):
+        fr = fr_stream(seed)
+        self.k = k
+        self.num_advice_columns = n_advice
+        self.num_instance_columns = 1
+        self.num_challenges = 0
+        self.advice_column_phase = [0] * n_advice
+        self.challenge_phase = []
+        self.advice_queries = [(c, 0) for c in range(n_advice)] + [(c, 1) for c in range(0, n_advice, 7)] + [(0, -1)]
+        self.instance_queries = [(0, 0)]
+        self.fixed_queries = [(0, 0), (1, 0)]
+        self.degree = 5                                                     # chunks of 3 permutation columns
+        self.blinding_factors = 5
+        self.permutation_columns = [("advice", c) for c in range(7)] + [("fixed", 0), ("instance", 0)]   # 3 sets
+        self.fixed_commitments = [pool[1], pool[2]]
+        self.permutation_commitments = [pool[3 + i] for i in range(len(self.permutation_columns))]
+        self.vk_scalar = int.from_bytes(fr(), "little")
+        A = lambda i: ("advice", i)
+        F = lambda i: ("fixed", i)
+        # a few gates in the style of the sample circuits: q * (a * b - c), q * (a + b - c), ...
+        self.gates = [[("product", F(0), ("sum", ("product", A(3 * g), A(3 * g + 1)), ("neg", A(3 * g + 2))))]
+                      for g in range(min(8, n_advice // 3))]
+        self.gates.append([("product", F(1), ("sum", ("scaled", A(0), 7), ("neg", ("instance", 0))))])
+        self.lookups = [([A(j), ("product", F(0), A(j + 1))], [F(1), A(j + 2)]) for j in range(n_lookups)]
+        self.n_sets = (len(self.permutation_columns) + 2) // 3
+
+    def rotations(self):
+        rots = []
+        for r in ([0] + [r for _c, r in self.advice_queries] + [1, -(self.blinding_factors + 1)] +
+                  ([0, -1, 1] if self.lookups else [])):
+            if r not in rots:
+                rots.append(r)
+        return rots
+
+    def proof_items(self):
+        """(number of points before the evaluations, number of evaluations, number of W points)"""
+        n_pts = self.num_advice_columns + 2 * len(self.lookups) + self.n_sets + len(self.lookups) + 1 + (self.degree - 1)
+        n_evals = (len(self.instance_queries) + len(self.advice_queries) + len(self.fixed_queries) + 1 +
+                   len(self.permutation_commitments) + (3 * self.n_sets - 1) + 5 * len(self.lookups))
+        return n_pts, n_evals, len(self.rotations())
+
+    def random_transcript(self, pool_compressed: Sequence[bytes], seed: int) -> bytes:
+        fr = fr_stream(seed)
+        n_pts, n_evals, n_w = self.proof_items()
+        npool = len(pool_compressed)
+        pts = b"".join(pool_compressed[(seed * 31 + j) % npool] for j in range(n_pts))
+        evals = b"".join(fr() for _ in range(n_evals))
+        w = b"".join(pool_compressed[(seed * 17 + 5 + j) % npool] for j in range(n_w))
+        return pts + evals + w

@@ -140,9 +140,10 @@ def test_verify_run_from_the_reference_files(eng, pkg, tmp_path):
     vk = ver.VerifyingKey(eng, ver.encode_vk(cs, O.aff_to_bytes))
     try:
         s_g2, g2 = fs.pairing_g2(eng, p)
-        proofs = [(fs.load_instances(fs.load_target_circuit_instance(folder, "simple", i))[0:1] and
-                   [b"".join(fs.load_instances(fs.load_target_circuit_instance(folder, "simple", i))[0])],
-                   fs.load_target_circuit_proof(folder, "simple", i)) for i in range(nproofs)]
+        proofs = []
+        for i in range(nproofs):
+            cols = fs.load_instances(fs.load_target_circuit_instance(folder, "simple", i))      # one column: vec![vec![ret]]
+            proofs.append(([b"".join(col) for col in cols], fs.load_target_circuit_proof(folder, "simple", i)))
         left, right, lam, ok = ver.verify_aggregation(eng, [(vk, "simple", table, proofs)], s_g2, g2)
         assert ok is True
         flat_inst = [O.fe_to_bytes(v) for inst in all_inst for v in inst[0][0]]

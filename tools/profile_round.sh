@@ -21,6 +21,11 @@ for ctrs in "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_
 done
 cd $root
 python tools/make_traffic_json.py $out/${tag} > $out/${tag}_traffic.json 2>> $out/${tag}_traffic.err
+# batch kernels at n = 2^22 (HBM roofline rows)
+cd /tmp && rm -rf /tmp/prof_b && rocprofv3 --kernel-trace --stats -d /tmp/prof_b -o b -- python $root/tools/batch_roofline.py run > /dev/null 2>&1
+python $root/tools/rocpd_summary.py /tmp/prof_b/b_results.db > $out/${tag}_batch_kernel_stats.txt 2>&1
+python $root/tools/batch_roofline.py report $out/${tag}_batch_kernel_stats.txt > $out/${tag}_batch_roofline.txt 2>&1
+cd $root
 # full-size aggregation path trace
 cd /tmp && rm -rf /tmp/prof_agg && rocprofv3 --kernel-trace --stats -d /tmp/prof_agg -o agg -- python $root/tools/agg_phases.py --reps 10 > $out/${tag}_agg_phases.txt 2>/dev/null
 python $root/tools/rocpd_summary.py /tmp/prof_agg/agg_results.db > $out/${tag}_agg_kernel_stats.txt 2>&1
