@@ -148,6 +148,30 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
     syn = importlib.import_module(entry.PKG_NAME + ".synthetic")
     backend = agg.GpuBackend(pkg, eng)
     n_total = args.agg_proofs * world
+    # The one collective of the path: on RCCL it runs INSIDE the C ABI (h2agg_allgather_add_points: ncclAllGather + local EC
+    # adds, csrc/comm.inc) — the entry point a non-Python host binds; the 128-byte id travels over torch.distributed's
+    # existing group.  If the library's communicator cannot be set up on every rank, the exchange falls back to
+    # torch.distributed's all_gather + h2agg_g1_sum and the JSON says so.
+    comm, exchange_how = None, "none (1 rank)"
+    if dist is not None:
+        exchange_how = "torch.distributed all_gather of 128 B per rank + local EC adds (h2agg_g1_sum)"
+        if dist.get_backend() == "nccl":
+            ok = 1
+            try:
+                if eng.comm_size() == 0:
+                    uid = torch.zeros(128, dtype=torch.uint8, device=coll_dev)
+                    if rank == 0:
+                        uid = torch.frombuffer(bytearray(pkg.H2Agg.comm_unique_id()), dtype=torch.uint8).to(coll_dev)
+                    dist.broadcast(uid, src=0)
+                    eng.comm_init_rank(bytes(uid.cpu().numpy().tobytes()), rank, world)
+            except Exception as ex:          # noqa: BLE001 - any failure here only selects the other exchange
+                ok = 0
+                print("rank %d: C-ABI communicator not available (%s)" % (rank, ex), file=sys.stderr)
+            flag = torch.tensor([ok], dtype=torch.int32, device=coll_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                comm = eng
+                exchange_how = "h2agg_allgather_add_points (RCCL all-gather of 192 B per rank inside the C ABI + local EC adds)"
     # per-proof data generated once (same on every rank: seeded); building the schemas is inside the timed region
     pool = syn.point_pool(eng, 0xA66)
     specs, lam = syn.make_proofs(pool, n_total, args.agg_commitments)
@@ -190,7 +214,8 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
                 last_commits[idx[j]] = aff[64 * j:64 * j + 64]
         return out
 
-    pair = agg.aggregate_sharded(backend, build, n_total, lam, dist=dist, device=coll_dev)     # warm-up
+    pair = agg.aggregate_sharded(backend, build, n_total, lam, dist=dist, device=coll_dev, comm=comm,
+                                 rank_world=(rank, world))     # warm-up
     # ---- what is about to be timed must be right: refuse to report a rate for a pair that a second route through the
     # product does not reproduce (single rank: every proof is local, so the whole fold can be recomputed here)
     verified = None
@@ -207,10 +232,13 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
+    reps = 8
+    times = []
     t0 = time.perf_counter()
-    reps = 3
     for _ in range(reps):
-        pair2 = agg.aggregate_sharded(backend, build, n_total, lam, dist=dist, device=coll_dev)
+        t1 = time.perf_counter()
+        pair2 = agg.aggregate_sharded(backend, build, n_total, lam, dist=dist, device=coll_dev, comm=comm, rank_world=(rank, world))
+        times.append(time.perf_counter() - t1)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
@@ -225,10 +253,13 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
         "proofs_per_sec": n_total / dt,
         "proofs": n_total,
         "seconds_per_aggregation": dt,
+        "seconds_per_aggregation_min_max": [min(times), max(times)],
+        "repetitions": reps,
         "commitments_per_proof": specs[0].nq,
         "instance_msm_points_per_proof": n_inst,
         "instance_msm_fixed_base_levels": bool(n_inst and args.agg_instance_log2 <= 18 and not args.no_fixed_base),
         "final_pair_sha": __import__("hashlib").sha256(pair[0] + pair[1]).hexdigest()[:16],
+        "exchange": exchange_how,
         "verified": verified if verified else "sharded run: every rank's timed repetitions reproduce the warm-up pair "
                                               "(the single-rank run of the same proofs is cross-checked per proof)",
         "note": "synthetic shape-faithful schemas; per proof: the instance-column commitment MSM against the fixed "
