@@ -51,13 +51,40 @@ FP_INLINE Fr psd_get(const PsdLds& x, int g, int i) {
     for (int k = 0; k < NL; ++k) v.l[k] = x.w[g][i][k];
     return v;
 }
-// s <- M s for a dense T x T matrix at spec[base ..]: every lane publishes its word, then forms its row's dot product
+// lane 0 of every 16-lane group -> all lanes of the group (ds_bpermute; the groups are DPP rows)
+FP_INLINE Fr psd_bcast0(const Fr& v) {
+    Fr r;
+    const int src = (int)(threadIdx.x & ~(PSD_GROUP - 1)) & 63;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) r.l[k] = (uint32_t)__shfl((int)v.l[k], src, 64);
+    return r;
+}
+// sum over the 16 lanes of a group, result valid in lane 0: four row_shl steps (lanes past the row read zero)
+template <int N>
+FP_INLINE Fr psd_shl(const Fr& v) {
+    Fr r;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) r.l[k] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[k], 0x100 + N, 0xF, 0xF, true);
+    return r;
+}
+FP_INLINE Fr psd_row_sum(Fr t) {
+    t = fr_add2r(t, psd_shl<1>(t));
+    t = fr_add2r(t, psd_shl<2>(t));
+    t = fr_add2r(t, psd_shl<4>(t));
+    return fr_add2r(t, psd_shl<8>(t));
+}
+// s <- M s for a dense T x T matrix at spec[base ..]: every lane publishes its word, then forms its row's dot product as
+// three 3-term products with one Montgomery reduction each (fp_mul3)
 FP_INLINE Fr psd_dense(const uint32_t* __restrict__ spec, uint32_t base, PsdLds& x, int g, int l, int lc, const Fr& s) {
     if (l < PSD_T) psd_put(x, g, l, s);
     __syncthreads();
-    Fr acc = fp_mul<FrParams>(reg_load(spec, base + lc * PSD_T), psd_get(x, g, 0));
-#pragma unroll 1
-    for (int j = 1; j < PSD_T; ++j) acc = fr_add2r(acc, fp_mul<FrParams>(reg_load(spec, base + lc * PSD_T + j), psd_get(x, g, j)));
+    const uint32_t rb = base + lc * PSD_T;
+    Fr acc = fp_mul3_ps<FrParams>(reg_load(spec, rb), psd_get(x, g, 0), reg_load(spec, rb + 1), psd_get(x, g, 1),
+                                  reg_load(spec, rb + 2), psd_get(x, g, 2));
+    acc = fr_add2r(acc, fp_mul3_ps<FrParams>(reg_load(spec, rb + 3), psd_get(x, g, 3), reg_load(spec, rb + 4), psd_get(x, g, 4),
+                                             reg_load(spec, rb + 5), psd_get(x, g, 5)));
+    acc = fr_add2r(acc, fp_mul3_ps<FrParams>(reg_load(spec, rb + 6), psd_get(x, g, 6), reg_load(spec, rb + 7), psd_get(x, g, 7),
+                                             reg_load(spec, rb + 8), psd_get(x, g, 8)));
     __syncthreads();
     return acc;
 }
@@ -76,22 +103,32 @@ FP_INLINE Fr psd_permute(const uint32_t* __restrict__ spec, PsdLds& x, int g, in
     }
     s = fr_pow5_plus(s, reg_load(spec, PSD_START + PSD_H * PSD_T + lc));
     s = psd_dense(spec, PSD_PRE, x, g, l, lc, s);
+    if (l >= PSD_T) s = Fr::zero();   // idle lanes carry zeros: they take part in the row sums below
 #pragma unroll 1
     for (int k = 0; k < PSD_RP; ++k) {
-        // sbox_part: only s[0]; apply_sparse_mds: s0' = row . s, s_i' = col_hat[i-1] * s0 + s_i (s0 = the value AFTER the S-box)
-        const Fr sb = fr_pow5_plus(s, reg_load(spec, PSD_PARTIAL + k));
-        if (l == 0) s = sb;
-        const Fr u = fp_mul<FrParams>(reg_load(spec, PSD_SROW + k * PSD_T + lc), s);   // row[l] * s_l
-        if (l < PSD_T) psd_put(x, g, l, u);
-        if (l == 0) psd_put(x, g, PSD_T, s);                   // broadcast the post-S-box s0
-        __syncthreads();
-        Fr sum = psd_get(x, g, 0);
-#pragma unroll 1
-        for (int j = 1; j < PSD_T; ++j) sum = fr_add2r(sum, psd_get(x, g, j));
-        const Fr s0 = psd_get(x, g, PSD_T);
-        __syncthreads();
-        const Fr upd = fr_add2r(fp_mul<FrParams>(reg_load(spec, PSD_SCOL + k * (PSD_T - 1) + (lc ? lc - 1 : 0)), s0), s);
-        s = (l == 0) ? sum : upd;
+        // sbox_part (only s[0]) + apply_sparse_mds: s0' = row . s, s_i' = col_hat[i-1] * s0 + s_i, s0 = the value AFTER the
+        // S-box.  Four multiplication issues per round for the whole group (a wave's lanes multiply in lockstep):
+        //   1: lane 0: s0^2            lanes >= 1: u_i = row[i] * s_i     (independent of the S-box)
+        //   2: lane 0: s0^4    3: lane 0: s0^5 (+ c)
+        //   4: lane 0: row[0] * s0'    lanes >= 1: col_hat[i-1] * s0'
+        const Fr rowl = reg_load(spec, PSD_SROW + k * PSD_T + lc);
+        Fr b1;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) b1.l[i] = (l == 0) ? s.l[i] : rowl.l[i];
+        const Fr p1 = fp_mul<FrParams>(s, b1);                                  // lane 0: s^2; others: u_i
+        const Fr x4 = fp_sqr<FrParams>(p1);                                     // lane 0: s^4
+        const Fr sb = fr_add2r(fp_mul<FrParams>(x4, s), reg_load(spec, PSD_PARTIAL + k));   // lane 0: s^5 + c
+        const Fr s0 = psd_bcast0(sb);
+        const Fr coef = (l == 0) ? rowl : reg_load(spec, PSD_SCOL + k * (PSD_T - 1) + (lc ? lc - 1 : 0));
+        const Fr v = fp_mul<FrParams>(coef, s0);
+        // lane 0: row[0] * s0' + sum_{i >= 1} u_i ; lanes 1..8: v + s_i ; idle lanes stay zero
+        Fr t;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) t.l[i] = (l == 0) ? v.l[i] : (l < PSD_T ? p1.l[i] : 0u);
+        const Fr sum = psd_row_sum(t);
+        const Fr upd = fr_add2r(v, s);
+#pragma unroll
+        for (int i = 0; i < NL; ++i) s.l[i] = (l == 0) ? sum.l[i] : (l < PSD_T ? upd.l[i] : 0u);
     }
 #pragma unroll 1
     for (int k = 0; k < PSD_H - 1; ++k) {
