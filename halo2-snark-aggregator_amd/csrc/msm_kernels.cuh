@@ -123,11 +123,17 @@ __global__ void __launch_bounds__(BLOCK) k_msm_accumulate(const uint8_t* __restr
     const uint32_t* run = entries + offs[key];
     G1XYZZ acc = G1XYZZ::identity();
     if (hi > lo) {
+        // two-deep software pipeline: the base of entry k + 1 is gathered, and the INDEX of entry k + 2 loaded, under the
+        // addition of entry k — the index load used to sit in front of its gather with a full `s_waitcnt vmcnt(0)`
         G1Affine nxt = msm_gather(bases, endo_x, run[lo]);
+        uint32_t e_after = lo + 1 < hi ? run[lo + 1] : 0u;
 #pragma unroll 1
         for (uint32_t k = lo; k < hi; ++k) {
             G1Affine cur = nxt;
-            if (k + 1 < hi) nxt = msm_gather(bases, endo_x, run[k + 1]);  // next gather in flight under this add
+            if (k + 1 < hi) {
+                nxt = msm_gather(bases, endo_x, e_after);
+                e_after = k + 2 < hi ? run[k + 2] : 0u;
+            }
             xyzz_add_affine(acc, cur);
         }
     }
