@@ -287,13 +287,51 @@ FP_INLINE G1Affine affine_from_xyzz(const G1XYZZ& p) {
 }
 
 // MockEccChip::to_value = to_affine  (mock/arith/ecc.rs:64-66)
+// One inversion per point (safegcd, ~13 k instructions) is 3/4 of a point's work, so a lane shares one inversion among
+// TA_K of its points with Montgomery's trick (prefix products of the z's kept in registers, points re-read on the way
+// back: the kernel is far from bandwidth-bound): 2.8 ms -> see profiles/r02_final_batch_roofline.txt for 2^22 points.
+constexpr int TA_K = 8;
 __global__ void __launch_bounds__(BLOCK) k_g1_batch_to_affine(const uint8_t* __restrict__ in, size_t n,
                                                               uint8_t* __restrict__ out, uint32_t* flags) {
-    for (size_t i = (size_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * BLOCK) {
-        if (jac_noncanonical(in + 96 * i)) atomicOr(flags, FLAG_NONCANONICAL);
-        G1Affine a = affine_from_xyzz(xyzz_from_jac(jac_load_canonical(in + 96 * i)));
-        fp_store<FqParams>(out + 64 * i, fp_from_mont<FqParams>(a.x));
-        fp_store<FqParams>(out + 64 * i + 32, fp_from_mont<FqParams>(a.y));
+    const size_t stride = (size_t)gridDim.x * BLOCK;
+    for (size_t i0 = (size_t)blockIdx.x * BLOCK + threadIdx.x; i0 < n; i0 += stride * TA_K) {
+        // points i0, i0 + stride, ... (consecutive lanes touch consecutive points in every step)
+        Fq pre[TA_K];
+        Fq run = Fq::one();
+        uint32_t bad = 0;
+#pragma unroll
+        for (int j = 0; j < TA_K; ++j) {
+            const size_t i = i0 + (size_t)j * stride;
+            Fq z = Fq::one();
+            if (i < n) {
+                bad |= jac_noncanonical(in + 96 * i);
+                const Fq zc = fp_to_mont<FqParams>(fp_load<FqParams>(in + 96 * i + 64));
+                if (!fp_is_zero_mod<2, FqParams>(zc)) z = zc;               // identity: z = 0 stays out of the product
+            }
+            pre[j] = run;                                                   // product of the z's before point j
+            run = FQ_MUL(run, z);
+        }
+        if (bad) atomicOr(flags, FLAG_NONCANONICAL);
+        Fq inv = fp_inv<FqParams>(run);                                     // 1 / (z_0 ... z_{K-1})
+#pragma unroll
+        for (int j = TA_K - 1; j >= 0; --j) {
+            const size_t i = i0 + (size_t)j * stride;
+            if (i >= n) continue;
+            const Fq zc = fp_to_mont<FqParams>(fp_load<FqParams>(in + 96 * i + 64));
+            const bool ident = fp_is_zero_mod<2, FqParams>(zc);
+            Fq ox = Fq::zero(), oy = Fq::zero();
+            if (!ident) {
+                const Fq zi = FQ_MUL(inv, pre[j]);                           // 1 / z_j
+                inv = FQ_MUL(inv, zc);                                      // drop z_j from the running inverse
+                const Fq zi2 = FQ_SQR(zi);
+                const Fq x = fp_to_mont<FqParams>(fp_load<FqParams>(in + 96 * i));
+                const Fq y = fp_to_mont<FqParams>(fp_load<FqParams>(in + 96 * i + 32));
+                ox = fp_from_mont<FqParams>(FQ_MUL(x, zi2));               // x / z^2
+                oy = fp_from_mont<FqParams>(FQ_MUL(y, FQ_MUL(zi2, zi)));   // y / z^3
+            }
+            fp_store<FqParams>(out + 64 * i, ox);
+            fp_store<FqParams>(out + 64 * i + 32, oy);
+        }
     }
 }
 

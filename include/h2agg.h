@@ -58,7 +58,9 @@ void h2agg_destroy(h2agg_ctx* ctx);
 const char* h2agg_last_error(const h2agg_ctx* ctx);
 /* Use an existing HIP stream (hipStream_t) for every launch of this context; NULL = the context's own. */
 int h2agg_set_stream(h2agg_ctx* ctx, void* hip_stream);
-/* Block until everything queued on the context's stream has finished. */
+/* Block until everything queued on the context's stream (and its tail streams) has finished.  Also where device-side
+ * status raised by ASYNCHRONOUS calls surfaces: a non-canonical scalar handed to h2agg_g1_msm_device_async / _batch_async is
+ * reported here (or by the next synchronous entry point, whichever comes first) as H2AGG_ERR_NONCANONICAL, once. */
 int h2agg_synchronize(h2agg_ctx* ctx);
 /* Library / device description, e.g. "h2agg 0.1 gfx950 cu=256"; valid until the context is destroyed. */
 const char* h2agg_describe(h2agg_ctx* ctx);
@@ -348,7 +350,7 @@ int h2agg_fr_tape_eval(h2agg_ctx* ctx, const uint8_t* consts, size_t nconst, con
                        const uint32_t* out_regs, size_t nout, uint8_t* out);
 
 /* ---- tuning / measurement -------------------------------------------------------------------------
- * window_bits: Pippenger window c in [2, 16]; 0 = the measured table (GLV: 8 / 13 / 16 for n <= 2^10 / <= 2^14 / larger;
+ * window_bits: Pippenger window c in [2, 20]; 0 = the measured table (GLV: 8 / 13 / 16 for n <= 2^10 / <= 2^14 / larger;
  * plain: 8 / 15 / 16 for n <= 2^12 / < 2^19 / larger — wide windows with a uniform top window).
  * reduce_segment: buckets per running-sum segment of the bucket reduction (power of two; 0 = 2 / 4 / 8 by bucket count,
  * 32 for n >= 2^20 in overlap mode).  big_bucket_threshold: run length above which a bucket is cut into

@@ -37,7 +37,7 @@ def main(prefix):
     wave_adds = n * windows / 64.0
     print(json.dumps({
         "kernel": "k_msm_accumulate", "log2n": 20,
-        "workload": "2^20-point MSM, c=16, one launch (bench.py --steps 10 --warmup 2 --no-cpu-baseline --agg-proofs 0)",
+        "workload": "2^20-point MSM, c=16, one launch (bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pcie-leg --agg-proofs 0)",
         "csrc_sha": bench.csrc_sha(),
         "fetch_kb": fetch[0], "write_kb": write[0],
         "bytes_per_launch": int((fetch[0] + write[0]) * 1024),

@@ -8,7 +8,7 @@ root=$(pwd)
 out=$root/gpurun_out
 mkdir -p $out
 export TMPDIR=/tmp
-cmd="python $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --agg-proofs 0"
+cmd="python $root/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-pcie-leg --agg-proofs 0"
 cd /tmp
 rm -rf /tmp/prof_kt && rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o trace -- $cmd > $out/${tag}_bench_under_rocprof.json 2> /dev/null
 python $root/tools/rocpd_summary.py /tmp/prof_kt/trace_results.db > $out/${tag}_kernel_stats.txt 2>&1
