@@ -598,14 +598,20 @@ class SchemaBuilder:
         _need(s, 32, "scalar")
         return self._node(self._lib.h2agg_schema_node_scalar, s)
 
-    def evaluation_queries(self, keys: Sequence[str], commitments: bytes, evals: bytes, wrap: bool = True):
-        """n x EvaluationQuery::new in one call -> list of schema nodes ([C_i] + eval_i).
-        wrap=False returns the raw node-id array (accepted by batch_multi_open): a proof has hundreds of
-        queries and one Python object per query costs more than the device work."""
+    @staticmethod
+    def keys_array(keys: Sequence[str]):
+        """the query keys as a C string array, built once and reusable across calls (the reference formats its keys once per
+        proof too; re-encoding hundreds of Python strings per call costs more than the device work)"""
+        return (C.c_char_p * len(keys))(*[k.encode() for k in keys])
+
+    def evaluation_queries(self, keys, commitments: bytes, evals: bytes, wrap: bool = True):
+        """n x EvaluationQuery::new in one call -> list of schema nodes ([C_i] + eval_i).  `keys`: strings, or the array
+        from keys_array().  wrap=False returns the raw node-id array (accepted by batch_multi_open): a proof has hundreds
+        of queries and one Python object per query costs more than the device work."""
         n = len(keys)
         _need(commitments, 64 * n, "commitments")
         _need(evals, 32 * n, "evals")
-        arr = (C.c_char_p * n)(*[k.encode() for k in keys])
+        arr = keys if isinstance(keys, C.Array) else self.keys_array(keys)
         out = (C.c_uint32 * n)()
         self.eng._check(self._lib.h2agg_schema_evaluation_queries(self._s, n, arr, commitments, evals, out))
         if not wrap:
@@ -627,7 +633,7 @@ class SchemaBuilder:
         _need(u, 32, "u")
         if len(query_nodes) != nq:
             raise ValueError("one query node per rotation")
-        rot = (C.c_int32 * nq)(*rotations)
+        rot = rotations if isinstance(rotations, C.Array) else (C.c_int32 * nq)(*rotations)
         if isinstance(query_nodes, C.Array):
             qn = query_nodes
         else:

@@ -22,11 +22,12 @@ class ProofSpec:
     """byte-level proof data: keys[i], commitments (64 B each), evals (32 B each), rotations[i], points (32 B each),
     w (64 B each), v, u (32 B)"""
 
-    __slots__ = ("key", "keys", "commitments", "evals", "rotations", "points", "w", "v", "u")
+    __slots__ = ("key", "keys", "commitments", "evals", "rotations", "points", "w", "v", "u", "_c_keys", "_c_rot")
 
     def __init__(self, key, keys, commitments, evals, rotations, points, w, v, u):
         self.key, self.keys, self.commitments, self.evals = key, keys, commitments, evals
         self.rotations, self.points, self.w, self.v, self.u = rotations, points, w, v, u
+        self._c_keys = self._c_rot = None       # C arrays of the keys / rotations, made on first use (marshalling only)
 
     @property
     def nq(self) -> int:
@@ -74,8 +75,12 @@ def make_proofs(pool: Sequence[bytes], n_total: int, n_advice: int, seed: int = 
 
 def build_proof(builder, MultiOpenProof, spec: ProofSpec):
     """n x EvaluationQuery::new + batch_multi_open_proofs in the C++ host layer -> (MultiOpenProof, first query node)"""
-    qnodes = builder.evaluation_queries(spec.keys, spec.commitments, spec.evals, wrap=False)
-    w_x, w_g = builder.batch_multi_open(spec.key, spec.rotations, spec.points, qnodes, spec.w, spec.v, spec.u)
+    if spec._c_keys is None:
+        import ctypes as C
+        spec._c_keys = builder.keys_array(spec.keys)
+        spec._c_rot = (C.c_int32 * len(spec.rotations))(*spec.rotations)
+    qnodes = builder.evaluation_queries(spec._c_keys, spec.commitments, spec.evals, wrap=False)
+    w_x, w_g = builder.batch_multi_open(spec.key, spec._c_rot, spec.points, qnodes, spec.w, spec.v, spec.u)
     return MultiOpenProof(w_x, w_g), qnodes[0]
 
 
