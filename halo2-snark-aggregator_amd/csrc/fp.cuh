@@ -260,6 +260,155 @@ FP_INLINE Fp<P> fp_sqr_ps(const Fp<P>& a) {
     });
 }
 
+// ---- hand-scheduled multiply-add chains ------------------------------------------------------------------------
+// Written as C++ (`t += (uint64_t)a * b`), a column of the product comes out of LLVM as a fresh chain that starts from 0,
+// merged into the running carry by a 64-bit add (v_lshl_add_u64, half rate like the multiply-add itself): the reassociation
+// pass does that to every formulation, one or two partial sums alike — 16-17 merges per product, 7 % of a mixed addition.
+// The multiply-add instruction takes its 64-bit addend for free, so a column can start FROM the carry; that makes the whole
+// product one dependent chain, and the parallelism the merges bought has to come from somewhere else: two independent
+// products side by side (the group law offers them in pairs), written alternately.  An empty asm on the running sum after every
+// multiply-add keeps LLVM from reassociating (a real `v_mad_u64_u32` asm works too, but the hazard recogniser then puts an
+// s_nop behind every one of them).
+FP_INLINE void mad_vv(uint64_t& t, uint32_t a, uint32_t b) {
+    t += (uint64_t)a * b;
+    asm("" : "+v"(t));   // no instruction: keeps this multiply-add's sum out of the reassociation of the column
+}
+FP_INLINE void mad_vs(uint64_t& t, uint32_t a, uint32_t k) {   // k: wave-uniform (a modulus limb)
+    t += (uint64_t)a * k;
+    asm("" : "+v"(t));
+}
+FP_INLINE uint64_t mul_vv(uint32_t a, uint32_t b) {
+    uint64_t t = (uint64_t)a * b;
+    asm("" : "+v"(t));
+    return t;
+}
+// Two Montgomery products in lock step.  term(k, i, x0, y0, x1, y1) yields the i-th product term of column k of both
+// products (or returns false when column k has no i-th term).
+template <class P, class TermF>
+FP_INLINE void fp_mont_chain2(TermF&& term, Fp<P>& r0, Fp<P>& r1) {
+    uint32_t m0[NL], m1[NL];
+    uint64_t t0 = 0, t1 = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * NL - 1; ++k) {
+        bool first = (k == 0);
+#pragma unroll
+        for (int i = 0; i < 2 * NL; ++i) {
+            uint32_t x0, y0, x1, y1;
+            if (term(k, i, x0, y0, x1, y1)) {
+                if (first) {
+                    t0 = mul_vv(x0, y0);
+                    t1 = mul_vv(x1, y1);
+                    first = false;
+                } else {
+                    mad_vv(t0, x0, y0);
+                    mad_vv(t1, x1, y1);
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int j = k - i;
+            if (i < k && j >= 0 && j < NL) {   // m_i * p_(k-i), i < k
+                mad_vs(t0, m0[i], P::MOD[j]);
+                mad_vs(t1, m1[i], P::MOD[j]);
+            }
+        }
+        if (k < NL) {
+            m0[k] = ((uint32_t)t0 * P::NINV) & M29;
+            m1[k] = ((uint32_t)t1 * P::NINV) & M29;
+            mad_vs(t0, m0[k], P::MOD[0]);
+            mad_vs(t1, m1[k], P::MOD[0]);
+        } else {
+            r0.l[k - NL] = (uint32_t)t0 & M29;
+            r1.l[k - NL] = (uint32_t)t1 & M29;
+        }
+        t0 >>= 29;
+        t1 >>= 29;
+    }
+    r0.l[NL - 1] = (uint32_t)t0;
+    r1.l[NL - 1] = (uint32_t)t1;
+}
+// (r0, r1) = (a*b, c*d)
+template <class P>
+FP_INLINE void fp_mul_dual(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>& d, Fp<P>& r0, Fp<P>& r1) {
+    fp_mont_chain2<P>([&](int k, int i, uint32_t& x0, uint32_t& y0, uint32_t& x1, uint32_t& y1) {
+        const int j = k - i;
+        if (i >= NL || j < 0 || j >= NL) return false;
+        x0 = a.l[i]; y0 = b.l[j]; x1 = c.l[i]; y1 = d.l[j];
+        return true;
+    }, r0, r1);
+}
+// (r0, r1) = (a^2, c^2): cross terms once with a doubled operand
+template <class P>
+FP_INLINE void fp_sqr_dual(const Fp<P>& a, const Fp<P>& c, Fp<P>& r0, Fp<P>& r1) {
+    uint32_t a2[NL], c2[NL];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        a2[i] = a.l[i] << 1;
+        c2[i] = c.l[i] << 1;
+    }
+    fp_mont_chain2<P>([&](int k, int i, uint32_t& x0, uint32_t& y0, uint32_t& x1, uint32_t& y1) {
+        const int j = k - i;
+        if (i >= NL || j < i || j >= NL) return false;
+        if (j == i) { x0 = a.l[i]; y0 = a.l[i]; x1 = c.l[i]; y1 = c.l[i]; }
+        else { x0 = a2[i]; y0 = a.l[j]; x1 = c2[i]; y1 = c.l[j]; }
+        return true;
+    }, r0, r1);
+}
+// (r0, r1, r2) = (a*b + c*d, e*f, g*h): a two-product sum (one reduction) beside two plain products, three chains
+template <class P>
+FP_INLINE void fp_mul2_mul_mul(const Fp<P>& a, const Fp<P>& b, const Fp<P>& c, const Fp<P>& d, const Fp<P>& e,
+                               const Fp<P>& f, const Fp<P>& g, const Fp<P>& h, Fp<P>& r0, Fp<P>& r1, Fp<P>& r2) {
+    uint32_t m0[NL], m1[NL], m2[NL];
+    uint64_t t0 = 0, t1 = 0, t2 = 0;
+#pragma unroll
+    for (int k = 0; k < 2 * NL - 1; ++k) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int j = k - i;
+            if (j >= 0 && j < NL) {
+                if (k == 0) {
+                    t0 = mul_vv(a.l[i], b.l[j]);
+                    t1 = mul_vv(e.l[i], f.l[j]);
+                    t2 = mul_vv(g.l[i], h.l[j]);
+                } else {
+                    mad_vv(t0, a.l[i], b.l[j]);
+                    mad_vv(t1, e.l[i], f.l[j]);
+                    mad_vv(t2, g.l[i], h.l[j]);
+                }
+                mad_vv(t0, c.l[i], d.l[j]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            const int j = k - i;
+            if (i < k && j >= 0 && j < NL) {
+                mad_vs(t0, m0[i], P::MOD[j]);
+                mad_vs(t1, m1[i], P::MOD[j]);
+                mad_vs(t2, m2[i], P::MOD[j]);
+            }
+        }
+        if (k < NL) {
+            m0[k] = ((uint32_t)t0 * P::NINV) & M29;
+            m1[k] = ((uint32_t)t1 * P::NINV) & M29;
+            m2[k] = ((uint32_t)t2 * P::NINV) & M29;
+            mad_vs(t0, m0[k], P::MOD[0]);
+            mad_vs(t1, m1[k], P::MOD[0]);
+            mad_vs(t2, m2[k], P::MOD[0]);
+        } else {
+            r0.l[k - NL] = (uint32_t)t0 & M29;
+            r1.l[k - NL] = (uint32_t)t1 & M29;
+            r2.l[k - NL] = (uint32_t)t2 & M29;
+        }
+        t0 >>= 29;
+        t1 >>= 29;
+        t2 >>= 29;
+    }
+    r0.l[NL - 1] = (uint32_t)t0;
+    r1.l[NL - 1] = (uint32_t)t1;
+    r2.l[NL - 1] = (uint32_t)t2;
+}
+
 // a*b / 2^261 mod m.  Inputs: tight limbs, bounds A, B with A*B <= ~1000.  Output bound: A*B/169 + 1.
 template <class P>
 FP_INLINE Fp<P> fp_mul_os(const Fp<P>& a, const Fp<P>& b) {

@@ -109,8 +109,13 @@ FP_INLINE void xyzz_add_affine(G1XYZZ& acc, const G1Affine& q) {
         acc.zzz = Fq::one();
         return;
     }
+#ifndef H2AGG_SINGLE_MUL   // (A/B switch: -DH2AGG_SINGLE_MUL restores one product at a time)
+    Fq u2, s2;
+    fp_mul_dual<FqParams>(q.x, acc.zz, q.y, acc.zzz, u2, s2);   // 2*2 -> [2], [2]
+#else
     Fq u2 = FQ_MUL(q.x, acc.zz);                        // 2*2 -> [2]
     Fq s2 = FQ_MUL(q.y, acc.zzz);                       // [2]
+#endif
     Fq p = FQ_SUB(8, u2, acc.x);                        // [10]
     Fq r = FQ_SUB(4, s2, acc.y);                        // [6]
     if (fp_maybe_zero_mod<10, FqParams>(p)) {           // exact "no"; the rare "maybe" is decided exactly
@@ -128,6 +133,20 @@ FP_INLINE void xyzz_add_affine(G1XYZZ& acc, const G1Affine& q) {
     // zero high word, a v_mul_lo / v_add3 and register shuffles per product): -7 % instructions in the mixed addition.
     fq_fence(p);
     fq_fence(r);
+#ifndef H2AGG_SINGLE_MUL
+    // independent products side by side, one multiply-add chain each (fp_mont_chain2): (PP, RR), (PPP, Q), (Y3, ZZ3, ZZZ3)
+    Fq pp, rr, ppp, qq;
+    fp_sqr_dual<FqParams>(p, r, pp, rr);                // 100 -> [2], 36 -> [2]
+    fp_mul_dual<FqParams>(p, pp, acc.x, pp, ppp, qq);   // 20 -> [2], 16 -> [2]
+    Fq x3 = fp_sub_sub2<6, FqParams>(rr, ppp, qq);      // PPP + 2Q [6] -> [8]
+    // R*(Q - X3) - Y1*PPP as ONE reduction: R*(Q - X3 + 8p) + (4p - Y1)*PPP: (6*10 + 4*2)/169 + 1 -> [2]
+    Fq y3, zz3, zzz3;
+    fp_mul2_mul_mul<FqParams>(r, FQ_SUB(8, qq, x3), fp_neg<4, FqParams>(acc.y), ppp, acc.zz, pp, acc.zzz, ppp, y3, zz3, zzz3);
+    acc.x = x3;
+    acc.y = y3;
+    acc.zz = zz3;
+    acc.zzz = zzz3;
+#else
     Fq pp = FQ_SQR(p);                                  // 100 -> [2]
     Fq ppp = FQ_MUL(p, pp);                             // 20  -> [2]
     Fq qq = FQ_MUL(acc.x, pp);                          // 16  -> [2]
@@ -138,6 +157,7 @@ FP_INLINE void xyzz_add_affine(G1XYZZ& acc, const G1Affine& q) {
     acc.y = y3;
     acc.zz = FQ_MUL(acc.zz, pp);                        // [2]
     acc.zzz = FQ_MUL(acc.zzz, ppp);                     // [2]
+#endif
 }
 
 // a + b, add-2008-s, complete.
