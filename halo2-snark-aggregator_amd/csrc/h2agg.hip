@@ -25,6 +25,12 @@ using namespace h2agg;
 
 namespace {
 
+// Events that only order streams of this device / time kernels on it: device-scope release.  (The default is a system-scope
+// release — an L2 write-back at every record.)  H2AGG_EVENT_SCOPE=system restores the default for A/B runs.
+static const bool ev_scope_system = getenv("H2AGG_EVENT_SCOPE") && !strcmp(getenv("H2AGG_EVENT_SCOPE"), "system");
+#define EV_SYNC_FLAGS (ev_scope_system ? hipEventDisableTiming : (hipEventDisableTiming | hipEventReleaseToDevice))
+#define EV_TIME_FLAGS (ev_scope_system ? hipEventDefault : hipEventReleaseToDevice)
+
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -103,7 +109,7 @@ struct h2agg_ctx {
     int cfg_c = 0, cfg_seg = 0, cfg_big = 0, cfg_sub_bits = 0, cfg_tile = 0;
     int cfg_glv = 0;   // 0 = auto, 1 = on, -1 = off
     int cfg_lpb = 0;   // lanes per bucket in the accumulate kernel: 0 = auto, 1 / 2 / 4 / 8 / 16
-    bool cfg_no_stage = false, cfg_stage_l1 = false, staged_attr_set = false;
+    bool cfg_no_stage = false, cfg_stage_l1 = false, staged_attr_set = false, cfg_no_dm = false, dm_attr_set = false, r2d_attr_set = false;
 
     // optional overlap of the serial tail (k_msm_final) of MSM k with the bulk of MSM k+1
     bool tail_overlap = false;
@@ -114,6 +120,7 @@ struct h2agg_ctx {
     static constexpr int TAIL_SLOTS = 3;
     // what a tail reads: one independent allocation per slot, so MSMs with DIFFERENT plans (bucket counts, segment
     // counts, window counts) in flight on different slots can never alias one another, whatever their sizes
+    DevBuf r2d_ticket[TAIL_SLOTS];
     DevBuf buckets[TAIL_SLOTS], segsum[TAIL_SLOTS], wsum[TAIL_SLOTS];
     hipStream_t tail_streams[TAIL_SLOTS] = {};
     hipEvent_t ev_bulk[TAIL_SLOTS] = {}, ev_tail[TAIL_SLOTS] = {};
@@ -380,22 +387,43 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     const bool par4 = par4_env ? par4_env > 0 : nseg_total <= 16384;
     // pmeta words: pcount [PW] | pstart [PW + 1] | pcursor [PW] | bin_count [SIZE_BINS] | bin_start [SIZE_BINS + 1] |
     //              bin_cursor [SIZE_BINS] | big-bucket counters [2], each padded by 64 words
-    constexpr uint32_t M_PSTART = SORT_MAX_PW + 64, M_PCURSOR = M_PSTART + SORT_MAX_PW + 64,
-                       M_BCOUNT = M_PCURSOR + SORT_MAX_PW + 64, M_BSTART = M_BCOUNT + SIZE_BINS + 64,
+    constexpr uint32_t META_PW = DM_MAX_PW;   // (the digit-major path has up to 16 x 512 partitions)
+    constexpr uint32_t M_PSTART = META_PW + 64, M_PCURSOR = M_PSTART + META_PW + 64,
+                       M_BCOUNT = M_PCURSOR + META_PW + 64, M_BSTART = M_BCOUNT + SIZE_BINS + 64,
                        M_BCURSOR = M_BSTART + SIZE_BINS + 64, M_BIG = M_BCURSOR + SIZE_BINS + 64, M_WORDS = M_BIG + 64;
     TRY(ensure(c, c->pmeta, M_WORDS * 4));
     TRY(ensure(c, c->hist, (size_t)p.NBT * 4));
     TRY(ensure(c, c->offs, (size_t)p.NBT * 4));
     TRY(ensure(c, c->order, (size_t)p.NBT * 4));
-    TRY(ensure(c, c->item_idx, nent * 4));
-    TRY(ensure(c, c->item_sub, nent * 2));
+    // digit-major sort (sort_kernels.cuh): plain 16-bit windows over one table, 2^16 .. 2^22 points
+    static const bool dm_env_off = getenv("H2AGG_SORT") && !strcmp(getenv("H2AGG_SORT"), "packed");
+    const bool dm = !dm_env_off && !c->cfg_no_dm && !c->cfg_no_stage && !c->cfg_stage_l1 && !c->cfg_sub_bits && !c->cfg_tile && !p.glv && !pre && batch == 1 &&
+                    p.c == 16 && n >= ((size_t)1 << 16) && n <= ((size_t)1 << 22);
+    DmPlan dp{};
+    if (dm) {
+        dp.n = (uint32_t)n;
+        dp.n_pad = (uint32_t)((n + 7) & ~(size_t)7);
+        dp.ntile = (uint32_t)((n + DM_T1 - 1) / DM_T1);
+        dp.n_row = dp.ntile * (uint32_t)DM_T1;
+        dp.ppw = 64;
+        while (n / dp.ppw > 4096 && dp.ppw < (uint32_t)DM_MAX_PPW) dp.ppw *= 2;   // ~4 K keys per level-2 partition (8 K at 2^22)
+        dp.sub_bits = 15;
+        for (uint32_t q = dp.ppw; q > 1; q >>= 1) --dp.sub_bits;
+        dp.SB = 1u << dp.sub_bits;
+        dp.idx_bits = 31 - dp.sub_bits;
+    }
+    TRY(ensure(c, c->item_idx, dm ? (size_t)16 * dp.n_row * 4 : nent * 4));
+    TRY(ensure(c, c->item_sub, dm ? (size_t)16 * dp.n_pad * 2 : nent * 2));
     TRY(ensure(c, c->entries, nent * 4));
     // buckets / segsum / wsum exist once per tail slot: in overlap mode the reduction of MSM k (tail stream)
     // runs while MSM k+1 fills the next slot's set.  (They were one allocation cut at par * this-plan's-size: two MSMs
     // with different plans in flight then overlapped — ADVICE r1.)
     const int par = c->parity;
     TRY(ensure(c, c->buckets[par], (size_t)p.NBT * XYZZ_BYTES));
-    TRY(ensure(c, c->segsum[par], (size_t)nseg_total * XYZZ_BYTES));
+    {   // (the two-dimensional reduction keeps 4096 partial sums per window there)
+        const size_t r2d_records = p.NB == (uint32_t)(R2D_ROWS * R2D_COLS) ? (size_t)WT * (R2D_THREADS + 2) : 0;
+        TRY(ensure(c, c->segsum[par], (nseg_total > r2d_records ? nseg_total : r2d_records) * XYZZ_BYTES));
+    }
     TRY(ensure(c, c->wsum[par], (size_t)WT * XYZZ_BYTES));
     const size_t max_slots = nent / BIG_CHUNK + nent / ((size_t)p.big + 1) + 2;   // chunks of over-long buckets
     const size_t max_keys = nent / ((size_t)p.big + 1) + 2;
@@ -423,7 +451,10 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     const unsigned ntiles = (unsigned)((n + sp.tile - 1) / sp.tile);
     // per-tile partition counts from the counting pass, read back by the packed scatter pass (same tiles)
     uint32_t* tile_counts = nullptr;
-    if (staged && !c->cfg_stage_l1) {
+    if (dm) {
+        TRY(ensure(c, c->tile_counts, (size_t)16 * dp.ntile * (dp.ppw + 1) * 4));
+        tile_counts = (uint32_t*)c->tile_counts.p;
+    } else if (staged && !c->cfg_stage_l1) {
         TRY(ensure(c, c->tile_counts, (size_t)ntiles * sp.PW * 4));
         tile_counts = (uint32_t*)c->tile_counts.p;
     }
@@ -442,6 +473,30 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
                            (uint8_t*)c->glv_buf.p, c->d_flags);
         d_scalars = (const uint8_t*)c->glv_buf.p;
     }
+    if (dm) {
+        const uint32_t PW = 16u * dp.ppw;
+        {
+            StageTimer t(c, ST_PART_COUNT);
+            HIP_TRY(c, hipMemsetAsync(meta, 0, M_WORDS * 4, st));
+            hipLaunchKernelGGL(k_dm_digits, dim3((unsigned)((n + BLOCK * DM_DIG_PER - 1) / (BLOCK * DM_DIG_PER))), dim3(BLOCK), 0, st, d_scalars, dp.n,
+                               dp.n_pad, item_sub, c->d_flags);
+        }
+        {
+            StageTimer t(c, ST_PART_SCATTER);
+            hipLaunchKernelGGL(k_dm_partition, dim3(dp.ntile, 16), dim3(DM_TB1), 0, st, (const uint16_t*)item_sub, dp, pcount,
+                               tile_counts, item_idx);
+                hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)pcount, PW, pstart);
+            }
+        {
+            StageTimer t(c, ST_BUCKET_SORT);
+            if (n / dp.ppw <= 4096)
+                hipLaunchKernelGGL(k_dm_bucket_sort<16>, dim3(PW), dim3(DM_TB2), 0, st, (const uint32_t*)pstart,
+                                   (const uint32_t*)tile_counts, (const uint32_t*)item_idx, dp, p.NB, hist, offs, entries);
+            else
+                hipLaunchKernelGGL(k_dm_bucket_sort<32>, dim3(PW), dim3(DM_TB2), 0, st, (const uint32_t*)pstart,
+                                   (const uint32_t*)tile_counts, (const uint32_t*)item_idx, dp, p.NB, hist, offs, entries);
+        }
+    } else {
     {
         StageTimer t(c, ST_PART_COUNT);
         HIP_TRY(c, hipMemsetAsync(meta, 0, M_WORDS * 4, st));
@@ -486,6 +541,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
             hipLaunchKernelGGL(k_bucket_sort, dim3(sp.PW), dim3(BLOCK), 0, st, pstart, item_idx, item_sub, sp, p.NB,
                                hist, offs, entries);
         }
+    }
     }
     // ordering the buckets by length balances the lanes of a wave; with few entries the longest run bounds the kernel
     // either way and the three launches (~25 us) are pure latency
@@ -548,7 +604,28 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         HIP_TRY(c, hipStreamWaitEvent(c->tail_streams[par], c->ev_bulk[par], 0));
         ts = c->tail_streams[par];
     }
-    {
+    static const int dbg_skip = getenv("H2AGG_DBG_SKIP") ? atoi(getenv("H2AGG_DBG_SKIP")) : 0;   // measurement only: 1 reduce, 2 + window sums, 4 + final
+    // two-dimensional bucket reduction for 16-bit windows (msm_kernels.cuh); H2AGG_REDUCE=segments keeps the segment kernels
+    static const bool r2d_env_off = getenv("H2AGG_REDUCE") && !strcmp(getenv("H2AGG_REDUCE"), "segments");
+    const bool r2d = !r2d_env_off && !c->cfg_seg && !pre && p.NB == (uint32_t)(R2D_ROWS * R2D_COLS);
+    if (r2d) {
+        DevBuf& tk = c->r2d_ticket[par];   // arrival counters of the two half-window workgroups: zero between MSMs
+        if ((size_t)WT * 4 > tk.cap) {
+            TRY(ensure(c, tk, (size_t)WT * 4));
+            HIP_TRY(c, hipMemset(tk.p, 0, tk.cap));
+        }
+        if (!(dbg_skip & 1)) {
+            StageTimer t(c, ST_REDUCE, ts);
+            const uint32_t total = WT * (uint32_t)R2D_THREADS;
+            hipLaunchKernelGGL(k_msm_reduce2d_parts, dim3(total / 64), dim3(64), 0, ts, (const uint8_t*)buckets, total, segsum);
+        }
+        if (!(dbg_skip & 2)) {
+            StageTimer t(c, ST_WINDOW_SUM, ts);
+            hipLaunchKernelGGL(k_msm_reduce2d_window, dim3(WT, 2), dim3(R2D_TB), 0, ts, (const uint8_t*)segsum,
+                               segsum + XYZZ_BYTES * (size_t)WT * R2D_THREADS, (uint32_t*)tk.p, wsum);
+        }
+    } else {
+    if (!(dbg_skip & 1)) {
         StageTimer t(c, ST_REDUCE, ts);
         if (par4)
             hipLaunchKernelGGL(k_msm_reduce_segments_par4, dim3((4 * nseg_total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ts,
@@ -557,19 +634,20 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
             hipLaunchKernelGGL(k_msm_reduce_segments, dim3((nseg_total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ts, buckets,
                                p.NB, p.seg, p.spw, nseg_total, segsum);
     }
-    {
+    if (!(dbg_skip & 2)) {
         StageTimer t(c, ST_WINDOW_SUM, ts);
         if (par4)
             hipLaunchKernelGGL(k_msm_window_sum_par4, dim3(WT), dim3(PAR4_THREADS), 0, ts, segsum, p.spw, wsum);
         else
             hipLaunchKernelGGL(k_msm_window_sum, dim3(WT), dim3(BLOCK), 0, ts, segsum, p.spw, wsum);
     }
+    }
     if (c->tail_overlap && c->overlap_level < 2) {
         HIP_TRY(c, hipEventRecord(c->ev_bulk[par], st));
         HIP_TRY(c, hipStreamWaitEvent(c->tail_streams[par], c->ev_bulk[par], 0));
         ts = c->tail_streams[par];
     }
-    {
+    if (!(dbg_skip & 4)) {
         StageTimer t(c, ST_FINAL, ts);
         hipLaunchKernelGGL(k_msm_final, dim3(batch), dim3(64), 0, ts, wsum, p.c, W1, batch > 1 ? (uint8_t*)nullptr : c->d_res_xyzz,
                            d_out_jac);
@@ -636,12 +714,17 @@ int h2agg_create(int device_ordinal, h2agg_ctx** out) try {
     }
     c->stream = c->own_stream;
     for (int k = 0; k < h2agg_ctx::TAIL_SLOTS; ++k) {
-        if (hipStreamCreateWithFlags(&c->tail_streams[k], hipStreamNonBlocking) != hipSuccess) {
+        // H2AGG_TAIL_PRIO (experiment): -1 = lowest, 1 = highest stream priority for the tail streams
+        static const int tail_prio = getenv("H2AGG_TAIL_PRIO") ? atoi(getenv("H2AGG_TAIL_PRIO")) : 0;
+        int pr_lo = 0, pr_hi = 0;
+        hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);   // lo = least (numerically greatest)
+        if ((tail_prio ? hipStreamCreateWithPriority(&c->tail_streams[k], hipStreamNonBlocking, tail_prio < 0 ? pr_lo : pr_hi)
+                       : hipStreamCreateWithFlags(&c->tail_streams[k], hipStreamNonBlocking)) != hipSuccess) {
             h2agg_destroy(c);
             return H2AGG_ERR_HIP;
         }
-        hipEventCreateWithFlags(&c->ev_bulk[k], hipEventDisableTiming);
-        hipEventCreateWithFlags(&c->ev_tail[k], hipEventDisableTiming);
+        hipEventCreateWithFlags(&c->ev_bulk[k], EV_SYNC_FLAGS);
+        hipEventCreateWithFlags(&c->ev_tail[k], EV_SYNC_FLAGS);
     }
     c->d_flags = (uint32_t*)c->small.p;
     c->d_res_xyzz = (uint8_t*)c->small.p + 1024;   // 144 B
@@ -670,7 +753,7 @@ void h2agg_destroy(h2agg_ctx* c) {
     static_assert(h2agg_ctx::TAIL_SLOTS == 3, "the list below names every tail slot's buffers");
     DevBuf* bufs[] = {&c->in_a,  &c->in_b,     &c->in_c,     &c->out,   &c->tmp_bases, &c->comb, &c->psd_spec, &c->tr_in, &c->tr_points, &c->tr_elems, &c->tr_chal, &c->inst_vals, &c->inst_jac, &c->inst_aff, &c->agg_elems, &c->hist,
                       &c->offs,  &c->pmeta,    &c->item_idx, &c->item_sub, &c->order,  &c->entries,
-                      &c->buckets[0], &c->buckets[1], &c->buckets[2], &c->segsum[0], &c->segsum[1], &c->segsum[2],
+                      &c->r2d_ticket[0], &c->r2d_ticket[1], &c->r2d_ticket[2], &c->buckets[0], &c->buckets[1], &c->buckets[2], &c->segsum[0], &c->segsum[1], &c->segsum[2],
                       &c->wsum[0], &c->wsum[1], &c->wsum[2], &c->big_list, &c->big_keys, &c->big_part, &c->glv_buf, &c->parts, &c->small, &c->endo_buf, &c->tile_counts,
                       &c->sch_regs, &c->sch_in, &c->sch_scalars[0], &c->sch_scalars[1], &c->sch_bases[0], &c->sch_bases[1]};
     for (DevBuf* b : bufs)
@@ -1432,10 +1515,11 @@ int h2agg_msm_configure_sort(h2agg_ctx* c, int sub_bits, int tile) try {
     if (!c) return H2AGG_ERR_INVALID;
     if (sub_bits != 0 && (sub_bits < 4 || sub_bits > SORT_MAX_SUB_BITS))
         return fail(c, H2AGG_ERR_INVALID, "sub_bits must be 0 or in [4, 12]");
-    if (tile != 0 && tile != -1 && tile != -2 && (tile < BLOCK || tile > (1 << 16)))
+    if (tile != 0 && tile != -1 && tile != -2 && tile != -3 && (tile < BLOCK || tile > (1 << 16)))
         return fail(c, H2AGG_ERR_INVALID, "tile must be 0, -1, -2 or in [256, 65536]");
     c->cfg_sub_bits = sub_bits;
     c->cfg_no_stage = tile == -1;   // -1: force the direct two-array sort kernels
+    c->cfg_no_dm = tile == -3;      // -3: packed two-level sort even where the digit-major one applies
     c->cfg_stage_l1 = tile == -2;   // -2: also stage level 1 through LDS (experiment: slower, kept for tests)
     c->cfg_tile = tile > 0 ? tile : 0;
     return H2AGG_OK;
@@ -1463,7 +1547,7 @@ int h2agg_profile_enable(h2agg_ctx* c, int enable) try {
     if (enable && !c->prof_events_created) {
         for (int r = 0; r < h2agg_ctx::PROF_RING; ++r)
             for (int s = 0; s < ST_N; ++s)
-                for (int k = 0; k < 2; ++k) HIP_TRY(c, hipEventCreate(&c->prof[r].ev[s][k]));
+                for (int k = 0; k < 2; ++k) HIP_TRY(c, hipEventCreateWithFlags(&c->prof[r].ev[s][k], EV_TIME_FLAGS));
         c->prof_events_created = true;
     }
     if (!enable) profile_harvest_all(c);

@@ -246,6 +246,205 @@ __global__ void __launch_bounds__(BLOCK) k_msm_window_sum(const uint8_t* __restr
     if (threadIdx.x == 0) xyzz_store(wsum + XYZZ_BYTES * (size_t)w, tot);
 }
 
+// ---- two-dimensional bucket reduction (16-bit windows: 2^15 buckets = 256 rows x 128 columns) -----------------------
+// With the tails under the next MSM's bulk the whole step is VALU-issue-bound, and the segment kernels above are 124 M
+// wave-instructions per 2^20-point MSM against 548 M for the bucket accumulation (skipping them: 1.44 -> 1.20 ms per step).
+// They pay for short chains: 4 lanes per chain at 16 lane-products per 14-product addition, plus a double-and-add by the
+// segment offset per segment.  Writing the bucket index as b = 128 h + l,
+//     sum_b (b + 1) B_b  =  128 * sum_h h R_h  +  sum_l (l + 1) C_l,      R_h = sum_l B[h][l],   C_l = sum_h B[h][l],
+// turns the bulk of the work into PLAIN sums — two additions per bucket as before, but independent ones: one lane each,
+// every lane busy, chains of 16 — and leaves two weighted sums over 256 and 128 points per window for one workgroup.
+constexpr int R2D_LCOLS = 7, R2D_COLS = 1 << R2D_LCOLS, R2D_ROWS = 256, R2D_L = 16;
+constexpr int R2D_RPARTS = R2D_COLS / R2D_L, R2D_CPARTS = R2D_ROWS / R2D_L;              // 8 row parts, 16 column parts
+constexpr int R2D_ROW_THREADS = R2D_ROWS * R2D_RPARTS, R2D_THREADS = 2 * R2D_ROW_THREADS;   // 2048 + 2048 per window
+static_assert(R2D_ROWS * R2D_RPARTS == R2D_COLS * R2D_CPARTS, "row and column parts are laid out back to back");
+
+// 64 XYZZ records, one per lane, fetched by the wave as ONE 9216-byte block: slot g = 64 q + lane of the block is piece
+// g % 9 of lane g / 9's record, so consecutive lanes ask for consecutive 16-byte pieces (whole lines, each fetched once —
+// a lane reading its own record piece by piece touches 64 different lines per instruction and uses a quarter of each),
+// and CDNA4's LDS-DMA load (global_load_lds_dwordx4) drops them straight into LDS: no staging registers, the block for the
+// next addition is in flight while this one is computed.
+FP_INLINE void r2d_fetch(const uint8_t* __restrict__ B, const uint32_t (&off)[9], uint32_t step_bytes, uint32_t* lds_block) {
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(B + off[q] + step_bytes),
+                                         (__attribute__((address_space(3))) void*)(lds_block + 256 * q), 16, 0, 0);
+}
+FP_INLINE G1XYZZ r2d_own(const uint32_t* lds_block, int lane) {
+    const uint4* q = reinterpret_cast<const uint4*>(lds_block) + 9 * lane;
+    uint32_t w[36];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) {
+        const uint4 v = q[i];
+        w[4 * i] = v.x;
+        w[4 * i + 1] = v.y;
+        w[4 * i + 2] = v.z;
+        w[4 * i + 3] = v.w;
+    }
+    G1XYZZ r;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        r.x.l[i] = w[i];
+        r.y.l[i] = w[9 + i];
+        r.zz.l[i] = w[18 + i];
+        r.zzz.l[i] = w[27 + i];
+    }
+    return r;
+}
+
+// parts[w * 4096 + t]: t < 2048: row h = t >> 3, part j = t & 7: sum of B[h][j + 8 i], i < 16
+//                      t >= 2048: u = t - 2048, part j = u >> 7, column l = u & 127: sum of B[j + 16 i][l], i < 16
+// One-wave workgroups; a wave is all row parts or all column parts, so the step between a lane's records is wave-uniform.
+__global__ void __launch_bounds__(64) k_msm_reduce2d_parts(const uint8_t* __restrict__ buckets, uint32_t total,
+                                                           uint8_t* __restrict__ parts) {
+    __shared__ __attribute__((aligned(16))) uint32_t blk[2][9 * 256];
+    const int lane = threadIdx.x;
+    const uint32_t g = blockIdx.x * 64 + lane;
+    const uint32_t w = g / R2D_THREADS, t = g - w * R2D_THREADS;
+    uint32_t base, stride;
+    if (t < (uint32_t)R2D_ROW_THREADS) {
+        base = (t >> 3) * R2D_COLS + (t & 7);
+        stride = R2D_RPARTS;
+    } else {
+        const uint32_t u = t - R2D_ROW_THREADS;
+        base = (u >> R2D_LCOLS) * R2D_COLS + (u & (R2D_COLS - 1));
+        stride = R2D_CPARTS * R2D_COLS;
+    }
+    const uint8_t* B = buckets + XYZZ_BYTES * (size_t)w * (R2D_ROWS * R2D_COLS);
+    uint32_t off[9];   // byte offset (from B) of the piece this lane fetches in round q
+#pragma unroll
+    for (int q = 0; q < 9; ++q) {
+        const uint32_t slot = 64 * q + lane, r = slot / 9, piece = slot - 9 * r;
+        off[q] = (uint32_t)XYZZ_BYTES * (uint32_t)__shfl((int)base, (int)r, 64) + 16 * piece;
+    }
+    const uint32_t step = (uint32_t)XYZZ_BYTES * stride;
+    r2d_fetch(B, off, 0, blk[0]);
+    __syncthreads();
+    G1XYZZ acc = r2d_own(blk[0], lane);
+    r2d_fetch(B, off, step, blk[1]);
+#pragma unroll 1
+    for (int i = 1; i < R2D_L; ++i) {
+        __syncthreads();
+        const G1XYZZ cur = r2d_own(blk[i & 1], lane);
+        __syncthreads();
+        if (i + 1 < R2D_L) r2d_fetch(B, off, step * (i + 1), blk[(i + 1) & 1]);
+        acc = xyzz_add(acc, cur);
+    }
+    if (g < total) xyzz_store(parts + XYZZ_BYTES * (size_t)g, acc);
+}
+
+constexpr int R2D_TB = 256;   // one wave per SIMD: every level of the scans below costs one addition's latency
+FP_INLINE void r2d_put(uint32_t* lds, int slot, const G1XYZZ& p) {
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        lds[i * R2D_TB + slot] = p.x.l[i];
+        lds[(NL + i) * R2D_TB + slot] = p.y.l[i];
+        lds[(2 * NL + i) * R2D_TB + slot] = p.zz.l[i];
+        lds[(3 * NL + i) * R2D_TB + slot] = p.zzz.l[i];
+    }
+}
+FP_INLINE G1XYZZ r2d_get(const uint32_t* lds, int slot) {
+    G1XYZZ p;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        p.x.l[i] = lds[i * R2D_TB + slot];
+        p.y.l[i] = lds[(NL + i) * R2D_TB + slot];
+        p.zz.l[i] = lds[(2 * NL + i) * R2D_TB + slot];
+        p.zzz.l[i] = lds[(3 * NL + i) * R2D_TB + slot];
+    }
+    return p;
+}
+
+// Grid (windows, 2).  Workgroup (w, 0): 128 * sum_h h R_h over the 256 rows; (w, 1): sum_l (l + 1) C_l over the 128 columns
+// (two threads per column).  sum_k k X_k over a ramp = sum of the suffix sums S_k = sum_{i >= k} X_i, k >= 1 (columns:
+// weights l + 1, so S_0 counts too): a Hillis-Steele suffix scan and a tree, both log-depth, instead of a serial running
+// sum.  The second workgroup of a window to finish adds the two halves into wsum[w] (ticket[w] counts arrivals and is left
+// at zero again).
+__global__ void __launch_bounds__(R2D_TB) k_msm_reduce2d_window(const uint8_t* __restrict__ parts,
+                                                                 uint8_t* __restrict__ halves /* [2 * windows] XYZZ */,
+                                                                 uint32_t* __restrict__ ticket,
+                                                                 uint8_t* __restrict__ wsum) {
+    __shared__ uint32_t lds[XYZZ_WORDS * R2D_TB];
+    __shared__ uint32_t last_flag;
+    const int tid = threadIdx.x;
+    const uint32_t w = blockIdx.x;
+    const bool rows = blockIdx.y == 0;
+    const uint8_t* P = parts + XYZZ_BYTES * (size_t)w * R2D_THREADS;
+    // element `pos` of the group lives in LDS slot pos * sl; columns: slots 2l (the odd threads only feed the first level)
+    const int sl = rows ? 1 : 2;
+    const int pos = rows ? tid : (tid >> 1);
+    const int n = rows ? R2D_ROWS : R2D_COLS;
+    const bool owner = rows || (tid & 1) == 0;
+    const int lg = rows ? 8 : 7;   // log2(n)
+    G1XYZZ v;
+    {
+        const uint8_t* src;
+        size_t step;
+        if (rows) {
+            src = P + XYZZ_BYTES * (size_t)(tid * R2D_RPARTS);
+            step = XYZZ_BYTES;
+        } else {
+            src = P + XYZZ_BYTES * (size_t)(R2D_ROW_THREADS + (8 * (tid & 1)) * R2D_COLS + (tid >> 1));
+            step = XYZZ_BYTES * (size_t)R2D_COLS;
+        }
+        v = xyzz_load(src);
+        G1XYZZ nxt = xyzz_load(src + step);
+#pragma unroll 1
+        for (int j = 1; j < 8; ++j) {
+            const G1XYZZ cur = nxt;
+            if (j + 1 < 8) nxt = xyzz_load(src + step * (j + 1));
+            v = xyzz_add(v, cur);
+        }
+    }
+    r2d_put(lds, tid, v);
+    __syncthreads();
+    // levels: [columns only: the two halves] | suffix scan, d = 1, 2, .. n/2 | S_0 := 0 for rows | tree, s = n/2 .. 1
+    // ONE inlined addition serves them all (the operand's slot and the "active" predicate change per level)
+    const int first = rows ? 1 : 0;
+#pragma unroll 1
+    for (int lv = first; lv <= 2 * lg; ++lv) {
+        int partner;
+        bool act;
+        if (lv == 0) {               // columns: even thread += odd thread
+            partner = tid + 1;
+            act = owner;
+        } else if (lv <= lg) {       // scan
+            const int d = 1 << (lv - 1);
+            partner = (pos + d) * sl;
+            act = owner && pos + d < n;
+        } else {                     // tree
+            const int s2 = n >> (lv - lg);
+            partner = (pos + s2) * sl;
+            act = owner && pos < s2;
+            if (lv == lg + 1 && rows && tid == 0) {   // S_0 of the rows does not count (weight 0)
+                v = G1XYZZ::identity();
+            }
+        }
+        G1XYZZ o;
+        if (act) o = r2d_get(lds, partner);
+        __syncthreads();
+        if (act) v = xyzz_add(v, o);
+        if (act || (lv == lg + 1 && rows && tid == 0)) r2d_put(lds, tid, v);
+        __syncthreads();
+    }
+    if (tid == 0) {
+        if (rows) {
+#pragma unroll 1
+            for (int k = 0; k < R2D_LCOLS; ++k) v = xyzz_double(v);
+        }
+        xyzz_store(halves + XYZZ_BYTES * (size_t)(2 * w + blockIdx.y), v);
+        __threadfence();
+        last_flag = atomicAdd(&ticket[w], 1u);
+    }
+    __syncthreads();
+    if (last_flag == 1u && tid == 0) {
+        __threadfence();
+        const G1XYZZ other = xyzz_load(halves + XYZZ_BYTES * (size_t)(2 * w + (1 - blockIdx.y)));
+        xyzz_store(wsum + XYZZ_BYTES * (size_t)w, xyzz_add(v, other));
+        ticket[w] = 0;
+    }
+}
+
 // ---- 4-lane cooperative doubling for the serial Horner tail --------------------------------------------
 // A doubling is 9 field products on one lane (~2 300 VALU instructions, nothing to overlap with).  Its
 // dependency graph is only three products deep:   {V = U^2, XX = X^2} -> {W = U*V, S = X*V, M^2, V*ZZ}

@@ -675,6 +675,264 @@ __global__ void __launch_bounds__(TB) k_bucket_sort_staged(const uint32_t* __res
     }
 }
 
+// ------------------------------------------------------------------ digit-major sort (plain MSM, c = 16, n <= 2^22)
+// Round-2 PMC (profiles/r02_final_pmc_*.txt): the packed level 1 above is bound by its 16.7 M scattered 4-byte stores (one L2
+// request each, 278 MB written for 64 MB of payload) and by occupancy (a thread recodes a whole 256-bit scalar per digit walk,
+// 620 instructions per scalar, twice), not by LDS or HBM.  This path turns the problem by 90 degrees:
+//   digits     one pass writes the signed digits WINDOW-MAJOR as 16-bit codes (32 MiB at 2^20 points): everything after
+//              it reads 2 coalesced bytes per key and never touches a scalar again
+//   level 1    a workgroup takes (window, tile of 8192 points): 64..512 partitions of ONE window, so a partition's run in a
+//              tile is ~128 keys; the tile is ordered in 32 KiB of LDS and written back IN PLACE (tile-local, coalesced) with
+//              its table of partition offsets — no global reservation, no second recoding pass; the rank a key got from its
+//              one returning LDS atomic is kept in a register and reused for the placement
+//   level 2    one workgroup per partition collects its ~128-key run from every tile (contiguous, offsets from the tables),
+//              and sorts by bucket in LDS with ONE atomic per key as well (rank kept in registers)
+// LDS atomics per key: 2 (4 before); scattered global stores: none.
+constexpr int DM_T1 = 8192;          // keys per level-1 workgroup
+constexpr int DM_TB1 = 512;          // its threads
+constexpr int DM_PER1 = DM_T1 / DM_TB1;
+constexpr int DM_MAX_PPW = 512;      // partitions per window
+constexpr int DM_MAX_TILES = 512;    // n <= 2^22
+constexpr int DM_TB2 = 512;          // level-2 workgroup
+// keys a level-2 workgroup orders in LDS: PER per thread, 8192 (32 KiB, mean partition 4096) or 16384 (2^22 points: mean 8192).
+// The keys and their ranks sit in registers between the passes: PER = 16 keeps the kernel under 96 VGPRs, so that two workgroups
+// fit a CU NEXT TO the previous MSM's bucket reduction (128 VGPRs per wave), which runs on the tail stream during the sort.
+constexpr int DM_MAX_PW = 16 * DM_MAX_PPW;
+constexpr uint32_t DM_ZERO = 0x8000u;   // code of a zero digit; magnitude m > 0: m - 1 (positive), 0x8000 | m (negative)
+
+struct DmPlan {
+    uint32_t n, n_pad;     // points; row stride of codes[] (multiple of 8)
+    uint32_t n_row;        // row stride of items[]: ntile * DM_T1 (whole tiles: a tile's vector stores may run 3 keys past its last one)
+    uint32_t ntile;        // level-1 tiles per window
+    int sub_bits;          // low bucket bits resolved in level 2
+    uint32_t SB, ppw;      // buckets per partition, partitions per window
+    int idx_bits;          // 31 - sub_bits: item = sub | neg | idx
+};
+
+// codes[w * n_pad + i] = signed 16-bit digit w of scalar i (c = 16, W = 16; r < 2^254: no carry out of the top window)
+constexpr int DM_DIG_PER = 8;   // scalars per thread: few, long-lived waves (wave launches crawl while a VALU-saturating
+                                // kernel of the previous MSM's tail shares the SIMDs: 113 us instead of 20 with one scalar each)
+__global__ void __launch_bounds__(BLOCK) k_dm_digits(const uint8_t* __restrict__ scalars, uint32_t n, uint32_t n_pad,
+                                                     uint16_t* __restrict__ codes, uint32_t* flags) {
+    const uint32_t i0 = blockIdx.x * (BLOCK * DM_DIG_PER) + threadIdx.x;
+    U256 nxt;
+    if (i0 < n) nxt = u256_load(scalars + 32 * (size_t)i0);
+    uint32_t bad = 0;
+#pragma unroll 1
+    for (int k = 0; k < DM_DIG_PER; ++k) {
+        const uint32_t i = i0 + k * BLOCK;
+        if (i >= n) break;
+        const U256 s = nxt;
+        if (k + 1 < DM_DIG_PER && i + BLOCK < n) nxt = u256_load(scalars + 32 * (size_t)(i + BLOCK));
+        bad |= !u256_is_canonical_fr(s);
+        uint32_t carry = 0;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) {
+            const uint32_t raw = ((s.w[w >> 1] >> (16 * (w & 1))) & 0xffffu) + carry;
+            const bool neg = raw > 0x8000u;
+            carry = neg ? 1u : 0u;
+            const uint32_t code = neg ? (0x8000u | (0x10000u - raw)) : (raw == 0 ? DM_ZERO : raw - 1u);
+            codes[(size_t)w * n_pad + i] = (uint16_t)code;
+        }
+    }
+    if (bad) atomicOr(flags, FLAG_NONCANONICAL);
+}
+
+// exclusive scan of v[0..cnt) (cnt <= 512) in LDS, total -> v[cnt]: ONE wave does it (8 values per lane + a 6-step wave
+// scan), everybody else waits at the barrier — a Hillis-Steele scan over a 1024-thread workgroup is 20 barriers of 16 waves
+FP_INLINE uint32_t dm_wave_scan_incl(uint32_t x, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(x, d, 64);
+        if (lane >= (uint32_t)d) x += t;
+    }
+    return x;
+}
+FP_INLINE void dm_block_scan(uint32_t* v, uint32_t cnt) {
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const uint32_t lane = threadIdx.x;
+        uint32_t x[8], sum = 0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            x[j] = (8 * lane + j < cnt) ? v[8 * lane + j] : 0u;
+            sum += x[j];
+        }
+        const uint32_t inc = dm_wave_scan_incl(sum, lane);
+        uint32_t off = inc - sum;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (8 * lane + j < cnt) v[8 * lane + j] = off;
+            off += x[j];
+        }
+        if (lane == 63) v[cnt] = inc;
+    }
+    __syncthreads();
+}
+
+// out[i] = sum_{j<i} in[j] for i <= n (n <= DM_MAX_PW = 8192): one 1024-thread workgroup, 8 values per thread, wave scans
+__global__ void __launch_bounds__(1024) k_dm_scan(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
+    __shared__ uint32_t wsum[16];
+    const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t x[8], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        x[j] = (8 * tid + j < n) ? in[8 * tid + j] : 0u;
+        sum += x[j];
+    }
+    const uint32_t inc = dm_wave_scan_incl(sum, lane);
+    if (lane == 63) wsum[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t k = 0; k < wave; ++k) base += wsum[k];
+    uint32_t off = base + inc - sum;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (8 * tid + j <= n) out[8 * tid + j] = off;
+        off += x[j];
+    }
+    if (8 * tid + 8 == n) out[n] = off;   // n = 8 * blockDim.x: the total has no thread of its own
+}
+
+// grid (ntile, W).  items[w * n_row + tile * DM_T1 + k], k < toff[..][ppw]: the tile's keys ordered by partition;
+// toff[(w * ntile + tile) * (ppw + 1) + p]: where partition p starts inside the tile; pcount[w * ppw + p] += its length
+__global__ void __launch_bounds__(DM_TB1) k_dm_partition(const uint16_t* __restrict__ codes, DmPlan dp,
+                                                         uint32_t* __restrict__ pcount, uint32_t* __restrict__ toff,
+                                                         uint32_t* __restrict__ items) {
+    __shared__ uint32_t cnt[DM_MAX_PPW + 1];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[DM_T1];
+    const uint32_t tile = blockIdx.x, w = blockIdx.y;
+    const int tid = threadIdx.x;
+    for (uint32_t p = tid; p <= dp.ppw; p += DM_TB1) cnt[p] = 0;
+    __syncthreads();
+    const size_t row = (size_t)w * dp.n_pad;
+    const uint32_t t0 = tile * DM_T1;
+    uint4 v[DM_PER1 / 8];
+#pragma unroll
+    for (int k = 0; k < DM_PER1 / 8; ++k) {
+        const uint32_t i0 = t0 + (k * DM_TB1 + tid) * 8;
+        v[k] = (i0 < dp.n_pad) ? *reinterpret_cast<const uint4*>(codes + row + i0)
+                               : make_uint4(0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u);
+    }
+    uint32_t pr[DM_PER1];   // partition << 16 | rank inside (tile, partition); 0xffffffff: no key
+    const uint32_t submask = dp.SB - 1u;
+#pragma unroll
+    for (int k = 0; k < DM_PER1 / 8; ++k) {
+        const uint32_t wd[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t code = (wd[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+            const uint32_t i = t0 + (k * DM_TB1 + tid) * 8 + e;
+            const bool ok = code != DM_ZERO && i < dp.n;
+            const uint32_t bkt = (code & 0x8000u) ? (code & 0x7fffu) - 1u : code;
+            const uint32_t p = bkt >> dp.sub_bits;
+            pr[k * 8 + e] = ok ? ((p << 16) | atomicAdd(&cnt[p], 1u)) : 0xffffffffu;
+        }
+    }
+    __syncthreads();
+    for (uint32_t p = tid; p < dp.ppw; p += DM_TB1) {
+        const uint32_t c = cnt[p];
+        if (c) atomicAdd(&pcount[w * dp.ppw + p], c);
+    }
+    dm_block_scan(cnt, dp.ppw);   // cnt[p] = start of partition p, cnt[ppw] = keys in the tile
+    uint32_t* tt = toff + ((size_t)w * dp.ntile + tile) * (dp.ppw + 1);
+    for (uint32_t p = tid; p <= dp.ppw; p += DM_TB1) tt[p] = cnt[p];
+#pragma unroll
+    for (int k = 0; k < DM_PER1 / 8; ++k) {
+        const uint32_t wd[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const uint32_t q = pr[k * 8 + e];
+            if (q == 0xffffffffu) continue;
+            const uint32_t code = (wd[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+            const uint32_t neg = code >> 15;
+            const uint32_t bkt = neg ? (code & 0x7fffu) - 1u : code;
+            const uint32_t i = t0 + (k * DM_TB1 + tid) * 8 + e;
+            stage[cnt[q >> 16] + (q & 0xffffu)] = ((bkt & submask) << (dp.idx_bits + 1)) | (neg << dp.idx_bits) | i;
+        }
+    }
+    __syncthreads();
+    const uint32_t total = cnt[dp.ppw];
+    uint32_t* out = items + (size_t)w * dp.n_row + t0;
+    for (uint32_t k = 4 * tid; k < total; k += 4 * DM_TB1)   // rows and tiles start 16-byte aligned; the tail past `total` is slack
+        *reinterpret_cast<uint4*>(out + k) = *reinterpret_cast<const uint4*>(stage + k);
+}
+
+// level 2, one workgroup per partition (w, pl).  Key k of the partition (k < total) lives in tile t with
+// rpre[t] <= k < rpre[t + 1]; runs are nearly equal, so t is guessed from k and corrected by a step or two.
+template <int PER>
+__global__ void __launch_bounds__(DM_TB2) k_dm_bucket_sort(const uint32_t* __restrict__ pstart,
+                                                           const uint32_t* __restrict__ toff,
+                                                           const uint32_t* __restrict__ items, DmPlan dp, uint32_t NB,
+                                                           uint32_t* __restrict__ hist, uint32_t* __restrict__ offs,
+                                                           uint32_t* __restrict__ entries) {
+    constexpr int TB = DM_TB2;
+    __shared__ uint32_t h[DM_MAX_PPW + 8];              // [SB + 1]
+    __shared__ uint32_t rstart[DM_MAX_TILES];
+    __shared__ uint32_t rpre[DM_MAX_TILES + 8];         // run lengths, then their exclusive scan
+    constexpr int DM_STAGE = PER * DM_TB2;
+    __shared__ __attribute__((aligned(16))) uint32_t stage[DM_STAGE];
+    const uint32_t p = blockIdx.x, w = p / dp.ppw, pl = p - w * dp.ppw;
+    const int tid = threadIdx.x;
+    const uint32_t start = pstart[p], total = pstart[p + 1] - start;
+    for (uint32_t b = tid; b <= dp.SB; b += TB) h[b] = 0;
+    for (uint32_t t = tid; t < dp.ntile; t += TB) {
+        const uint32_t* tt = toff + ((size_t)w * dp.ntile + t) * (dp.ppw + 1) + pl;
+        const uint32_t a = tt[0];
+        rstart[t] = a;
+        rpre[t] = tt[1] - a;
+    }
+    dm_block_scan(rpre, dp.ntile);
+    const uint32_t* rowp = items + (size_t)w * dp.n_row;
+    const int sh = dp.idx_bits + 1;
+    const uint32_t idxmask = (1u << dp.idx_bits) - 1u;
+    const uint32_t key0 = w * NB + (pl << dp.sub_bits);
+    const float guess = total ? (float)dp.ntile / (float)total : 0.f;
+    auto locate = [&](uint32_t k) -> const uint32_t* {   // address of key k of this partition
+        uint32_t t = (uint32_t)((float)k * guess);
+        if (t >= dp.ntile) t = dp.ntile - 1;
+        while (rpre[t] > k) --t;
+        while (rpre[t + 1] <= k) ++t;
+        return rowp + (size_t)t * DM_T1 + rstart[t] + (k - rpre[t]);
+    };
+    if (total <= (uint32_t)DM_STAGE) {
+        uint32_t it[PER], rk[PER];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const uint32_t k = tid + j * TB;
+            it[j] = k < total ? *locate(k) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const uint32_t k = tid + j * TB;
+            rk[j] = k < total ? atomicAdd(&h[it[j] >> sh], 1u) : 0u;
+        }
+        __syncthreads();
+        for (uint32_t b = tid; b < dp.SB; b += TB) hist[key0 + b] = h[b];
+        dm_block_scan(h, dp.SB);
+        for (uint32_t b = tid; b < dp.SB; b += TB) offs[key0 + b] = start + h[b];
+#pragma unroll
+        for (int j = 0; j < PER; ++j) {
+            const uint32_t k = tid + j * TB;
+            if (k < total) stage[h[it[j] >> sh] + rk[j]] = (it[j] & idxmask) | (((it[j] >> dp.idx_bits) & 1u) << 31);
+        }
+        __syncthreads();
+        for (uint32_t k = tid; k < total; k += TB) entries[start + k] = stage[k];
+        return;
+    }
+    // over-long partition (skewed scalars: it does not fit the stage): count, scan, place straight into entries[]
+    for (uint32_t k = tid; k < total; k += TB) atomicAdd(&h[*locate(k) >> sh], 1u);
+    __syncthreads();
+    for (uint32_t b = tid; b < dp.SB; b += TB) hist[key0 + b] = h[b];
+    dm_block_scan(h, dp.SB);
+    for (uint32_t b = tid; b < dp.SB; b += TB) offs[key0 + b] = start + h[b];
+    __syncthreads();
+    for (uint32_t k = tid; k < total; k += TB) {
+        const uint32_t v = *locate(k);
+        entries[start + atomicAdd(&h[v >> sh], 1u)] = (v & idxmask) | (((v >> dp.idx_bits) & 1u) << 31);
+    }
+}
+
 // ------------------------------------------------------------------ order buckets by length (descending)
 FP_INLINE uint32_t size_bin(uint32_t len) { return (SIZE_BINS - 1) - (len < SIZE_BINS ? len : SIZE_BINS - 1); }
 

@@ -356,6 +356,8 @@ int h2agg_fr_tape_eval(h2agg_ctx* ctx, const uint8_t* consts, size_t nconst, con
  * 32 for n >= 2^20 in overlap mode).  big_bucket_threshold: run length above which a bucket is cut into
  * workgroup-sized chunks (0 = max(256, 8 x mean)). */
 int h2agg_msm_configure(h2agg_ctx* ctx, int window_bits, int reduce_segment, int big_bucket_threshold);
+/* (16-bit windows reduce their buckets as 256 rows x 128 columns — plain sums, then two weighted sums per window — unless
+ * reduce_segment is given, which selects the running-sum segment kernels; environment, for A/B runs: H2AGG_REDUCE=segments.) */
 /* GLV / endomorphism split of the scalars (k = k1 + lambda*k2, |k_i| < 2^127; phi(P) = (beta*x, y)): halves the
  * number of windows — same bucket additions, half the bucket reduction and half the serial doubling chain.
  * beta*x is computed once per base (a 32 B/point column beside the table), so the price is the decomposition pass and
@@ -368,7 +370,9 @@ int h2agg_msm_configure_lanes_per_bucket(h2agg_ctx* ctx, int lanes);
 /* Bucket-sort knobs: low bucket bits resolved per partition in LDS (4..12) and scalars per level-1
  * workgroup; 0 = default.  tile = -1 forces the two-array direct sort kernels (otherwise used only when
  * n does not fit the packed item's index field, n > 2^(31 - sub_bits)); tile = -2 additionally stages level 1
- * through LDS (measured slower; kept as a tested variant). */
+ * through LDS (measured slower; kept as a tested variant); tile = -3 keeps the packed two-level sort where the
+ * digit-major sort would apply (plain 16-bit windows over one table, 2^16 .. 2^22 points; any non-default knob
+ * here selects the packed kernels as well).  Environment, for A/B runs: H2AGG_SORT=packed. */
 int h2agg_msm_configure_sort(h2agg_ctx* ctx, int sub_bits, int tile);
 /* Overlap the latency-shaped tail of one MSM (enable = 1: the Horner kernel, one wave; 2: bucket reduction + window
  * sums + Horner) with the bulk kernels of the next ones: the tail runs on one of three tail streams of the context.  With overlap on, a result written by

@@ -1,0 +1,101 @@
+"""GPU: the digit-major bucket sort (csrc/sort_kernels.cuh: k_dm_digits / k_dm_partition / k_dm_bucket_sort) that plain
+16-bit-window MSMs of 2^16 .. 2^22 points take.  Expected values are (sum k_i s_i) * G from the Python oracle; every case
+is also run through the packed two-level sort (h2agg_msm_configure_sort(ctx, 0, -3)) and must give the same bytes."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import bn254 as O
+
+pytestmark = pytest.mark.gpu
+
+R = O.R
+
+
+def _bytes(vals):
+    return np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals), dtype=np.uint8).reshape(len(vals), 32)
+
+
+def _rand(n, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    raw = rng.bytes(64 * n)
+    return [int.from_bytes(raw[64 * i:64 * i + 64], "little") % R for i in range(n)]
+
+
+def _run(eng, ks, ss):
+    n = len(ks)
+    dev = torch.device("cuda", 0)
+    d_k = torch.from_numpy(_bytes(ks).copy()).to(dev)
+    d_s = torch.from_numpy(_bytes(ss).copy()).to(dev)
+    table = eng.bases_generate(d_k.data_ptr(), n)
+    want = O.aff_to_bytes(O.scalar_mul(sum(k * s for k, s in zip(ks, ss)) % R, O.G1))
+    try:
+        eng.msm_configure_glv(-1)
+        eng.msm_configure(16, 0, 0)
+        got = {}
+        for name, tile in (("digit-major", 0), ("packed", -3)):
+            eng.msm_configure_sort(0, tile)
+            got[name] = eng.g1_batch_to_affine(eng.g1_msm_device(table, d_s.data_ptr(), n))
+        assert got["digit-major"] == want
+        assert got["packed"] == want
+    finally:
+        eng.msm_configure_sort(0, 0)
+        eng.msm_configure(0, 0, 0)
+        eng.msm_configure_glv(0)
+        eng.bases_free(table)
+
+
+@pytest.mark.parametrize("n", [1 << 16, (1 << 16) + 5, 100003, (1 << 18) + 8191, 1 << 20, (1 << 21) + 12345, 1 << 22])
+def test_random_scalars(eng, n):
+    _run(eng, _rand(n, 7 * n + 1), _rand(n, 7 * n + 2))
+
+
+def test_ragged_sizes_around_the_tile(eng):
+    for n in (8192 * 9 - 1, 8192 * 9 + 1, 8192 * 8 + 4097):
+        _run(eng, _rand(n, n), _rand(n, n + 1))
+
+
+def test_structured_scalars(eng):
+    """zero digits, digits at both ends of the signed range, carries that ripple through every window, one value in every
+    lane (a single bucket per window holds everything: the over-long partition path), r - 1, 0"""
+    n = (1 << 16) + 77
+    ks = _rand(n, 5)
+    half = sum(0x8000 << (16 * w) for w in range(15))          # every digit exactly +2^15
+    ripple = sum(0xffff << (16 * w) for w in range(15))        # ... 0xffff: digit -1 then carries all the way up
+    over = sum(0x8001 << (16 * w) for w in range(15))          # first negative magnitude (2^15 - 1)
+    pats = [0, 1, R - 1, half, ripple, over, 1 << 240, (1 << 253) + 12345, 0x10000, 0xffff0000ffff]
+    _run(eng, ks, [pats[i % len(pats)] for i in range(n)])
+    _run(eng, ks, [R - 1] * n)
+    _run(eng, ks, [0x1234_5678_9abc_def0_1111_2222_3333_4444_5555_6666_7777_8888_9999_aaaa_bbbb % R] * n)
+    _run(eng, ks, [0] * n)
+
+
+def test_skewed_partitions(eng):
+    """three quarters of the scalars share their low digits (one level-2 partition far beyond the LDS stage), the rest random"""
+    n = 1 << 17
+    ks = _rand(n, 9)
+    rnd = _rand(n, 10)
+    ss = [(rnd[i] & ~0xffffffff) | 0x12345678 if i % 4 else rnd[i] for i in range(n)]
+    _run(eng, ks, [s % R for s in ss])
+
+
+def test_reduction_paths_agree(eng):
+    """16-bit windows take the two-dimensional bucket reduction (k_msm_reduce2d_*); an explicit reduce_segment keeps the
+    segment kernels: same bytes, with and without GLV (8 / 16 windows), one MSM after another on rotating tail slots"""
+    n = (1 << 16) + 123
+    ks, ss = _rand(n, 21), _rand(n, 22)
+    dev = torch.device("cuda", 0)
+    d_k = torch.from_numpy(_bytes(ks).copy()).to(dev)
+    d_s = torch.from_numpy(_bytes(ss).copy()).to(dev)
+    table = eng.bases_generate(d_k.data_ptr(), n)
+    want = O.aff_to_bytes(O.scalar_mul(sum(k * s for k, s in zip(ks, ss)) % R, O.G1))
+    try:
+        for glv in (-1, 1):
+            eng.msm_configure_glv(glv)
+            for seg in (0, 32, 0, 8, 0):
+                eng.msm_configure(16, seg, 0)
+                assert eng.g1_batch_to_affine(eng.g1_msm_device(table, d_s.data_ptr(), n)) == want, (glv, seg)
+    finally:
+        eng.msm_configure(0, 0, 0)
+        eng.msm_configure_glv(0)
+        eng.bases_free(table)

@@ -1,0 +1,32 @@
+"""timing only (no verification): K asynchronous 2^log2n-point MSMs in overlap mode, three repetitions.
+    python tools/steps_time.py [log2n] [K] [bracket the accumulation with events: 0|1]
+Used with H2AGG_DBG_SKIP=1|3|7 (skip bucket reduction / + window sums / + Horner tail: WRONG results, timing only) to price the tails."""
+import sys, time, numpy as np, torch
+sys.path.insert(0, '.')
+import __graft_entry__ as e
+pkg = e.load_package()
+eng = pkg.H2Agg(0)
+n = 1 << int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 40
+PROF = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+from bench import gen_scalars
+_, k = gen_scalars(1, n)
+_, s = gen_scalars(2, n)
+k = k.copy(); s = s.copy()
+dev = torch.device('cuda', 0)
+dk = torch.from_numpy(k).to(dev); ds = torch.from_numpy(s).to(dev)
+out = torch.zeros(96 * K, dtype=torch.uint8, device=dev)
+t = eng.bases_generate(dk.data_ptr(), n)
+eng.msm_set_tail_overlap(2)
+if PROF:
+    eng.profile_enable(True, only_stage=4)
+for rep in range(3):
+    for i in range(5):
+        eng.g1_msm_device_async(t, ds.data_ptr(), n, out.data_ptr() + 96 * i)
+    eng.synchronize()
+    t0 = time.perf_counter()
+    for i in range(K):
+        eng.g1_msm_device_async(t, ds.data_ptr(), n, out.data_ptr() + 96 * i)
+    eng.synchronize()
+    dt = (time.perf_counter() - t0) / K
+    print("ms/step %.3f  %.1f Mpts/s" % (dt * 1e3, n / dt / 1e6), flush=True)
