@@ -80,7 +80,8 @@ struct h2agg_ctx {
     bool psd_ready = false;
     // verifier pipeline (csrc/verifier.inc): instance values / commitments of a circuit's proofs, the aggregation transcript
     DevBuf inst_vals, inst_jac, inst_aff, agg_elems;
-    DevBuf hist, offs, pmeta, item_idx, item_sub, order, entries, big_list, big_keys, big_part,
+    DevBuf hist[2], offs[2], pmeta[2], order[2], entries[2];   // what the accumulation reads: one set per sort slot (overlap level 3)
+    DevBuf item_idx, item_sub, big_list, big_keys, big_part,
         glv_buf, parts, small, endo_buf, tile_counts;  // MSM (bulk side: main stream only)
     uint32_t* d_flags = nullptr;      // in `small`: [0] status flags, [1] big_count
     uint8_t* d_res_xyzz = nullptr;    // in `small` + 1024 + 144 * slot of the LAST msm_run (see msm_run)
@@ -126,6 +127,12 @@ struct h2agg_ctx {
     hipEvent_t ev_bulk[TAIL_SLOTS] = {}, ev_tail[TAIL_SLOTS] = {};
     bool tail_pending[TAIL_SLOTS] = {};
     int parity = 0;   // slot of the next MSM
+    // overlap level 3: the bucket accumulation of MSM k runs on its own stream, under the sort of MSM k+1 (which stays on the
+    // context's stream, ordered after whatever the caller queued there).  The sort's outputs exist twice.
+    hipStream_t acc_stream = nullptr;
+    hipEvent_t ev_sorted[2] = {}, ev_accdone[2] = {};
+    bool accdone_pending[2] = {};
+    int sort_par = 0;
 
     // profiling: a ring of per-call event sets, harvested lazily so that measuring does not serialise
     // back-to-back asynchronous MSMs
@@ -311,6 +318,12 @@ int join_tails(h2agg_ctx* c) {
             c->tail_pending[k] = false;
         }
     }
+    for (int q = 0; q < 2; ++q) {   // (every accumulation is followed by a tail, so these have completed: bookkeeping)
+        if (c->accdone_pending[q]) {
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_accdone[q], 0));
+            c->accdone_pending[q] = false;
+        }
+    }
     return H2AGG_OK;
 }
 
@@ -391,10 +404,13 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     constexpr uint32_t M_PSTART = META_PW + 64, M_PCURSOR = M_PSTART + META_PW + 64,
                        M_BCOUNT = M_PCURSOR + META_PW + 64, M_BSTART = M_BCOUNT + SIZE_BINS + 64,
                        M_BCURSOR = M_BSTART + SIZE_BINS + 64, M_BIG = M_BCURSOR + SIZE_BINS + 64, M_WORDS = M_BIG + 64;
-    TRY(ensure(c, c->pmeta, M_WORDS * 4));
-    TRY(ensure(c, c->hist, (size_t)p.NBT * 4));
-    TRY(ensure(c, c->offs, (size_t)p.NBT * 4));
-    TRY(ensure(c, c->order, (size_t)p.NBT * 4));
+    // overlap level 3 (see h2agg_ctx::acc_stream): this MSM's accumulation leaves the context's stream
+    const bool piped = c->tail_overlap && c->overlap_level >= 3;
+    const int sq = piped ? c->sort_par : 0;
+    TRY(ensure(c, c->pmeta[sq], M_WORDS * 4));
+    TRY(ensure(c, c->hist[sq], (size_t)p.NBT * 4));
+    TRY(ensure(c, c->offs[sq], (size_t)p.NBT * 4));
+    TRY(ensure(c, c->order[sq], (size_t)p.NBT * 4));
     // digit-major sort (sort_kernels.cuh): plain 16-bit windows over one table, 2^16 .. 2^22 points
     static const bool dm_env_off = getenv("H2AGG_SORT") && !strcmp(getenv("H2AGG_SORT"), "packed");
     const bool dm = !dm_env_off && !c->cfg_no_dm && !c->cfg_no_stage && !c->cfg_stage_l1 && !c->cfg_sub_bits && !c->cfg_tile && !p.glv && !pre && batch == 1 &&
@@ -414,7 +430,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     }
     TRY(ensure(c, c->item_idx, dm ? (size_t)16 * dp.n_row * 4 : nent * 4));
     TRY(ensure(c, c->item_sub, dm ? (size_t)16 * dp.n_pad * 2 : nent * 2));
-    TRY(ensure(c, c->entries, nent * 4));
+    TRY(ensure(c, c->entries[sq], nent * 4));
     // buckets / segsum / wsum exist once per tail slot: in overlap mode the reduction of MSM k (tail stream)
     // runs while MSM k+1 fills the next slot's set.  (They were one allocation cut at par * this-plan's-size: two MSMs
     // with different plans in flight then overlapped — ADVICE r1.)
@@ -430,15 +446,15 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     TRY(ensure(c, c->big_list, max_slots * 12));
     TRY(ensure(c, c->big_keys, max_keys * 12));
     TRY(ensure(c, c->big_part, max_slots * XYZZ_BYTES));
-    uint32_t* meta = (uint32_t*)c->pmeta.p;
+    uint32_t* meta = (uint32_t*)c->pmeta[sq].p;
     uint32_t *pcount = meta, *pstart = meta + M_PSTART, *pcursor = meta + M_PCURSOR;
     uint32_t *bin_count = meta + M_BCOUNT, *bin_start = meta + M_BSTART, *bin_cursor = meta + M_BCURSOR;
-    uint32_t* hist = (uint32_t*)c->hist.p;
-    uint32_t* offs = (uint32_t*)c->offs.p;
-    uint32_t* order = (uint32_t*)c->order.p;
+    uint32_t* hist = (uint32_t*)c->hist[sq].p;
+    uint32_t* offs = (uint32_t*)c->offs[sq].p;
+    uint32_t* order = (uint32_t*)c->order[sq].p;
     uint32_t* item_idx = (uint32_t*)c->item_idx.p;
     uint16_t* item_sub = (uint16_t*)c->item_sub.p;
-    uint32_t* entries = (uint32_t*)c->entries.p;
+    uint32_t* entries = (uint32_t*)c->entries[sq].p;
     c->d_res_xyzz = (uint8_t*)c->small.p + 1024 + 144 * par;   // each tail slot has its own XYZZ result
     uint8_t* buckets = (uint8_t*)c->buckets[par].p;
     uint8_t* segsum = (uint8_t*)c->segsum[par].p;
@@ -459,6 +475,14 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         tile_counts = (uint32_t*)c->tile_counts.p;
     }
     profile_begin_call(c);
+    // the accumulation that last read this slot's sort outputs (two MSMs ago, or any earlier one for an MSM that does not
+    // leave the stream: it uses slot 0 and scratch the accumulation stream may still read — beta*x column, slice sums)
+    for (int q = 0; q < 2; ++q) {
+        if (c->accdone_pending[q] && (!piped || q == sq || (p.glv && !d_endo_x))) {
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_accdone[q], 0));
+            c->accdone_pending[q] = false;
+        }
+    }
 
     if (p.glv && !d_endo_x) {
         TRY(ensure(c, c->endo_buf, n_base * 32));
@@ -555,6 +579,11 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
                            bin_cursor);
         hipLaunchKernelGGL(k_size_scatter, dim3(g), dim3(BLOCK), 0, st, hist, p.NBT, bin_cursor, order);
     }
+    if (piped) {   // from here on: the accumulation stream
+        HIP_TRY(c, hipEventRecord(c->ev_sorted[sq], st));
+        HIP_TRY(c, hipStreamWaitEvent(c->acc_stream, c->ev_sorted[sq], 0));
+        st = c->acc_stream;
+    }
     if (c->tail_pending[par]) {  // the tail TAIL_SLOTS MSMs ago read this slot's buckets / segsum / wsum
         HIP_TRY(c, hipStreamWaitEvent(st, c->ev_tail[par], 0));
         c->tail_pending[par] = false;
@@ -574,7 +603,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     }
     constexpr int acc_block = 64;
     {
-        StageTimer t(c, ST_ACCUM);
+        StageTimer t(c, ST_ACCUM, st);
         // one-wave workgroups: a 4-wave workgroup needs a free slot on all four SIMDs of a CU at once and its waves retire
         // at different times; single waves fill any slot as it frees up (2^20 points: 1.74 -> 1.67 ms/step)
         hipLaunchKernelGGL(k_msm_accumulate, dim3((unsigned)(((size_t)p.NBT * lpb + acc_block - 1) / acc_block)), dim3(acc_block), 0,
@@ -582,7 +611,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
                            big_list, big_keys, big_count);
     }
     {
-        StageTimer t(c, ST_ACCUM_BIG);
+        StageTimer t(c, ST_ACCUM_BIG, st);
         size_t grid = max_slots;
         const size_t cap = (size_t)c->cu_count * 4;
         if (grid > cap) grid = cap;
@@ -594,6 +623,11 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         if (lpb > 1)
             hipLaunchKernelGGL(k_msm_bucket_combine, dim3((p.NBT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st,
                                (const uint8_t*)acc_out, hist, p.NBT, p.big, lpb, buckets);
+    }
+    if (piped) {
+        HIP_TRY(c, hipEventRecord(c->ev_accdone[sq], st));
+        c->accdone_pending[sq] = true;
+        c->sort_par ^= 1;
     }
     // Everything after the bucket accumulation is latency-shaped (one wave per SIMD or less): bucket
     // reduction, per-window sums, Horner tail.  In overlap mode it runs on the context's second stream,
@@ -726,6 +760,18 @@ int h2agg_create(int device_ordinal, h2agg_ctx** out) try {
         hipEventCreateWithFlags(&c->ev_bulk[k], EV_SYNC_FLAGS);
         hipEventCreateWithFlags(&c->ev_tail[k], EV_SYNC_FLAGS);
     }
+    int apr_lo = 0, apr_hi = 0;
+    hipDeviceGetStreamPriorityRange(&apr_lo, &apr_hi);
+    static const int acc_prio = getenv("H2AGG_ACC_PRIO") ? atoi(getenv("H2AGG_ACC_PRIO")) : 0;   // experiment: -1 lowest
+    if ((acc_prio ? hipStreamCreateWithPriority(&c->acc_stream, hipStreamNonBlocking, acc_prio < 0 ? apr_lo : apr_hi)
+                  : hipStreamCreateWithFlags(&c->acc_stream, hipStreamNonBlocking)) != hipSuccess) {
+        h2agg_destroy(c);
+        return H2AGG_ERR_HIP;
+    }
+    for (int q = 0; q < 2; ++q) {
+        hipEventCreateWithFlags(&c->ev_sorted[q], EV_SYNC_FLAGS);
+        hipEventCreateWithFlags(&c->ev_accdone[q], EV_SYNC_FLAGS);
+    }
     c->d_flags = (uint32_t*)c->small.p;
     c->d_res_xyzz = (uint8_t*)c->small.p + 1024;   // 144 B
     c->d_res_jac = (uint8_t*)c->small.p + 256;   // 96 B
@@ -748,11 +794,12 @@ void h2agg_destroy(h2agg_ctx* c) {
     hipSetDevice(c->device);
     comm_release(c);
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->acc_stream) hipStreamSynchronize(c->acc_stream);
     for (int k = 0; k < h2agg_ctx::TAIL_SLOTS; ++k)
         if (c->tail_streams[k]) hipStreamSynchronize(c->tail_streams[k]);
     static_assert(h2agg_ctx::TAIL_SLOTS == 3, "the list below names every tail slot's buffers");
-    DevBuf* bufs[] = {&c->in_a,  &c->in_b,     &c->in_c,     &c->out,   &c->tmp_bases, &c->comb, &c->psd_spec, &c->tr_in, &c->tr_points, &c->tr_elems, &c->tr_chal, &c->inst_vals, &c->inst_jac, &c->inst_aff, &c->agg_elems, &c->hist,
-                      &c->offs,  &c->pmeta,    &c->item_idx, &c->item_sub, &c->order,  &c->entries,
+    DevBuf* bufs[] = {&c->in_a,  &c->in_b,     &c->in_c,     &c->out,   &c->tmp_bases, &c->comb, &c->psd_spec, &c->tr_in, &c->tr_points, &c->tr_elems, &c->tr_chal, &c->inst_vals, &c->inst_jac, &c->inst_aff, &c->agg_elems, &c->hist[0], &c->hist[1],
+                      &c->offs[0], &c->offs[1], &c->pmeta[0], &c->pmeta[1], &c->item_idx, &c->item_sub, &c->order[0], &c->order[1], &c->entries[0], &c->entries[1],
                       &c->r2d_ticket[0], &c->r2d_ticket[1], &c->r2d_ticket[2], &c->buckets[0], &c->buckets[1], &c->buckets[2], &c->segsum[0], &c->segsum[1], &c->segsum[2],
                       &c->wsum[0], &c->wsum[1], &c->wsum[2], &c->big_list, &c->big_keys, &c->big_part, &c->glv_buf, &c->parts, &c->small, &c->endo_buf, &c->tile_counts,
                       &c->sch_regs, &c->sch_in, &c->sch_scalars[0], &c->sch_scalars[1], &c->sch_bases[0], &c->sch_bases[1]};
@@ -781,6 +828,11 @@ void h2agg_destroy(h2agg_ctx* c) {
         if (c->ev_tail[k]) hipEventDestroy(c->ev_tail[k]);
         if (c->tail_streams[k]) hipStreamDestroy(c->tail_streams[k]);
     }
+    for (int q = 0; q < 2; ++q) {
+        if (c->ev_sorted[q]) hipEventDestroy(c->ev_sorted[q]);
+        if (c->ev_accdone[q]) hipEventDestroy(c->ev_accdone[q]);
+    }
+    if (c->acc_stream) hipStreamDestroy(c->acc_stream);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -1534,7 +1586,7 @@ int h2agg_msm_set_tail_overlap(h2agg_ctx* c, int enable) try {
     TRY(join_tails(c));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->tail_overlap = enable != 0;
-    if (enable == 1 || enable == 2) c->overlap_level = enable;
+    if (enable >= 1 && enable <= 3) c->overlap_level = enable;
     return H2AGG_OK;
 } catch (const std::bad_alloc&) {
     return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI

@@ -65,7 +65,7 @@ def test_sliced_device_msm_ragged_last_slice_every_parity(eng):
         eng.bases_free(table)
 
 
-@pytest.mark.parametrize("level", [1, 2])
+@pytest.mark.parametrize("level", [1, 2, 3])
 def test_overlap_mode_alternating_sizes(eng, level):
     """public overlap mode, back-to-back asynchronous MSMs of very different sizes (2^20 / 2^10 / 2^14 / 3 points):
     every result must be right, whatever tails were in flight around it."""

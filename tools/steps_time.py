@@ -17,7 +17,8 @@ dev = torch.device('cuda', 0)
 dk = torch.from_numpy(k).to(dev); ds = torch.from_numpy(s).to(dev)
 out = torch.zeros(96 * K, dtype=torch.uint8, device=dev)
 t = eng.bases_generate(dk.data_ptr(), n)
-eng.msm_set_tail_overlap(2)
+import os
+eng.msm_set_tail_overlap(int(os.environ.get('LEVEL', '2')))
 if PROF:
     eng.profile_enable(True, only_stage=4)
 for rep in range(3):
