@@ -81,7 +81,9 @@ struct h2agg_ctx {
     // verifier pipeline (csrc/verifier.inc): instance values / commitments of a circuit's proofs, the aggregation transcript
     DevBuf inst_vals, inst_jac, inst_aff, agg_elems;
     DevBuf hist[2], offs[2], pmeta[2], order[2], entries[2];   // what the accumulation reads: one set per sort slot (overlap level 3)
-    DevBuf item_idx, item_sub, big_list, big_keys, big_part,
+    DevBuf big_list[2], big_keys[2], big_part[2];              // written by the accumulation, read by the over-long-bucket kernels
+    bool meta_clean[2] = {};                                   // pmeta[q] was zeroed behind its last use (tail stream)
+    DevBuf item_idx, item_sub,
         glv_buf, parts, small, endo_buf, tile_counts;  // MSM (bulk side: main stream only)
     uint32_t* d_flags = nullptr;      // in `small`: [0] status flags, [1] big_count
     uint8_t* d_res_xyzz = nullptr;    // in `small` + 1024 + 144 * slot of the LAST msm_run (see msm_run)
@@ -406,8 +408,15 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
                        M_BCURSOR = M_BSTART + SIZE_BINS + 64, M_BIG = M_BCURSOR + SIZE_BINS + 64, M_WORDS = M_BIG + 64;
     // overlap level 3 (see h2agg_ctx::acc_stream): this MSM's accumulation leaves the context's stream
     const bool piped = c->tail_overlap && c->overlap_level >= 3;
-    const int sq = piped ? c->sort_par : 0;
-    TRY(ensure(c, c->pmeta[sq], M_WORDS * 4));
+    // overlap level >= 2: consecutive MSMs alternate between the two sets of sort outputs, so that what still reads one set
+    // behind the accumulation (over-long-bucket kernels, zeroing of the counters: tail stream) never holds up the next sort
+    const bool altbuf = c->tail_overlap && c->overlap_level >= 2;
+    const int sq = altbuf ? c->sort_par : 0;
+    {
+        const size_t cap0 = c->pmeta[sq].cap;
+        TRY(ensure(c, c->pmeta[sq], M_WORDS * 4));
+        if (c->pmeta[sq].cap != cap0) c->meta_clean[sq] = false;
+    }
     TRY(ensure(c, c->hist[sq], (size_t)p.NBT * 4));
     TRY(ensure(c, c->offs[sq], (size_t)p.NBT * 4));
     TRY(ensure(c, c->order[sq], (size_t)p.NBT * 4));
@@ -443,9 +452,9 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     TRY(ensure(c, c->wsum[par], (size_t)WT * XYZZ_BYTES));
     const size_t max_slots = nent / BIG_CHUNK + nent / ((size_t)p.big + 1) + 2;   // chunks of over-long buckets
     const size_t max_keys = nent / ((size_t)p.big + 1) + 2;
-    TRY(ensure(c, c->big_list, max_slots * 12));
-    TRY(ensure(c, c->big_keys, max_keys * 12));
-    TRY(ensure(c, c->big_part, max_slots * XYZZ_BYTES));
+    TRY(ensure(c, c->big_list[sq], max_slots * 12));
+    TRY(ensure(c, c->big_keys[sq], max_keys * 12));
+    TRY(ensure(c, c->big_part[sq], max_slots * XYZZ_BYTES));
     uint32_t* meta = (uint32_t*)c->pmeta[sq].p;
     uint32_t *pcount = meta, *pstart = meta + M_PSTART, *pcursor = meta + M_PCURSOR;
     uint32_t *bin_count = meta + M_BCOUNT, *bin_start = meta + M_BSTART, *bin_cursor = meta + M_BCURSOR;
@@ -459,9 +468,9 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     uint8_t* buckets = (uint8_t*)c->buckets[par].p;
     uint8_t* segsum = (uint8_t*)c->segsum[par].p;
     uint8_t* wsum = (uint8_t*)c->wsum[par].p;
-    uint32_t* big_list = (uint32_t*)c->big_list.p;
-    uint32_t* big_keys = (uint32_t*)c->big_keys.p;
-    uint8_t* big_part = (uint8_t*)c->big_part.p;
+    uint32_t* big_list = (uint32_t*)c->big_list[sq].p;
+    uint32_t* big_keys = (uint32_t*)c->big_keys[sq].p;
+    uint8_t* big_part = (uint8_t*)c->big_part[sq].p;
     uint32_t* big_count = meta + M_BIG;   // [0] chunk slots, [1] multi-chunk buckets (zeroed with the rest of meta)
     hipStream_t st = c->stream;
     const unsigned ntiles = (unsigned)((n + sp.tile - 1) / sp.tile);
@@ -474,11 +483,13 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         TRY(ensure(c, c->tile_counts, (size_t)ntiles * sp.PW * 4));
         tile_counts = (uint32_t*)c->tile_counts.p;
     }
+    const bool meta_was_clean = altbuf && c->meta_clean[sq];
+    c->meta_clean[sq] = false;
     profile_begin_call(c);
     // the accumulation that last read this slot's sort outputs (two MSMs ago, or any earlier one for an MSM that does not
     // leave the stream: it uses slot 0 and scratch the accumulation stream may still read — beta*x column, slice sums)
     for (int q = 0; q < 2; ++q) {
-        if (c->accdone_pending[q] && (!piped || q == sq || (p.glv && !d_endo_x))) {
+        if (c->accdone_pending[q] && (!altbuf || q == sq || (p.glv && !d_endo_x))) {
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_accdone[q], 0));
             c->accdone_pending[q] = false;
         }
@@ -501,7 +512,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         const uint32_t PW = 16u * dp.ppw;
         {
             StageTimer t(c, ST_PART_COUNT);
-            HIP_TRY(c, hipMemsetAsync(meta, 0, M_WORDS * 4, st));
+            if (!meta_was_clean) HIP_TRY(c, hipMemsetAsync(meta, 0, M_WORDS * 4, st));
             hipLaunchKernelGGL(k_dm_digits, dim3((unsigned)((n + BLOCK * DM_DIG_PER - 1) / (BLOCK * DM_DIG_PER))), dim3(BLOCK), 0, st, d_scalars, dp.n,
                                dp.n_pad, item_sub, c->d_flags);
         }
@@ -523,7 +534,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     } else {
     {
         StageTimer t(c, ST_PART_COUNT);
-        HIP_TRY(c, hipMemsetAsync(meta, 0, M_WORDS * 4, st));
+        if (!meta_was_clean) HIP_TRY(c, hipMemsetAsync(meta, 0, M_WORDS * 4, st));
         hipLaunchKernelGGL(k_part_count, dim3(ntiles), dim3(BLOCK), 0, st, d_scalars, n, p.c, Wd, sp, pcount,
                            c->d_flags, tile_counts);
         hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(BLOCK), 0, st, pcount, sp.PW, pstart, pcursor);
@@ -606,29 +617,37 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         StageTimer t(c, ST_ACCUM, st);
         // one-wave workgroups: a 4-wave workgroup needs a free slot on all four SIMDs of a CU at once and its waves retire
         // at different times; single waves fill any slot as it frees up (2^20 points: 1.74 -> 1.67 ms/step)
-        hipLaunchKernelGGL(k_msm_accumulate, dim3((unsigned)(((size_t)p.NBT * lpb + acc_block - 1) / acc_block)), dim3(acc_block), 0,
+        static const int acc_lds = getenv("H2AGG_ACC_LDS") ? atoi(getenv("H2AGG_ACC_LDS")) : 0;   // experiment: unused LDS per wave caps the occupancy
+        hipLaunchKernelGGL(k_msm_accumulate, dim3((unsigned)(((size_t)p.NBT * lpb + acc_block - 1) / acc_block)), dim3(acc_block), (size_t)acc_lds,
                            st, d_bases, d_endo_x, entries, offs, hist, ordered ? order : (uint32_t*)nullptr, p.NBT, p.big, lpb, acc_out,
                            big_list, big_keys, big_count);
     }
-    {
-        StageTimer t(c, ST_ACCUM_BIG, st);
+    // Buckets longer than `big` (skewed scalars; none for uniform ones, where the two launches below only find empty lists):
+    // with alternating sort outputs they leave the bulk stream and go in front of the bucket reduction on the tail stream,
+    // followed by the zeroing of this slot's counters for the MSM after next.
+    const bool tail_big = altbuf && c->overlap_level >= 2 && lpb == 1;
+    auto big_kernels = [&](hipStream_t bs) {
+        StageTimer t(c, ST_ACCUM_BIG, bs);
         size_t grid = max_slots;
         const size_t cap = (size_t)c->cu_count * 4;
         if (grid > cap) grid = cap;
-        hipLaunchKernelGGL(k_msm_accumulate_big, dim3((unsigned)grid), dim3(BLOCK), 0, st, d_bases, d_endo_x, entries, offs, hist,
+        hipLaunchKernelGGL(k_msm_accumulate_big, dim3((unsigned)grid), dim3(BLOCK), 0, bs, d_bases, d_endo_x, entries, offs, hist,
                            acc_out, lpb, big_part, big_list, big_count);
         size_t gk = max_keys < cap ? max_keys : cap;
-        hipLaunchKernelGGL(k_msm_big_combine, dim3((unsigned)gk), dim3(BLOCK), 0, st, big_part, big_keys, big_count,
+        hipLaunchKernelGGL(k_msm_big_combine, dim3((unsigned)gk), dim3(BLOCK), 0, bs, big_part, big_keys, big_count,
                            acc_out, lpb);
         if (lpb > 1)
-            hipLaunchKernelGGL(k_msm_bucket_combine, dim3((p.NBT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, st,
+            hipLaunchKernelGGL(k_msm_bucket_combine, dim3((p.NBT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, bs,
                                (const uint8_t*)acc_out, hist, p.NBT, p.big, lpb, buckets);
+    };
+    if (!tail_big) {
+        big_kernels(st);
+        if (altbuf) {
+            HIP_TRY(c, hipEventRecord(c->ev_accdone[sq], st));
+            c->accdone_pending[sq] = true;
+        }
     }
-    if (piped) {
-        HIP_TRY(c, hipEventRecord(c->ev_accdone[sq], st));
-        c->accdone_pending[sq] = true;
-        c->sort_par ^= 1;
-    }
+    if (altbuf) c->sort_par ^= 1;
     // Everything after the bucket accumulation is latency-shaped (one wave per SIMD or less): bucket
     // reduction, per-window sums, Horner tail.  In overlap mode it runs on the context's second stream,
     // under the sort + accumulation of the next MSM; results are picked up by join_tails().
@@ -637,6 +656,13 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         HIP_TRY(c, hipEventRecord(c->ev_bulk[par], st));
         HIP_TRY(c, hipStreamWaitEvent(c->tail_streams[par], c->ev_bulk[par], 0));
         ts = c->tail_streams[par];
+    }
+    if (tail_big) {
+        big_kernels(ts);
+        HIP_TRY(c, hipMemsetAsync(meta, 0, M_WORDS * 4, ts));
+        c->meta_clean[sq] = true;
+        HIP_TRY(c, hipEventRecord(c->ev_accdone[sq], ts));
+        c->accdone_pending[sq] = true;
     }
     static const int dbg_skip = getenv("H2AGG_DBG_SKIP") ? atoi(getenv("H2AGG_DBG_SKIP")) : 0;   // measurement only: 1 reduce, 2 + window sums, 4 + final
     // two-dimensional bucket reduction for 16-bit windows (msm_kernels.cuh); H2AGG_REDUCE=segments keeps the segment kernels
@@ -801,7 +827,7 @@ void h2agg_destroy(h2agg_ctx* c) {
     DevBuf* bufs[] = {&c->in_a,  &c->in_b,     &c->in_c,     &c->out,   &c->tmp_bases, &c->comb, &c->psd_spec, &c->tr_in, &c->tr_points, &c->tr_elems, &c->tr_chal, &c->inst_vals, &c->inst_jac, &c->inst_aff, &c->agg_elems, &c->hist[0], &c->hist[1],
                       &c->offs[0], &c->offs[1], &c->pmeta[0], &c->pmeta[1], &c->item_idx, &c->item_sub, &c->order[0], &c->order[1], &c->entries[0], &c->entries[1],
                       &c->r2d_ticket[0], &c->r2d_ticket[1], &c->r2d_ticket[2], &c->buckets[0], &c->buckets[1], &c->buckets[2], &c->segsum[0], &c->segsum[1], &c->segsum[2],
-                      &c->wsum[0], &c->wsum[1], &c->wsum[2], &c->big_list, &c->big_keys, &c->big_part, &c->glv_buf, &c->parts, &c->small, &c->endo_buf, &c->tile_counts,
+                      &c->wsum[0], &c->wsum[1], &c->wsum[2], &c->big_list[0], &c->big_list[1], &c->big_keys[0], &c->big_keys[1], &c->big_part[0], &c->big_part[1], &c->glv_buf, &c->parts, &c->small, &c->endo_buf, &c->tile_counts,
                       &c->sch_regs, &c->sch_in, &c->sch_scalars[0], &c->sch_scalars[1], &c->sch_bases[0], &c->sch_bases[1]};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);

@@ -31,13 +31,13 @@ def main():
     while time.time() < t_end:
         it += 1
         n = 1 + rng.next() % (1 << (1 + rng.next() % args.max_log2n))
-        c = 0 if rng.next() % 4 == 0 else 2 + rng.next() % 15
+        c = 0 if rng.next() % 4 == 0 else (16 if rng.next() % 3 == 0 else 2 + rng.next() % 15)   # 16: digit-major sort, 2-D reduction
         glv = (0, 1, -1)[rng.next() % 3]
         lpb = (0, 1, 2, 4, 8, 16)[rng.next() % 6]
         seg = (0, 1, 2, 8, 32)[rng.next() % 5]
         sub = (0, 4, 6, 9, 11)[rng.next() % 5]
-        tile = (0, 0, 256, 1024, -1, -2)[rng.next() % 6]
-        ovl = rng.next() % 3
+        tile = (0, 0, 0, 256, 1024, -1, -2, -3)[rng.next() % 8]
+        ovl = rng.next() % 4
         pat = rng.next() % 8
         idx = [rng.next() % pool_n for _ in range(n)]
         bases = bytearray(b"".join(pool[64 * i:64 * i + 64] for i in idx))

@@ -46,11 +46,12 @@ def main(prefix):
                       "the counter is uncalibrated. WRITE_SIZE matches 524288 buckets x 144 B = 75.5 MB + partial lines.",
         "valu_insts": insts, "duration_us": dur_us, "shader_clock_hz": clk_hz,
         "wave_instructions_per_mixed_add": insts / wave_adds,
-        "ideal_cpi": 3.76,
+        "ideal_cpi": 3.57,
         "ideal_cpi_note": "cycles per wave-instruction per SIMD if the VALU never stalled: the kernel's mix at the measured "
                           "issue rates (v_mad_u64_u32 / v_mul_lo_u32 / v_lshl_add_u64 / 64-bit shifts 4 cycles per wave64, "
-                          "32-bit add / and / cndmask 2; profiles/r01_ubench_instruction_rates.txt): 2 039 of 2 316 "
-                          "instructions per mixed addition are half rate",
+                          "32-bit add / and / cndmask 2; profiles/r01_ubench_instruction_rates.txt): 1 693 of 2 160 "
+                          "VALU instructions per mixed addition are half rate (1 467 multiply-adds, 144 64-bit shifts, 82 "
+                          "v_mul_lo) since the merges of partial sums went away (fp_mont_chain2)",
         "source": "%s_pmc_{fetch,write,sq}.txt (rocprofv3 --pmc, separate passes, per-dispatch average, summed over the 8 XCDs)"
                   % os.path.basename(prefix),
     }, indent=1))
