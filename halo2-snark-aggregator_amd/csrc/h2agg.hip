@@ -422,10 +422,14 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     TRY(ensure(c, c->order[sq], (size_t)p.NBT * 4));
     // digit-major sort (sort_kernels.cuh): plain 16-bit windows over one table, 2^16 .. 2^22 points
     static const bool dm_env_off = getenv("H2AGG_SORT") && !strcmp(getenv("H2AGG_SORT"), "packed");
-    const bool dm = !dm_env_off && !c->cfg_no_dm && !c->cfg_no_stage && !c->cfg_stage_l1 && !c->cfg_sub_bits && !c->cfg_tile && !p.glv && !pre && batch == 1 &&
-                    p.c == 16 && n >= ((size_t)1 << 16) && n <= ((size_t)1 << 22);
+    const size_t dm_row = p.glv ? 2 * n : n;   // keys per window (GLV: both halves of a scalar land in the same 8 windows)
+    const bool dm = !dm_env_off && !c->cfg_no_dm && !c->cfg_no_stage && !c->cfg_stage_l1 && !c->cfg_sub_bits && !c->cfg_tile && !pre && batch == 1 &&
+                    p.c == 16 && dm_row >= ((size_t)1 << 16) && dm_row <= ((size_t)1 << 22);
+    const uint32_t dm_nwin = p.glv ? 8u : 16u;
     DmPlan dp{};
     if (dm) {
+        const size_t n = dm_row;   // (shadows the point count inside this block)
+        dp.n_pts = p.glv ? (uint32_t)(dm_row / 2) : 0xffffffffu;
         dp.n = (uint32_t)n;
         dp.n_pad = (uint32_t)((n + 7) & ~(size_t)7);
         dp.ntile = (uint32_t)((n + DM_T1 - 1) / DM_T1);
@@ -437,8 +441,8 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         dp.SB = 1u << dp.sub_bits;
         dp.idx_bits = 31 - dp.sub_bits;
     }
-    TRY(ensure(c, c->item_idx, dm ? (size_t)16 * dp.n_row * 4 : nent * 4));
-    TRY(ensure(c, c->item_sub, dm ? (size_t)16 * dp.n_pad * 2 : nent * 2));
+    TRY(ensure(c, c->item_idx, dm ? (size_t)dm_nwin * dp.n_row * 4 : nent * 4));
+    TRY(ensure(c, c->item_sub, dm ? (size_t)dm_nwin * dp.n_pad * 2 : nent * 2));
     TRY(ensure(c, c->entries[sq], nent * 4));
     // buckets / segsum / wsum exist once per tail slot: in overlap mode the reduction of MSM k (tail stream)
     // runs while MSM k+1 fills the next slot's set.  (They were one allocation cut at par * this-plan's-size: two MSMs
@@ -477,7 +481,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     // per-tile partition counts from the counting pass, read back by the packed scatter pass (same tiles)
     uint32_t* tile_counts = nullptr;
     if (dm) {
-        TRY(ensure(c, c->tile_counts, (size_t)16 * dp.ntile * (dp.ppw + 1) * 4));
+        TRY(ensure(c, c->tile_counts, (size_t)dm_nwin * dp.ntile * (dp.ppw + 1) * 4));
         tile_counts = (uint32_t*)c->tile_counts.p;
     } else if (staged && !c->cfg_stage_l1) {
         TRY(ensure(c, c->tile_counts, (size_t)ntiles * sp.PW * 4));
@@ -509,22 +513,25 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         d_scalars = (const uint8_t*)c->glv_buf.p;
     }
     if (dm) {
-        const uint32_t PW = 16u * dp.ppw;
+        const uint32_t PW = dm_nwin * dp.ppw;
         {
             StageTimer t(c, ST_PART_COUNT);
             if (!meta_was_clean) HIP_TRY(c, hipMemsetAsync(meta, 0, M_WORDS * 4, st));
-            hipLaunchKernelGGL(k_dm_digits, dim3((unsigned)((n + BLOCK * DM_DIG_PER - 1) / (BLOCK * DM_DIG_PER))), dim3(BLOCK), 0, st, d_scalars, dp.n,
-                               dp.n_pad, item_sub, c->d_flags);
+            const unsigned dg = (unsigned)((n + BLOCK * DM_DIG_PER - 1) / (BLOCK * DM_DIG_PER));
+            if (p.glv)   // d_scalars: the decomposed words (range-checked by k_glv_decompose)
+                hipLaunchKernelGGL(k_dm_digits_glv, dim3(dg), dim3(BLOCK), 0, st, d_scalars, (uint32_t)n, dp.n_pad, item_sub);
+            else
+                hipLaunchKernelGGL(k_dm_digits, dim3(dg), dim3(BLOCK), 0, st, d_scalars, dp.n, dp.n_pad, item_sub, c->d_flags);
         }
         {
             StageTimer t(c, ST_PART_SCATTER);
-            hipLaunchKernelGGL(k_dm_partition, dim3(dp.ntile, 16), dim3(DM_TB1), 0, st, (const uint16_t*)item_sub, dp, pcount,
+            hipLaunchKernelGGL(k_dm_partition, dim3(dp.ntile, dm_nwin), dim3(DM_TB1), 0, st, (const uint16_t*)item_sub, dp, pcount,
                                tile_counts, item_idx);
                 hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)pcount, PW, pstart);
             }
         {
             StageTimer t(c, ST_BUCKET_SORT);
-            if (n / dp.ppw <= 4096)
+            if (dp.n / dp.ppw <= 4096)
                 hipLaunchKernelGGL(k_dm_bucket_sort<16>, dim3(PW), dim3(DM_TB2), 0, st, (const uint32_t*)pstart,
                                    (const uint32_t*)tile_counts, (const uint32_t*)item_idx, dp, p.NB, hist, offs, entries);
             else

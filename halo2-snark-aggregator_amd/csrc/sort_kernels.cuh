@@ -707,6 +707,8 @@ struct DmPlan {
     int sub_bits;          // low bucket bits resolved in level 2
     uint32_t SB, ppw;      // buckets per partition, partitions per window
     int idx_bits;          // 31 - sub_bits: item = sub | neg | idx
+    uint32_t n_pts;        // GLV: a row holds the keys of both halves, idx >= n_pts = second half (endo) of point idx - n_pts;
+                           // otherwise 0xffffffff
 };
 
 // codes[w * n_pad + i] = signed 16-bit digit w of scalar i (c = 16, W = 16; r < 2^254: no carry out of the top window)
@@ -736,6 +738,39 @@ __global__ void __launch_bounds__(BLOCK) k_dm_digits(const uint8_t* __restrict__
         }
     }
     if (bad) atomicOr(flags, FLAG_NONCANONICAL);
+}
+
+// GLV: `words` are glv_decompose() outputs (two sign-magnitude 127-bit halves).  Both halves are recoded over the same 8
+// windows; row w holds the first halves' digits at [0, n) and the second halves' at [n, 2n).
+__global__ void __launch_bounds__(BLOCK) k_dm_digits_glv(const uint8_t* __restrict__ words, uint32_t n, uint32_t n_pad,
+                                                         uint16_t* __restrict__ codes) {
+    const uint32_t i0 = blockIdx.x * (BLOCK * DM_DIG_PER) + threadIdx.x;
+#pragma unroll 1
+    for (int k = 0; k < DM_DIG_PER; ++k) {
+        const uint32_t i = i0 + k * BLOCK;
+        if (i >= n) break;
+        const U256 s = u256_load(words + 32 * (size_t)i);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t sgn = s.w[4 * h + 3] >> 31;
+            uint32_t carry = 0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) {
+                uint32_t hw = (s.w[4 * h + (w >> 1)] >> (16 * (w & 1))) & 0xffffu;
+                if (w == 7) hw &= 0x7fffu;   // bit 127 is the sign
+                const uint32_t raw = hw + carry;
+                // digits of a half lie in [-(2^15 - 1), 2^15]; a negative half flips them to [-2^15, 2^15 - 1], and -2^15
+                // has no 16-bit code.  Recoding a negative half with the mirrored threshold (raw 2^15 -> digit -2^15, carry)
+                // keeps its flipped digits in [-(2^15 - 1), 2^15] as well.  |k_i| < 2^126.4: no carry out of window 7.
+                const bool big = raw > (sgn ? 0x7fffu : 0x8000u);
+                carry = big ? 1u : 0u;
+                const uint32_t mag = big ? 0x10000u - raw : raw;            // 0 .. 0x8000
+                const uint32_t neg = (big ? 1u : 0u) ^ sgn;
+                const uint32_t code = mag == 0 ? DM_ZERO : (neg ? (0x8000u | (mag & 0x7fffu)) : mag - 1u);
+                codes[(size_t)w * n_pad + (size_t)h * n + i] = (uint16_t)code;
+            }
+        }
+    }
 }
 
 // exclusive scan of v[0..cnt) (cnt <= 512) in LDS, total -> v[cnt]: ONE wave does it (8 values per lane + a 6-step wave
@@ -858,6 +893,17 @@ __global__ void __launch_bounds__(DM_TB1) k_dm_partition(const uint16_t* __restr
         *reinterpret_cast<uint4*>(out + k) = *reinterpret_cast<const uint4*>(stage + k);
 }
 
+// item -> bucket entry: point index | ENT_NEG | ENT_ENDO (GLV rows: positions >= n_pts are second halves)
+FP_INLINE uint32_t dm_entry(uint32_t it, const DmPlan& dp, uint32_t idxmask) {
+    uint32_t idx = it & idxmask;
+    uint32_t e = ((it >> dp.idx_bits) & 1u) << 31;
+    if (idx >= dp.n_pts) {
+        idx -= dp.n_pts;
+        e |= ENT_ENDO;
+    }
+    return e | idx;
+}
+
 // level 2, one workgroup per partition (w, pl).  Key k of the partition (k < total) lives in tile t with
 // rpre[t] <= k < rpre[t + 1]; runs are nearly equal, so t is guessed from k and corrected by a step or two.
 template <int PER>
@@ -914,7 +960,7 @@ __global__ void __launch_bounds__(DM_TB2) k_dm_bucket_sort(const uint32_t* __res
 #pragma unroll
         for (int j = 0; j < PER; ++j) {
             const uint32_t k = tid + j * TB;
-            if (k < total) stage[h[it[j] >> sh] + rk[j]] = (it[j] & idxmask) | (((it[j] >> dp.idx_bits) & 1u) << 31);
+            if (k < total) stage[h[it[j] >> sh] + rk[j]] = dm_entry(it[j], dp, idxmask);
         }
         __syncthreads();
         for (uint32_t k = tid; k < total; k += TB) entries[start + k] = stage[k];
@@ -929,7 +975,7 @@ __global__ void __launch_bounds__(DM_TB2) k_dm_bucket_sort(const uint32_t* __res
     __syncthreads();
     for (uint32_t k = tid; k < total; k += TB) {
         const uint32_t v = *locate(k);
-        entries[start + atomicAdd(&h[v >> sh], 1u)] = (v & idxmask) | (((v >> dp.idx_bits) & 1u) << 31);
+        entries[start + atomicAdd(&h[v >> sh], 1u)] = dm_entry(v, dp, idxmask);
     }
 }
 

@@ -30,14 +30,15 @@ def _run(eng, ks, ss):
     table = eng.bases_generate(d_k.data_ptr(), n)
     want = O.aff_to_bytes(O.scalar_mul(sum(k * s for k, s in zip(ks, ss)) % R, O.G1))
     try:
-        eng.msm_configure_glv(-1)
         eng.msm_configure(16, 0, 0)
-        got = {}
-        for name, tile in (("digit-major", 0), ("packed", -3)):
-            eng.msm_configure_sort(0, tile)
-            got[name] = eng.g1_batch_to_affine(eng.g1_msm_device(table, d_s.data_ptr(), n))
-        assert got["digit-major"] == want
-        assert got["packed"] == want
+        for glv in (-1, 1):   # 16 windows of n keys / 8 windows of 2n keys (both halves of the endomorphism split)
+            eng.msm_configure_glv(glv)
+            got = {}
+            for name, tile in (("digit-major", 0), ("packed", -3)):
+                eng.msm_configure_sort(0, tile)
+                got[name] = eng.g1_batch_to_affine(eng.g1_msm_device(table, d_s.data_ptr(), n))
+            assert got["digit-major"] == want, glv
+            assert got["packed"] == want, glv
     finally:
         eng.msm_configure_sort(0, 0)
         eng.msm_configure(0, 0, 0)
@@ -68,6 +69,17 @@ def test_structured_scalars(eng):
     _run(eng, ks, [R - 1] * n)
     _run(eng, ks, [0x1234_5678_9abc_def0_1111_2222_3333_4444_5555_6666_7777_8888_9999_aaaa_bbbb % R] * n)
     _run(eng, ks, [0] * n)
+    # endomorphism split: scalars k1 + lambda * k2 with halves full of 0x8000 / 0x7fff / 0xffff digits, both signs
+    lam = 0x30644e72e131a029048b6e193fd84104cc37a73fec2bc5e9b8ca0b2d36636f23
+    halves = [sum(0x8000 << (16 * w) for w in range(7)), sum(0x7fff << (16 * w) for w in range(7)),
+              sum(0xffff << (16 * w) for w in range(7)), (1 << 112) - 1, 1 << 111, 0x8000, 0x7fff, 0x18000]
+    glv = []
+    for a in halves:
+        for b in halves:
+            for sa in (1, -1):
+                for sb in (1, -1):
+                    glv.append((sa * a + sb * b * lam) % R)
+    _run(eng, ks, [glv[i % len(glv)] for i in range(n)])
 
 
 def test_skewed_partitions(eng):
