@@ -160,6 +160,31 @@ FP_INLINE void xyzz_add_affine(G1XYZZ& acc, const G1Affine& q) {
 #endif
 }
 
+// a + q for two AFFINE points (mmadd-2008-s, 4M + 2S against the 8M + 2S of a mixed addition): the second point that
+// lands in a bucket.  Neither operand is the identity.
+FP_INLINE G1XYZZ xyzz_add_affine_affine(const G1Affine& a, const G1Affine& q) {
+    Fq p = FQ_SUB(2, q.x, a.x);                         // [4]
+    Fq r = FQ_SUB(2, q.y, a.y);                         // [4]
+    if (fp_maybe_zero_mod<4, FqParams>(p)) {
+        if (fp_is_zero_mod<4, FqParams>(p)) {
+            if (fp_is_zero_mod<4, FqParams>(r)) return xyzz_double_affine(q);
+            return G1XYZZ::identity();
+        }
+    }
+    fq_fence(p);
+    fq_fence(r);
+    G1XYZZ o;
+    Fq pp, rr, ppp, qq;
+    fp_sqr_dual<FqParams>(p, r, pp, rr);                // 16 -> [2], [2]
+    fp_mul_dual<FqParams>(p, pp, a.x, pp, ppp, qq);     // [2], [2]
+    o.x = fp_sub_sub2<6, FqParams>(rr, ppp, qq);        // [8]
+    // R*(Q - X3 + 8p) + (2p - Y1)*PPP: (4*10 + 2*2)/169 + 1 -> [2]
+    o.y = fp_mul2<FqParams>(r, FQ_SUB(8, qq, o.x), fp_neg<2, FqParams>(a.y), ppp);
+    o.zz = pp;
+    o.zzz = ppp;
+    return o;
+}
+
 // a + b, add-2008-s, complete.
 FP_INLINE G1XYZZ xyzz_add(const G1XYZZ& a, const G1XYZZ& b) {
     if (a.is_identity()) return b;

@@ -122,9 +122,29 @@ __global__ void __launch_bounds__(BLOCK) k_msm_accumulate(const uint8_t* __restr
     const uint32_t lo = (uint32_t)(((uint64_t)len * part) / lpb), hi = (uint32_t)(((uint64_t)len * (part + 1)) / lpb);
     const uint32_t* run = entries + offs[key];
     G1XYZZ acc = G1XYZZ::identity();
-    if (hi > lo) {
+    uint32_t k0 = lo;
+    // The first point of a bucket is a copy and the second an affine + affine addition (4M + 2S): both outside the loop,
+    // which then only ever sees the 8M + 2S mixed addition.  (Identity bases are skipped; a lane that meets some simply
+    // enters the loop at its own k0.)
+    G1Affine first;
+    bool have_first = false;
+    while (k0 < hi && !have_first) {
+        first = msm_gather(bases, endo_x, run[k0++]);
+        have_first = !first.is_identity();
+    }
+    if (have_first) {
+        acc = G1XYZZ::from_affine(first);
+        while (k0 < hi) {
+            const G1Affine q = msm_gather(bases, endo_x, run[k0++]);
+            if (q.is_identity()) continue;
+            acc = xyzz_add_affine_affine(first, q);
+            break;
+        }
+    }
+    if (hi > k0) {
         // two-deep software pipeline: the base of entry k + 1 is gathered, and the INDEX of entry k + 2 loaded, under the
         // addition of entry k — the index load used to sit in front of its gather with a full `s_waitcnt vmcnt(0)`
+        const uint32_t lo = k0;
         G1Affine nxt = msm_gather(bases, endo_x, run[lo]);
         uint32_t e_after = lo + 1 < hi ? run[lo + 1] : 0u;
 #pragma unroll 1
