@@ -132,15 +132,14 @@ __global__ void __launch_bounds__(BLOCK) k_msm_accumulate(const uint8_t* __restr
         first = msm_gather(bases, endo_x, run[k0++]);
         have_first = !first.is_identity();
     }
-    if (have_first) {
-        acc = G1XYZZ::from_affine(first);
-        while (k0 < hi) {
-            const G1Affine q = msm_gather(bases, endo_x, run[k0++]);
-            if (q.is_identity()) continue;
-            acc = xyzz_add_affine_affine(first, q);
-            break;
-        }
+    G1Affine second;
+    bool have_second = false;
+    while (have_first && k0 < hi && !have_second) {
+        second = msm_gather(bases, endo_x, run[k0++]);
+        have_second = !second.is_identity();
     }
+    if (have_second) acc = xyzz_add_affine_affine(first, second);
+    else if (have_first) acc = G1XYZZ::from_affine(first);
     if (hi > k0) {
         // two-deep software pipeline: the base of entry k + 1 is gathered, and the INDEX of entry k + 2 loaded, under the
         // addition of entry k — the index load used to sit in front of its gather with a full `s_waitcnt vmcnt(0)`
