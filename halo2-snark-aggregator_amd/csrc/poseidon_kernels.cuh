@@ -67,11 +67,13 @@ FP_INLINE Fr psd_shl(const Fr& v) {
     for (int k = 0; k < NL; ++k) r.l[k] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v.l[k], 0x100 + N, 0xF, 0xF, true);
     return r;
 }
+// Inputs < 2r on at most nine lanes (zero elsewhere); the sum is left unfolded, < 18r: it is only ever an operand of the next
+// round's multiplications (18 * 18 / 169 + 1 < 3), and every fold on this chain is ~30 instructions of a lone wave's time.
 FP_INLINE Fr psd_row_sum(Fr t) {
-    t = fr_add2r(t, psd_shl<1>(t));
-    t = fr_add2r(t, psd_shl<2>(t));
-    t = fr_add2r(t, psd_shl<4>(t));
-    return fr_add2r(t, psd_shl<8>(t));
+    t = fp_add<FrParams>(t, psd_shl<1>(t));
+    t = fp_add<FrParams>(t, psd_shl<2>(t));
+    t = fp_add<FrParams>(t, psd_shl<4>(t));
+    return fp_add<FrParams>(t, psd_shl<8>(t));
 }
 // s <- M s for a dense T x T matrix at spec[base ..]: every lane publishes its word, then forms its row's dot product as
 // three 3-term products with one Montgomery reduction each (fp_mul3)
@@ -104,6 +106,10 @@ FP_INLINE Fr psd_permute(const uint32_t* __restrict__ spec, PsdLds& x, int g, in
     s = fr_pow5_plus(s, reg_load(spec, PSD_START + PSD_H * PSD_T + lc));
     s = psd_dense(spec, PSD_PRE, x, g, l, lc, s);
     if (l >= PSD_T) s = Fr::zero();   // idle lanes carry zeros: they take part in the row sums below
+    // this round's constants were loaded during the previous round (three L2 round trips per round sat on the chain otherwise)
+    Fr rowl = reg_load(spec, PSD_SROW + lc);
+    Fr pck = reg_load(spec, PSD_PARTIAL);
+    Fr colk = reg_load(spec, PSD_SCOL + (lc ? lc - 1 : 0));
 #pragma unroll 1
     for (int k = 0; k < PSD_RP; ++k) {
         // sbox_part (only s[0]) + apply_sparse_mds: s0' = row . s, s_i' = col_hat[i-1] * s0 + s_i, s0 = the value AFTER the
@@ -111,15 +117,18 @@ FP_INLINE Fr psd_permute(const uint32_t* __restrict__ spec, PsdLds& x, int g, in
         //   1: lane 0: s0^2            lanes >= 1: u_i = row[i] * s_i     (independent of the S-box)
         //   2: lane 0: s0^4    3: lane 0: s0^5 (+ c)
         //   4: lane 0: row[0] * s0'    lanes >= 1: col_hat[i-1] * s0'
-        const Fr rowl = reg_load(spec, PSD_SROW + k * PSD_T + lc);
+        const int kn = k + 1 < PSD_RP ? k + 1 : k;
+        const Fr rowl_n = reg_load(spec, PSD_SROW + kn * PSD_T + lc);
+        const Fr pck_n = reg_load(spec, PSD_PARTIAL + kn);
+        const Fr colk_n = reg_load(spec, PSD_SCOL + kn * (PSD_T - 1) + (lc ? lc - 1 : 0));
         Fr b1;
 #pragma unroll
         for (int i = 0; i < NL; ++i) b1.l[i] = (l == 0) ? s.l[i] : rowl.l[i];
         const Fr p1 = fp_mul<FrParams>(s, b1);                                  // lane 0: s^2; others: u_i
         const Fr x4 = fp_sqr<FrParams>(p1);                                     // lane 0: s^4
-        const Fr sb = fr_add2r(fp_mul<FrParams>(x4, s), reg_load(spec, PSD_PARTIAL + k));   // lane 0: s^5 + c
+        const Fr sb = fr_add2r(fp_mul<FrParams>(x4, s), pck);   // lane 0: s^5 + c
         const Fr s0 = psd_bcast0(sb);
-        const Fr coef = (l == 0) ? rowl : reg_load(spec, PSD_SCOL + k * (PSD_T - 1) + (lc ? lc - 1 : 0));
+        const Fr coef = (l == 0) ? rowl : colk;
         const Fr v = fp_mul<FrParams>(coef, s0);
         // lane 0: row[0] * s0' + sum_{i >= 1} u_i ; lanes 1..8: v + s_i ; idle lanes stay zero
         Fr t;
@@ -129,6 +138,9 @@ FP_INLINE Fr psd_permute(const uint32_t* __restrict__ spec, PsdLds& x, int g, in
         const Fr upd = fr_add2r(v, s);
 #pragma unroll
         for (int i = 0; i < NL; ++i) s.l[i] = (l == 0) ? sum.l[i] : (l < PSD_T ? upd.l[i] : 0u);
+        rowl = rowl_n;
+        pck = pck_n;
+        colk = colk_n;
     }
 #pragma unroll 1
     for (int k = 0; k < PSD_H - 1; ++k) {
