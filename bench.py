@@ -107,6 +107,10 @@ def pmc_evidence(stage_name: str, log2n: int):
     valu = {"wave_instructions_per_launch": t["valu_insts"], "shader_clock_ghz": t["shader_clock_hz"] / 1e9, "simds": simds,
             "pmc_run_kernel_ms": t["duration_us"] / 1e3, "cycles_per_instruction_per_simd": cpi,
             "ideal_cycles_per_instruction": t["ideal_cpi"], "issue_frac": t["ideal_cpi"] / cpi,
+            # the same with the issue rates MEASURED on this part (tools/ubench_chain.hip: a v_mad_u64_u32 occupies a SIMD for
+            # ~5 cycles at even wave counts, not the nominal 4): what the instruction stream can reach at all
+            "measured_rate_cycles_per_instruction": t.get("measured_rate_cpi"),
+            "issue_frac_at_measured_rates": (t["measured_rate_cpi"] / cpi) if t.get("measured_rate_cpi") else None,
             "source": "profiles/r02_traffic.json (rocprofv3 --pmc passes of this command; instruction count, clock AND "
                       "duration from the same pass)"}
     return t["bytes_per_launch"], valu, "csrc_sha " + t["csrc_sha"]

@@ -47,6 +47,9 @@ def main(prefix):
         "valu_insts": insts, "duration_us": dur_us, "shader_clock_hz": clk_hz,
         "wave_instructions_per_mixed_add": insts / wave_adds,
         "ideal_cpi": 3.57,
+        "measured_rate_cpi": 4.25,
+        "measured_rate_note": "the same mix with the multiply-add at the ~5 cycles per wave64 it takes on this part at even "
+                              "wave counts (tools/ubench_chain.hip, profiles/r02_sweeps.txt): (1 467 x 5 + 226 x 4 + 467 x 2) / 2 160",
         "ideal_cpi_note": "cycles per wave-instruction per SIMD if the VALU never stalled: the kernel's mix at the measured "
                           "issue rates (v_mad_u64_u32 / v_mul_lo_u32 / v_lshl_add_u64 / 64-bit shifts 4 cycles per wave64, "
                           "32-bit add / and / cndmask 2; profiles/r01_ubench_instruction_rates.txt): 1 693 of 2 160 "
