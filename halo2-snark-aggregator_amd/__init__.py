@@ -82,6 +82,7 @@ def load_library():
         "h2agg_g1_batch_decompress": (i32, [ctxp, u8p, sz, vp, vp]),
         "h2agg_g1_batch_compress": (i32, [ctxp, u8p, sz, vp]),
         "h2agg_g1_msm": (i32, [ctxp, vp, vp, sz, vp]),
+        "h2agg_g1_msm_jac": (i32, [ctxp, vp, vp, sz, vp]),
         "h2agg_host_alloc": (i32, [ctxp, sz, C.POINTER(vp)]),
         "h2agg_host_free": (i32, [ctxp, vp]),
         "h2agg_eval_flat": (i32, [ctxp, u8p, u8p, u8p, sz, vp]),
@@ -326,6 +327,15 @@ class H2Agg:
         pb = C.cast(bases_aff, C.c_void_p) if isinstance(bases_aff, (bytes, bytearray)) else C.c_void_p(bases_aff)
         ps = C.cast(scalars, C.c_void_p) if isinstance(scalars, (bytes, bytearray)) else C.c_void_p(scalars)
         self._check(self._lib.h2agg_g1_msm(self._ctx, pb, ps, n, out))
+        return out.raw
+
+    def g1_msm_jac(self, points_jac: bytes, scalars: bytes) -> bytes:
+        """multi_exp over projective points (x || y || z, 96 B each): normalised on the device"""
+        n = len(scalars) // 32
+        _need(scalars, 32 * n, "scalars")
+        _need(points_jac, 96 * n, "points_jac")
+        out = C.create_string_buffer(96)
+        self._check(self._lib.h2agg_g1_msm_jac(self._ctx, C.cast(points_jac, C.c_void_p), C.cast(scalars, C.c_void_p), n, out))
         return out.raw
 
     def host_alloc(self, nbytes: int) -> int:

@@ -291,8 +291,10 @@ FP_INLINE G1Affine affine_from_xyzz(const G1XYZZ& p) {
 // TA_K of its points with Montgomery's trick (prefix products of the z's kept in registers, points re-read on the way
 // back: the kernel is far from bandwidth-bound): 2.8 ms -> see profiles/r02_final_batch_roofline.txt for 2^22 points.
 constexpr int TA_K = 8;
-__global__ void __launch_bounds__(BLOCK) k_g1_batch_to_affine(const uint8_t* __restrict__ in, size_t n,
-                                                              uint8_t* __restrict__ out, uint32_t* flags) {
+// MONT = false: canonical affine out (the C ABI's to_affine); true: Montgomery affine out, the form of a base table —
+// h2agg_g1_msm_jac normalises the caller's projective points on the device instead of asking for batch_normalize on the host
+template <bool MONT>
+FP_INLINE void jac_batch_normalise(const uint8_t* __restrict__ in, size_t n, uint8_t* __restrict__ out, uint32_t* flags) {
     const size_t stride = (size_t)gridDim.x * BLOCK;
     for (size_t i0 = (size_t)blockIdx.x * BLOCK + threadIdx.x; i0 < n; i0 += stride * TA_K) {
         // points i0, i0 + stride, ... (consecutive lanes touch consecutive points in every step)
@@ -326,13 +328,25 @@ __global__ void __launch_bounds__(BLOCK) k_g1_batch_to_affine(const uint8_t* __r
                 const Fq zi2 = FQ_SQR(zi);
                 const Fq x = fp_to_mont<FqParams>(fp_load<FqParams>(in + 96 * i));
                 const Fq y = fp_to_mont<FqParams>(fp_load<FqParams>(in + 96 * i + 32));
-                ox = fp_from_mont<FqParams>(FQ_MUL(x, zi2));               // x / z^2
-                oy = fp_from_mont<FqParams>(FQ_MUL(y, FQ_MUL(zi2, zi)));   // y / z^3
+                ox = FQ_MUL(x, zi2);                                        // x / z^2
+                oy = FQ_MUL(y, FQ_MUL(zi2, zi));                            // y / z^3
+                if (!MONT) {
+                    ox = fp_from_mont<FqParams>(ox);
+                    oy = fp_from_mont<FqParams>(oy);
+                }
             }
             fp_store<FqParams>(out + 64 * i, ox);
             fp_store<FqParams>(out + 64 * i + 32, oy);
         }
     }
+}
+__global__ void __launch_bounds__(BLOCK) k_g1_batch_to_affine(const uint8_t* __restrict__ in, size_t n,
+                                                              uint8_t* __restrict__ out, uint32_t* flags) {
+    jac_batch_normalise<false>(in, n, out, flags);
+}
+__global__ void __launch_bounds__(BLOCK) k_jac_to_mont_affine(const uint8_t* __restrict__ in, size_t n,
+                                                              uint8_t* __restrict__ out, uint32_t* flags) {
+    jac_batch_normalise<true>(in, n, out, flags);
 }
 
 // ------------------------------------------------------------------ proof wire format of a G1 point

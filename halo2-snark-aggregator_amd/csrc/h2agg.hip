@@ -1445,13 +1445,36 @@ int h2agg_host_free(h2agg_ctx* c, void* p) try {
     return H2AGG_ERR_INVALID;
 }
 
+}   // extern "C"
+namespace {
+// h2agg_g1_msm / h2agg_g1_msm_jac: host buffers in.  stride = 64: canonical affine bases; 96: canonical Jacobian points,
+// normalised on the device (k_jac_to_mont_affine) where the affine entry point converts to Montgomery form (k_bases_to_mont)
+int msm_host(h2agg_ctx* c, const uint8_t* bases, size_t stride, const uint8_t* scalars, size_t n, uint8_t out[96]);
+}
+extern "C" {
 int h2agg_g1_msm(h2agg_ctx* c, const uint8_t* bases, const uint8_t* scalars, size_t n, uint8_t out[96]) try {
+    return msm_host(c, bases, 64, scalars, n, out);
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
+}
+int h2agg_g1_msm_jac(h2agg_ctx* c, const uint8_t* points_jac, const uint8_t* scalars, size_t n, uint8_t out[96]) try {
+    return msm_host(c, points_jac, 96, scalars, n, out);
+} catch (const std::bad_alloc&) {
+    return H2AGG_ERR_NOMEM;
+} catch (...) {
+    return H2AGG_ERR_INVALID;
+}
+}   // extern "C"
+namespace {
+int msm_host(h2agg_ctx* c, const uint8_t* bases, size_t stride, const uint8_t* scalars, size_t n, uint8_t out[96]) {
     TRY(bind(c));
     if (!out) return fail(c, H2AGG_ERR_INVALID, "null buffer");
     set_identity_jac(out);
     if (n == 0) return fail(c, H2AGG_ERR_EMPTY, "multi_exp of zero pairs (reference panics: mock/arith/ecc.rs:128)");
     if (!bases || !scalars) return fail(c, H2AGG_ERR_INVALID, "null buffer");
-    TRY(ensure(c, c->in_a, 64 * n));
+    TRY(ensure(c, c->in_a, stride * n));
     TRY(ensure(c, c->in_b, 32 * n));
     TRY(ensure(c, c->tmp_bases, 64 * n));
     TRY(clear_flags(c));
@@ -1462,10 +1485,14 @@ int h2agg_g1_msm(h2agg_ctx* c, const uint8_t* bases, const uint8_t* scalars, siz
     size_t nslices = n / MIN_SLICE;
     if (nslices > MSM_MAX_SLICES) nslices = MSM_MAX_SLICES;
     if (nslices < 2) {
-        HIP_TRY(c, hipMemcpyAsync(c->in_a.p, bases, 64 * n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipMemcpyAsync(c->in_a.p, bases, stride * n, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->in_b.p, scalars, 32 * n, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_bases_to_mont, dim3(grid_for(c, n)), dim3(BLOCK), 0, c->stream, (const uint8_t*)c->in_a.p, n,
-                           (uint8_t*)c->tmp_bases.p, c->d_flags);
+        if (stride == 96)
+            hipLaunchKernelGGL(k_jac_to_mont_affine, dim3(grid_for(c, (n + TA_K - 1) / TA_K)), dim3(BLOCK), 0, c->stream,
+                               (const uint8_t*)c->in_a.p, n, (uint8_t*)c->tmp_bases.p, c->d_flags);
+        else
+            hipLaunchKernelGGL(k_bases_to_mont, dim3(grid_for(c, n)), dim3(BLOCK), 0, c->stream, (const uint8_t*)c->in_a.p, n,
+                               (uint8_t*)c->tmp_bases.p, c->d_flags);
         TRY(msm_run(c, (const uint8_t*)c->tmp_bases.p, (const uint8_t*)c->in_b.p, n, c->d_res_jac));
         return fetch_result_jac(c, out);
     }
@@ -1490,7 +1517,7 @@ int h2agg_g1_msm(h2agg_ctx* c, const uint8_t* bases, const uint8_t* scalars, siz
         hipError_t e = hipMemcpyAsync((uint8_t*)c->in_b.p + 32 * done, scalars + 32 * done, 32 * m, hipMemcpyHostToDevice,
                                       c->copy_stream);
         if (e == hipSuccess)
-            e = hipMemcpyAsync((uint8_t*)c->in_a.p + 64 * done, bases + 64 * done, 64 * m, hipMemcpyHostToDevice,
+            e = hipMemcpyAsync((uint8_t*)c->in_a.p + stride * done, bases + stride * done, stride * m, hipMemcpyHostToDevice,
                                c->copy_stream);
         if (e == hipSuccess) e = hipEventRecord(c->ev_copy[k], c->copy_stream);
         if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_copy[k], 0);
@@ -1498,8 +1525,12 @@ int h2agg_g1_msm(h2agg_ctx* c, const uint8_t* bases, const uint8_t* scalars, siz
             rc = fail(c, H2AGG_ERR_HIP, hipGetErrorString(e));
             break;
         }
-        hipLaunchKernelGGL(k_bases_to_mont, dim3(grid_for(c, m)), dim3(BLOCK), 0, c->stream,
-                           (const uint8_t*)c->in_a.p + 64 * done, m, (uint8_t*)c->tmp_bases.p + 64 * done, c->d_flags);
+        if (stride == 96)
+            hipLaunchKernelGGL(k_jac_to_mont_affine, dim3(grid_for(c, (m + TA_K - 1) / TA_K)), dim3(BLOCK), 0, c->stream,
+                               (const uint8_t*)c->in_a.p + 96 * done, m, (uint8_t*)c->tmp_bases.p + 64 * done, c->d_flags);
+        else
+            hipLaunchKernelGGL(k_bases_to_mont, dim3(grid_for(c, m)), dim3(BLOCK), 0, c->stream,
+                               (const uint8_t*)c->in_a.p + 64 * done, m, (uint8_t*)c->tmp_bases.p + 64 * done, c->d_flags);
         rc = msm_run(c, (const uint8_t*)c->tmp_bases.p + 64 * done, (const uint8_t*)c->in_b.p + 32 * done, m,
                      (uint8_t*)c->out.p + 96 * k);
     }
@@ -1509,11 +1540,9 @@ int h2agg_g1_msm(h2agg_ctx* c, const uint8_t* bases, const uint8_t* scalars, siz
     TRY(join_tails(c));
     hipLaunchKernelGGL(k_g1_sum, dim3(1), dim3(BLOCK), 0, c->stream, (const uint8_t*)c->out.p, k, c->d_res_jac, c->d_flags);
     return fetch_result_jac(c, out);
-} catch (const std::bad_alloc&) {
-    return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
-} catch (...) {
-    return H2AGG_ERR_INVALID;
 }
+}   // namespace
+extern "C" {
 
 int h2agg_eval_flat(h2agg_ctx* c, const uint8_t* pts, const uint8_t* scalars, const uint8_t* has_scalar, size_t n,
                     uint8_t out[96]) try {

@@ -129,6 +129,11 @@ int h2agg_host_free(h2agg_ctx* ctx, void* p);
  * output buffer is then set to the identity so a caller that prefers "empty sum = identity" can
  * ignore that one status. */
 int h2agg_g1_msm(h2agg_ctx* ctx, const uint8_t* bases_aff, const uint8_t* scalars, size_t n, uint8_t out_jac[96]);
+/* The same with the points as the trait hands them over: `Vec<C::CurveExt>`, projective (x || y || z, 96 B each, canonical;
+ * z = 0: identity).  They are normalised on the device (one inversion per 8 points per lane), so the binding does not
+ * have to run `batch_normalize` over a million points on one host core first (mock/arith/ecc.rs:106-129 takes
+ * `points: Vec<Self::AssignedPoint>` = `C::CurveExt`); 128 instead of 96 bytes per point cross PCIe. */
+int h2agg_g1_msm_jac(h2agg_ctx* ctx, const uint8_t* points_jac, const uint8_t* scalars, size_t n, uint8_t out_jac[96]);
 
 /* replaces: eval()'s flat tail — multi_exp over the entries that carry a scalar, then `pchip.add` of
  * every scalar-less point (halo2-snark-aggregator-api/src/systems/halo2/evaluation.rs:189-200).

@@ -380,3 +380,30 @@ def test_fr_tape_eval(eng, pkg):
         eng.fr_tape_eval(fr_bytes([1, 2]), [(0, 0, 1)], [3])               # output out of range
     with pytest.raises(pkg.H2AggError):
         eng.fr_tape_eval(O.R.to_bytes(32, "little"), [], [0])              # non-canonical input
+
+
+def test_msm_over_projective_points(eng):
+    """h2agg_g1_msm_jac: the points as `Vec<C::CurveExt>` (projective, arbitrary z, some identities) normalised on the
+    device; same bytes as normalising first and calling h2agg_g1_msm, and as the oracle's naive multi_exp"""
+    from oracle import bn254 as O, cref
+    rng = O.SplitMix64(0x1AC)
+    for n in (1, 7, 300, 5000):
+        ks = [rng.fr() for _ in range(n)]
+        aff = cref.g1_batch_to_affine(cref.g1_batch_scalar_mul(O.aff_to_bytes(O.G1) * n, b"".join(O.fe_to_bytes(k) for k in ks), n), n)
+        jac = bytearray()
+        for i in range(n):
+            x = int.from_bytes(aff[64 * i:64 * i + 32], "little")
+            y = int.from_bytes(aff[64 * i + 32:64 * i + 64], "little")
+            if i % 11 == 5:
+                jac += (0).to_bytes(32, "little") + (1).to_bytes(32, "little") + (0).to_bytes(32, "little")   # identity
+                aff = aff[:64 * i] + bytes(64) + aff[64 * i + 64:]
+                continue
+            z = 1 if i % 3 == 0 else rng.next() % O.P or 1
+            jac += (x * z * z % O.P).to_bytes(32, "little") + (y * z * z * z % O.P).to_bytes(32, "little") + z.to_bytes(32, "little")
+        sc = b"".join(O.fe_to_bytes(rng.fr()) for _ in range(n))
+        got = eng.g1_batch_to_affine(eng.g1_msm_jac(bytes(jac), sc))
+        assert got == eng.g1_batch_to_affine(eng.g1_msm(aff, sc))
+        assert got == cref.multi_exp_naive(aff, sc, n)
+    import pytest
+    with pytest.raises(Exception):
+        eng.g1_msm_jac(b"", b"")
