@@ -308,7 +308,45 @@ struct Spec {
         sparse_row.assign(rows.rbegin(), rows.rend());
         sparse_col.assign(cols.rbegin(), cols.rend());
         pre_sparse = acc_m;
-        ok = true;
+        ok = scale_partial_rounds();
+    }
+
+    // The partial rounds with one multiplication less on the S-box lane (csrc/poseidon_kernels.cuh).  A partial round is
+    //     s0' = s0^5 + c_k,   s0 <- row_0 s0' + sum_{i>=1} row_i s_i,   s_i <- s_i + col_i s0'.
+    // Track w with s0 = beta_k w (beta_0 = 1) and z = w^5, and the other words without their constant parts,
+    // s_i = shat_i + cum_{k,i}.  Then, with b5 = beta_k^5 and beta_{k+1} = row_0 b5,
+    //     shat_i <- shat_i + A_{k,i} z            A_{k,i} = col_i b5          cum_{k+1,i} = cum_{k,i} + col_i c_k
+    //     w      <- z + D_k + sum_i R_{k,i} shat_i  R_{k,i} = row_i / beta_{k+1}   D_k = c_k / b5 + sum_i R_{k,i} cum_{k,i}
+    // — exact field identities; the row's multiplication by row_0 after the S-box is gone from the chain, and the lanes'
+    // A z product of round k shares an issue slot with the S-box lane's first squaring of round k + 1.
+    Mat ps_a, ps_r;                 // [r_p][t - 1]
+    std::vector<HFr> ps_d;          // [r_p]
+    std::vector<HFr> ps_fin;        // [t]: beta_{r_p}, cum_{r_p, 1..t-1}
+    bool scale_partial_rounds() {
+        HFr beta = one();
+        std::vector<HFr> cum(t - 1, zero());
+        ps_a.assign(r_p, std::vector<HFr>(t - 1));
+        ps_r.assign(r_p, std::vector<HFr>(t - 1));
+        ps_d.assign(r_p, zero());
+        for (int k = 0; k < r_p; ++k) {
+            const HFr b2 = mul(beta, beta), b4 = mul(b2, b2), b5 = mul(b4, beta);
+            const HFr beta_n = mul(sparse_row[k][0], b5);
+            if (is_zero(beta_n)) return false;
+            const HFr ib = inv(beta_n);
+            HFr d = mul(partial[k], inv(b5));
+            for (int i = 0; i < t - 1; ++i) {
+                ps_a[k][i] = mul(sparse_col[k][i], b5);
+                ps_r[k][i] = mul(sparse_row[k][i + 1], ib);
+                d = add(d, mul(ps_r[k][i], cum[i]));
+            }
+            ps_d[k] = d;
+            for (int i = 0; i < t - 1; ++i) cum[i] = add(cum[i], mul(sparse_col[k][i], partial[k]));
+            beta = beta_n;
+        }
+        ps_fin.assign(t, zero());
+        ps_fin[0] = beta;
+        for (int i = 0; i < t - 1; ++i) ps_fin[i + 1] = cum[i];
+        return true;
     }
 };
 

@@ -18,7 +18,8 @@
 // decompressed points and the raw scalars, and one kernel runs the sponges.
 //
 // Constants: csrc/poseidon_host.hpp (Grain LFSR + optimized schedule), uploaded once per context as 9-limb registers:
-//   START(k, i) k < 5 | PARTIAL(k) k < 63 | END(k, i) k < 3 | MDS(i, j) | PRE(i, j) | SROW(k, j) | SCOL(k, j) j < 8
+//   START(k, i) k < 5 | PARTIAL(k) k < 63 | END(k, i) k < 3 | MDS(i, j) | PRE(i, j) | SROW(k, j) | SCOL(k, j) j < 8 | FIN(i)
+// (SROW / SCOL / FIN hold the SCALED partial rounds: D_k | R_k, A_k, beta_63 | cum — poseidon_host.hpp scale_partial_rounds)
 #pragma once
 #include "schema.cuh"
 
@@ -28,7 +29,7 @@ constexpr int PSD_T = 9, PSD_RF = 8, PSD_RP = 63, PSD_H = PSD_RF / 2;
 constexpr uint32_t PSD_START = 0, PSD_PARTIAL = PSD_START + (PSD_H + 1) * PSD_T, PSD_END = PSD_PARTIAL + PSD_RP,
                    PSD_MDS = PSD_END + (PSD_H - 1) * PSD_T, PSD_PRE = PSD_MDS + PSD_T * PSD_T,
                    PSD_SROW = PSD_PRE + PSD_T * PSD_T, PSD_SCOL = PSD_SROW + PSD_RP * PSD_T,
-                   PSD_NCONST = PSD_SCOL + PSD_RP * (PSD_T - 1);
+                   PSD_FIN = PSD_SCOL + PSD_RP * (PSD_T - 1), PSD_NCONST = PSD_FIN + PSD_T;
 constexpr int PSD_GROUP = 16, PSD_BLOCK = 64, PSD_PER_BLOCK = PSD_BLOCK / PSD_GROUP;
 
 FP_INLINE Fr fr_add2r(const Fr& a, const Fr& b) { return fr_fold_2r(fp_add<FrParams>(a, b)); }   // < 2r + < 2r -> < 2r
@@ -106,41 +107,60 @@ FP_INLINE Fr psd_permute(const uint32_t* __restrict__ spec, PsdLds& x, int g, in
     s = fr_pow5_plus(s, reg_load(spec, PSD_START + PSD_H * PSD_T + lc));
     s = psd_dense(spec, PSD_PRE, x, g, l, lc, s);
     if (l >= PSD_T) s = Fr::zero();   // idle lanes carry zeros: they take part in the row sums below
-    // this round's constants were loaded during the previous round (three L2 round trips per round sat on the chain otherwise)
-    Fr rowl = reg_load(spec, PSD_SROW + lc);
-    Fr pck = reg_load(spec, PSD_PARTIAL);
-    Fr colk = reg_load(spec, PSD_SCOL + (lc ? lc - 1 : 0));
+    // Partial rounds, scaled (Spec::scale_partial_rounds): lane 0 carries w (s0 = beta_k w), lanes 1..8 carry shat_i.
+    // THREE multiplication issues per round for the whole group (a wave's lanes multiply in lockstep):
+    //   1: lane 0: w^2            lanes >= 1: A_{k-1,i} * z_{k-1}   (the update the previous round owes them)
+    //   2: lane 0: w^4            lanes >= 1: R_{k,i} * shat_i
+    //   3: lane 0: z_k = w^5      lanes >= 1: —
+    // then w <- z_k + D_k + sum_i R_{k,i} shat_i.  This round's constants were loaded during the previous round.
+    Fr zprev = Fr::zero(), aprev = Fr::zero();
+    Fr rk = reg_load(spec, PSD_SROW + lc);                       // lane 0: D_0; lanes 1..8: R_{0,i}
+    Fr ak = reg_load(spec, PSD_SCOL + (lc ? lc - 1 : 0));        // A_{0,i}
 #pragma unroll 1
     for (int k = 0; k < PSD_RP; ++k) {
-        // sbox_part (only s[0]) + apply_sparse_mds: s0' = row . s, s_i' = col_hat[i-1] * s0 + s_i, s0 = the value AFTER the
-        // S-box.  Four multiplication issues per round for the whole group (a wave's lanes multiply in lockstep):
-        //   1: lane 0: s0^2            lanes >= 1: u_i = row[i] * s_i     (independent of the S-box)
-        //   2: lane 0: s0^4    3: lane 0: s0^5 (+ c)
-        //   4: lane 0: row[0] * s0'    lanes >= 1: col_hat[i-1] * s0'
         const int kn = k + 1 < PSD_RP ? k + 1 : k;
-        const Fr rowl_n = reg_load(spec, PSD_SROW + kn * PSD_T + lc);
-        const Fr pck_n = reg_load(spec, PSD_PARTIAL + kn);
-        const Fr colk_n = reg_load(spec, PSD_SCOL + kn * (PSD_T - 1) + (lc ? lc - 1 : 0));
-        Fr b1;
+        const Fr rk_n = reg_load(spec, PSD_SROW + kn * PSD_T + lc);
+        const Fr ak_n = reg_load(spec, PSD_SCOL + kn * (PSD_T - 1) + (lc ? lc - 1 : 0));
+        Fr a1, b1;
 #pragma unroll
-        for (int i = 0; i < NL; ++i) b1.l[i] = (l == 0) ? s.l[i] : rowl.l[i];
-        const Fr p1 = fp_mul<FrParams>(s, b1);                                  // lane 0: s^2; others: u_i
-        const Fr x4 = fp_sqr<FrParams>(p1);                                     // lane 0: s^4
-        const Fr sb = fr_add2r(fp_mul<FrParams>(x4, s), pck);   // lane 0: s^5 + c
-        const Fr s0 = psd_bcast0(sb);
-        const Fr coef = (l == 0) ? rowl : colk;
-        const Fr v = fp_mul<FrParams>(coef, s0);
-        // lane 0: row[0] * s0' + sum_{i >= 1} u_i ; lanes 1..8: v + s_i ; idle lanes stay zero
+        for (int i = 0; i < NL; ++i) {
+            a1.l[i] = (l == 0) ? s.l[i] : aprev.l[i];
+            b1.l[i] = (l == 0) ? s.l[i] : zprev.l[i];
+        }
+        const Fr p1 = fp_mul<FrParams>(a1, b1);                  // lane 0: w^2 (< 4r); others: A z (zero in round 0)
+        const Fr sh = fr_fold_2r(fp_add<FrParams>(s, p1));       // lanes >= 1: shat_i + A z, < 2r
+        Fr a2, b2;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            a2.l[i] = (l == 0) ? p1.l[i] : rk.l[i];
+            b2.l[i] = (l == 0) ? p1.l[i] : sh.l[i];
+        }
+        const Fr p2 = fp_mul<FrParams>(a2, b2);                  // lane 0: w^4; others: R shat_i
+        const Fr z = fp_mul<FrParams>(p2, s);                    // lane 0: w^5 (others: unused)
         Fr t;
 #pragma unroll
-        for (int i = 0; i < NL; ++i) t.l[i] = (l == 0) ? v.l[i] : (l < PSD_T ? p1.l[i] : 0u);
-        const Fr sum = psd_row_sum(t);
-        const Fr upd = fr_add2r(v, s);
+        for (int i = 0; i < NL; ++i) t.l[i] = (l >= 1 && l < PSD_T) ? p2.l[i] : 0u;
+        const Fr sum = psd_row_sum(t);                           // lane 0: sum_i R shat_i, < 16r
+        const Fr wn = fp_add<FrParams>(fp_add<FrParams>(z, rk), sum);   // lane 0: z + D_k + sum, < 20r: only ever squared / multiplied
+        zprev = psd_bcast0(z);
 #pragma unroll
-        for (int i = 0; i < NL; ++i) s.l[i] = (l == 0) ? sum.l[i] : (l < PSD_T ? upd.l[i] : 0u);
-        rowl = rowl_n;
-        pck = pck_n;
-        colk = colk_n;
+        for (int i = 0; i < NL; ++i) s.l[i] = (l == 0) ? wn.l[i] : (l < PSD_T ? sh.l[i] : 0u);
+        aprev = ak;
+        rk = rk_n;
+        ak = ak_n;
+    }
+    {   // the last update owed to lanes 1..8, the constants they were carried without, and s0 = beta_63 w
+        const Fr fin = reg_load(spec, PSD_FIN + lc);
+        Fr a1, b1;
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            a1.l[i] = (l == 0) ? fin.l[i] : aprev.l[i];
+            b1.l[i] = (l == 0) ? s.l[i] : zprev.l[i];
+        }
+        const Fr p1 = fp_mul<FrParams>(a1, b1);                  // lane 0: beta_63 w (< 2r); others: A z
+        const Fr up = fr_fold_2r(fp_add<FrParams>(fr_fold_2r(fp_add<FrParams>(s, p1)), fin));
+#pragma unroll
+        for (int i = 0; i < NL; ++i) s.l[i] = (l == 0) ? p1.l[i] : (l < PSD_T ? up.l[i] : 0u);
     }
 #pragma unroll 1
     for (int k = 0; k < PSD_H - 1; ++k) {
