@@ -1386,7 +1386,9 @@ int h2agg_g1_msm_device_batch_async(h2agg_ctx* c, uint64_t handle, const void* d
     }
     c->tail_overlap = was_overlap;
     c->overlap_level = was_level;
-    return rc;
+    TRY(rc);
+    if (one_by_one && batch > 1 && !was_overlap) TRY(join_tails(c));   // without overlap mode the caller's stream orders the results
+    return H2AGG_OK;
 } catch (const std::bad_alloc&) {
     return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
 } catch (...) {
