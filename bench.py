@@ -78,7 +78,7 @@ def csrc_sha() -> str:
     h = hashlib.sha256()
     d = os.path.join(entry.PKG_DIR, "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".cuh", ".hip", ".inc", ".hpp")):
+        if name.endswith((".hpp", ".hip", ".inc", ".hpp")):
             with open(os.path.join(d, name), "rb") as f:
                 h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]

@@ -1,7 +1,7 @@
 // Batched Fr / G1 kernels (HBM-shaped: one element per lane, 16-byte vector loads, grid-stride).
 // Each kernel names the reference operation it stands behind.
 #pragma once
-#include "g1.cuh"
+#include "g1.hpp"
 
 namespace h2agg {
 

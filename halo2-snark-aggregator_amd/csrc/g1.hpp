@@ -13,7 +13,7 @@
 // results must be bit-exact on adversarial inputs (duplicate bases, a base and its negation in one
 // bucket), not only on random ones.
 #pragma once
-#include "fp.cuh"
+#include "fp.hpp"
 
 namespace h2agg {
 

@@ -1,5 +1,5 @@
 // libh2agg.so — context management and the C ABI declared in include/h2agg.h.
-// Everything numeric runs in the HIP kernels of batch_kernels.cuh / msm_kernels.cuh; there is no CPU
+// Everything numeric runs in the HIP kernels of batch_kernels.hpp / msm_kernels.hpp; there is no CPU
 // arithmetic path in this library (a context cannot be created without a HIP device).
 #include "../../include/h2agg.h"
 
@@ -16,10 +16,10 @@
 #include <string>
 #include <vector>
 
-#include "scalar_mul_kernels.cuh"
+#include "scalar_mul_kernels.hpp"
 #include "pairing.hpp"
 #include "poseidon_host.hpp"
-#include "poseidon_kernels.cuh"
+#include "poseidon_kernels.hpp"
 
 using namespace h2agg;
 
@@ -395,7 +395,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     if (staged && sp.tile < (uint32_t)BLOCK) staged = false;
     if (sp.PW > (uint32_t)SORT_MAX_PW) return fail(c, H2AGG_ERR_INVALID, "too many sort partitions");
     const uint32_t nseg_total = WT * p.spw;
-    // 4 lanes per chain in the bucket reduction / window sums (latency) or 1 (least work): see msm_kernels.cuh
+    // 4 lanes per chain in the bucket reduction / window sums (latency) or 1 (least work): see msm_kernels.hpp
     static const int par4_env = getenv("H2AGG_PAR4") ? atoi(getenv("H2AGG_PAR4")) : 0;
     // measured: wins up to 16384 segments (c <= 13; also a 2^20-point MSM with 32-bucket segments in throughput mode,
     // where 1 024 waves of 94-addition chains would otherwise outlast the step), loses to the extra work above
@@ -420,7 +420,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     TRY(ensure(c, c->hist[sq], (size_t)p.NBT * 4));
     TRY(ensure(c, c->offs[sq], (size_t)p.NBT * 4));
     TRY(ensure(c, c->order[sq], (size_t)p.NBT * 4));
-    // digit-major sort (sort_kernels.cuh): plain 16-bit windows over one table, 2^16 .. 2^22 points
+    // digit-major sort (sort_kernels.hpp): plain 16-bit windows over one table, 2^16 .. 2^22 points
     static const bool dm_env_off = getenv("H2AGG_SORT") && !strcmp(getenv("H2AGG_SORT"), "packed");
     const size_t dm_row = p.glv ? 2 * n : n;   // keys per window (GLV: both halves of a scalar land in the same 8 windows)
     const bool dm = !dm_env_off && !c->cfg_no_dm && !c->cfg_no_stage && !c->cfg_stage_l1 && !c->cfg_sub_bits && !c->cfg_tile && !pre && batch == 1 &&
@@ -672,7 +672,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         c->accdone_pending[sq] = true;
     }
     static const int dbg_skip = getenv("H2AGG_DBG_SKIP") ? atoi(getenv("H2AGG_DBG_SKIP")) : 0;   // measurement only: 1 reduce, 2 + window sums, 4 + final
-    // two-dimensional bucket reduction for 16-bit windows (msm_kernels.cuh); H2AGG_REDUCE=segments keeps the segment kernels
+    // two-dimensional bucket reduction for 16-bit windows (msm_kernels.hpp); H2AGG_REDUCE=segments keeps the segment kernels
     static const bool r2d_env_off = getenv("H2AGG_REDUCE") && !strcmp(getenv("H2AGG_REDUCE"), "segments");
     const bool r2d = !r2d_env_off && !c->cfg_seg && !pre && p.NB == (uint32_t)(R2D_ROWS * R2D_COLS);
     if (r2d) {
@@ -1016,7 +1016,7 @@ int h2agg_g1_batch_scalar_mul(h2agg_ctx* c, const uint8_t* bases, const uint8_t*
     HIP_TRY(c, hipMemcpyAsync(c->in_a.p, bases, 64 * n, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(c->in_b.p, scalars, 32 * n, hipMemcpyHostToDevice, c->stream));
     TRY(clear_flags(c));
-    // GLV + signed window-4 ladder, four lanes per point (csrc/scalar_mul_kernels.cuh); H2AGG_SCALAR_MUL=ladder selects the
+    // GLV + signed window-4 ladder, four lanes per point (csrc/scalar_mul_kernels.hpp); H2AGG_SCALAR_MUL=ladder selects the
     // round-1 bit-serial kernel for A/B measurements
     static const bool ladder = getenv("H2AGG_SCALAR_MUL") && !strcmp(getenv("H2AGG_SCALAR_MUL"), "ladder");
     if (ladder) {

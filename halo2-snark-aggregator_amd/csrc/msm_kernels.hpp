@@ -7,7 +7,7 @@
 //
 //   digits      each lane recodes one canonical scalar into W signed c-bit digits (carry chain in
 //               registers, the 256-bit value is shifted down c bits per window), coalesced 32-B reads
-//   sort        two-level LDS partition of the (window, |digit|) keys (sort_kernels.cuh)
+//   sort        two-level LDS partition of the (window, |digit|) keys (sort_kernels.hpp)
 //               -> hist[W * 2^(c-1)], offs[], entries[n * W] (point index | sign << 31), order[]
 //   accumulate  one lane per bucket (longest first) walks its run: 64-B gathers of Montgomery affine
 //               bases, XYZZ mixed adds; buckets longer than `big` are handed to a workgroup each
@@ -18,7 +18,7 @@
 // Point order inside a bucket is whatever the scatter's atomics produced; the result does not depend on
 // it because the arithmetic is exact.
 #pragma once
-#include "sort_kernels.cuh"
+#include "sort_kernels.hpp"
 
 namespace h2agg {
 

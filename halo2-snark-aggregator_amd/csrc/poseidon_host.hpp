@@ -1,4 +1,4 @@
-// Poseidon parameter generation on the host (C++), for the device sponge of csrc/poseidon_kernels.cuh.
+// Poseidon parameter generation on the host (C++), for the device sponge of csrc/poseidon_kernels.hpp.
 //
 // Stands behind `Spec::<Fr, T, RATE>::new(r_f, r_p)` of the `poseidon` crate (privacy-scaling-explorations/poseidon rev
 // 0b9965fb, reference Cargo.lock:2517-2519; not vendored), which the reference instantiates through
@@ -311,7 +311,7 @@ struct Spec {
         ok = scale_partial_rounds();
     }
 
-    // The partial rounds with one multiplication less on the S-box lane (csrc/poseidon_kernels.cuh).  A partial round is
+    // The partial rounds with one multiplication less on the S-box lane (csrc/poseidon_kernels.hpp).  A partial round is
     //     s0' = s0^5 + c_k,   s0 <- row_0 s0' + sum_{i>=1} row_i s_i,   s_i <- s_i + col_i s0'.
     // Track w with s0 = beta_k w (beta_0 = 1) and z = w^5, and the other words without their constant parts,
     // s_i = shat_i + cum_{k,i}.  Then, with b5 = beta_k^5 and beta_{k+1} = row_0 b5,

@@ -21,7 +21,7 @@
 //   START(k, i) k < 5 | PARTIAL(k) k < 63 | END(k, i) k < 3 | MDS(i, j) | PRE(i, j) | SROW(k, j) | SCOL(k, j) j < 8 | FIN(i)
 // (SROW / SCOL / FIN hold the SCALED partial rounds: D_k | R_k, A_k, beta_63 | cum — poseidon_host.hpp scale_partial_rounds)
 #pragma once
-#include "schema.cuh"
+#include "schema.hpp"
 
 namespace h2agg {
 

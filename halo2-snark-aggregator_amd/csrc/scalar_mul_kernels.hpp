@@ -11,7 +11,7 @@
 //     of 256; phi(T) of a table entry is a single multiplication of its X by beta;
 //   * signed window-4 digits in [-8, 8]: 33 digit positions, one table of 1P .. 8P per point (in LDS, XYZZ), at most two
 //     additions per position (one per GLV half), no per-bit branches;
-//   * four lanes per point (xyzz_double_par4 / xyzz_add_par4 of msm_kernels.cuh): a doubling is 3 products deep instead
+//   * four lanes per point (xyzz_double_par4 / xyzz_add_par4 of msm_kernels.hpp): a doubling is 3 products deep instead
 //     of 9, an addition 4 instead of 14.
 // Chain per point: 7 table additions + 32 x (4 doublings + <= 2 additions) ~ 0.5 ms, against 1.9 ms.
 //
@@ -19,7 +19,7 @@
 // d = 1..255, w = 0..31 (8160 affine points, 510 KiB, built once per context) turns k * G into <= 32 mixed additions and
 // no doubling at all.
 #pragma once
-#include "msm_kernels.cuh"
+#include "msm_kernels.hpp"
 
 namespace h2agg {
 

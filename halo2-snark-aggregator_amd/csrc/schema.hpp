@@ -24,7 +24,7 @@
 #include <unordered_map>
 #include <vector>
 
-#include "msm_kernels.cuh"
+#include "msm_kernels.hpp"
 
 namespace h2agg {
 

@@ -16,7 +16,7 @@
 //   order    buckets are counting-sorted by length (descending) so the 64 lanes of a wave in the
 //            accumulate kernel walk runs of (nearly) equal length
 #pragma once
-#include "batch_kernels.cuh"
+#include "batch_kernels.hpp"
 
 namespace h2agg {
 

@@ -143,7 +143,7 @@ def test_g1_batch_to_affine(eng):
 
 
 def test_inversion_edges_and_shapes(eng):
-    """The device inverse is a safegcd (divsteps) implementation on signed 29-bit limbs (csrc/fp.cuh): exercise limb
+    """The device inverse is a safegcd (divsteps) implementation on signed 29-bit limbs (csrc/fp.hpp): exercise limb
     boundaries, near-modulus values and short / long operands in both fields against exact big-int inverses."""
     rng = O.SplitMix64(77)
     for mod, is_fr in ((O.R, True), (O.P, False)):

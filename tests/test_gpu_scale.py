@@ -57,7 +57,7 @@ def test_msm_identity_and_linearity(eng, log2n):
         eng.bases_free(table)
 
 
-# Python model of csrc/sort_kernels.cuh glv_decompose (same constants), used to craft scalars
+# Python model of csrc/sort_kernels.hpp glv_decompose (same constants), used to craft scalars
 _LAM = 0x30644e72e131a029048b6e193fd84104cc37a73fec2bc5e9b8ca0b2d36636f23
 _A1, _B1N = 147946756881789319000765030803803410728, 9931322734385697763
 _A2, _B2 = 9931322734385697763, 147946756881789319010696353538189108491

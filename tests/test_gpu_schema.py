@@ -170,7 +170,7 @@ def _rand_tree(rng, depth, keys, consts):
 
 @pytest.mark.parametrize("seed", range(12))
 def test_random_schema_trees_vs_oracle(eng, pkg, seed):
-    """Differential test of the tape recorder (interned constants, power chains, deferred sums: csrc/schema.cuh)
+    """Differential test of the tape recorder (interned constants, power chains, deferred sums: csrc/schema.hpp)
     on random ASTs: repeated keys (merging), repeated constants, scalar-only subtrees on either side of Add / Mul,
     and a long Horner chain in one repeated scalar on top."""
     rng = O.SplitMix64(0x5EED00 + seed)

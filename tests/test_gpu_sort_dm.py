@@ -1,4 +1,4 @@
-"""GPU: the digit-major bucket sort (csrc/sort_kernels.cuh: k_dm_digits / k_dm_partition / k_dm_bucket_sort) that plain
+"""GPU: the digit-major bucket sort (csrc/sort_kernels.hpp: k_dm_digits / k_dm_partition / k_dm_bucket_sort) that plain
 16-bit-window MSMs of 2^16 .. 2^22 points take.  Expected values are (sum k_i s_i) * G from the Python oracle; every case
 is also run through the packed two-level sort (h2agg_msm_configure_sort(ctx, 0, -3)) and must give the same bytes."""
 import numpy as np

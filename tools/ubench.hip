@@ -3,7 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdint>
-#include "g1.cuh"
+#include "g1.hpp"
 using namespace h2agg;
 
 #define ITERS 2000

@@ -4,7 +4,7 @@
 //   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/ubench_latency.hip -o tools/ubench_latency
 #include <hip/hip_runtime.h>
 #include <cstdio>
-#include "../halo2-snark-aggregator_amd/csrc/msm_kernels.cuh"
+#include "../halo2-snark-aggregator_amd/csrc/msm_kernels.hpp"
 using namespace h2agg;
 
 __global__ void __launch_bounds__(64) k_chain(int mode, int iters, const uint8_t* in, uint8_t* out, uint64_t* clk) {
