@@ -1,0 +1,175 @@
+// Test driver (tests/ only): the C++ mirror of the trait surface (include/h2agg_chips.hpp) against the C restatement of
+// the reference algorithm (oracle/liboracle_bn254.so, dlopen'ed here: the oracle is the checker, never linked into the
+// product).  Exit status 0 and "chips ok" on parity; a message and 1 otherwise.
+//   g++ -std=c++17 -I include tests/cpp/chips_driver.cpp -L halo2-snark-aggregator_amd -lh2agg -ldl -Wl,-rpath,...
+#include <dlfcn.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+#include "h2agg_chips.hpp"
+
+using namespace h2agg_chips;
+
+namespace {
+uint64_t sm_state = 0x48324147ull;
+uint64_t splitmix() {
+    uint64_t z = (sm_state += 0x9e3779b97f4a7c15ull);
+    z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+    z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+    return z ^ (z >> 31);
+}
+// an Fr element: 253 random bits (always < r)
+Scalar rand_fr() {
+    Scalar s;
+    for (int i = 0; i < 4; ++i) {
+        const uint64_t v = splitmix();
+        for (int k = 0; k < 8; ++k) s[8 * i + k] = (uint8_t)(v >> (8 * k));
+    }
+    s[31] &= 0x1f;
+    return s;
+}
+template <class F>
+F sym(void* h, const char* name) {
+    void* p = dlsym(h, name);
+    if (!p) {
+        std::fprintf(stderr, "oracle symbol %s missing\n", name);
+        std::exit(1);
+    }
+    return reinterpret_cast<F>(p);
+}
+int fails = 0;
+void expect(bool ok, const char* what) {
+    if (!ok) {
+        std::fprintf(stderr, "MISMATCH: %s\n", what);
+        ++fails;
+    }
+}
+}  // namespace
+
+int main(int argc, char** argv) {
+    if (argc < 2) {
+        std::fprintf(stderr, "usage: chips_driver <path to liboracle_bn254.so>\n");
+        return 2;
+    }
+    void* o = dlopen(argv[1], RTLD_NOW);
+    if (!o) {
+        std::fprintf(stderr, "dlopen: %s\n", dlerror());
+        return 2;
+    }
+    auto o_field = sym<int (*)(int, int, const uint8_t*, const uint8_t*, size_t, uint8_t*)>(o, "oracle_field_batch_op");
+    auto o_horner = sym<int (*)(const uint8_t*, size_t, const uint8_t*, uint8_t*)>(o, "oracle_fr_mul_add_accumulate");
+    auto o_add = sym<int (*)(const uint8_t*, const uint8_t*, size_t, int, uint8_t*)>(o, "oracle_g1_batch_add");
+    auto o_smul = sym<int (*)(const uint8_t*, const uint8_t*, size_t, uint8_t*)>(o, "oracle_g1_batch_scalar_mul");
+    auto o_aff = sym<int (*)(const uint8_t*, size_t, uint8_t*)>(o, "oracle_g1_batch_to_affine");
+    auto o_msm = sym<int (*)(const uint8_t*, const uint8_t*, size_t, uint8_t*)>(o, "oracle_multi_exp_naive");
+
+    Gpu gpu(0);
+    GpuFieldChip schip(gpu);
+    GpuEccChip pchip(gpu);
+    GpuChipCtx ctx;
+
+    // ---- ArithFieldChip: every method against the oracle's Fr (which = 0; the oracle has INV, not DIV: a / b = a * inv(b))
+    for (int it = 0; it < 8; ++it) {
+        const Scalar a = rand_fr(), b = rand_fr(), c = rand_fr();
+        Scalar w;
+        const int ops[5] = {H2AGG_OP_ADD, H2AGG_OP_SUB, H2AGG_OP_MUL, H2AGG_OP_DIV, H2AGG_OP_SQR};
+        const Scalar got[5] = {schip.add(ctx, a, b), schip.sub(ctx, a, b), schip.mul(ctx, a, b), schip.div(ctx, a, b),
+                               schip.square(ctx, a)};
+        for (int k = 0; k < 5; ++k) {
+            if (ops[k] == H2AGG_OP_DIV) {
+                Scalar ib;
+                o_field(0, H2AGG_OP_INV, b.data(), nullptr, 1, ib.data());
+                o_field(0, H2AGG_OP_MUL, a.data(), ib.data(), 1, w.data());
+            } else {
+                o_field(0, ops[k], a.data(), b.data(), 1, w.data());
+            }
+            expect(w == got[k], "field op");
+        }
+        // mul_add = a * b + c
+        Scalar ab;
+        o_field(0, H2AGG_OP_MUL, a.data(), b.data(), 1, ab.data());
+        o_field(0, H2AGG_OP_ADD, ab.data(), c.data(), 1, w.data());
+        expect(schip.mul_add(ctx, a, b, c) == w && schip.mul_add_constant(ctx, a, b, c) == w, "mul_add");
+        // Horner
+        std::vector<Scalar> v = {a, b, c, rand_fr(), rand_fr()};
+        std::vector<uint8_t> flat;
+        for (const Scalar& x : v) flat.insert(flat.end(), x.begin(), x.end());
+        const Scalar base = rand_fr();
+        o_horner(flat.data(), v.size(), base.data(), w.data());
+        expect(schip.mul_add_accumulate(ctx, v, base) == w, "mul_add_accumulate");
+        // sum_with_coeff_and_constant: c + a*b + b*a
+        Scalar t;
+        o_field(0, H2AGG_OP_ADD, ab.data(), ab.data(), 1, t.data());
+        o_field(0, H2AGG_OP_ADD, t.data(), c.data(), 1, w.data());
+        expect(schip.sum_with_coeff_and_constant(ctx, {{a, b}, {b, a}}, c) == w, "sum_with_coeff_and_constant");
+        // pow_constant(a, 5) = a^4 * a
+        Scalar a2, a4;
+        o_field(0, H2AGG_OP_SQR, a.data(), nullptr, 1, a2.data());
+        o_field(0, H2AGG_OP_SQR, a2.data(), nullptr, 1, a4.data());
+        o_field(0, H2AGG_OP_MUL, a4.data(), a.data(), 1, w.data());
+        expect(schip.pow_constant(ctx, a, 5) == w, "pow_constant");
+    }
+    // division by zero: the reference panics
+    try {
+        schip.div(ctx, rand_fr(), Scalar{});
+        expect(false, "div by zero must fail");
+    } catch (const ChipError& e) {
+        expect(e.code == H2AGG_ERR_DIV_ZERO, "div by zero code");
+    }
+
+    // ---- ArithEccChip
+    const Point g = pchip.assign_one(ctx);
+    const Affine g_aff = pchip.to_value(g);
+    std::vector<Point> pts;
+    std::vector<Scalar> scs;
+    std::vector<uint8_t> aff_flat, sc_flat;
+    for (int i = 0; i < 40; ++i) {
+        const Scalar k = rand_fr(), s = rand_fr();
+        Point p = pchip.scalar_mul_constant(ctx, k, g_aff);          // k * G
+        Point want;
+        o_smul(g_aff.data(), k.data(), 1, want.data());
+        Affine pa = pchip.to_value(p), wa;
+        o_aff(want.data(), 1, wa.data());
+        expect(pa == wa, "scalar_mul_constant / to_value");
+        if (i % 9 == 4) p = pchip.assign_zero(ctx), pa = Affine{};   // identities among the points
+        pts.push_back(p);
+        scs.push_back(s);
+        aff_flat.insert(aff_flat.end(), pa.begin(), pa.end());
+        sc_flat.insert(sc_flat.end(), s.begin(), s.end());
+    }
+    {   // add / sub / scalar_mul on projective operands
+        Point w;
+        Affine wa;
+        o_add(pts[0].data(), pts[1].data(), 1, 0, w.data());
+        o_aff(w.data(), 1, wa.data());
+        expect(pchip.to_value(pchip.add(ctx, pts[0], pts[1])) == wa, "add");
+        o_add(pts[0].data(), pts[1].data(), 1, 1, w.data());
+        o_aff(w.data(), 1, wa.data());
+        expect(pchip.to_value(pchip.sub(ctx, pts[0], pts[1])) == wa, "sub");
+        expect(pchip.to_value(pchip.sub(ctx, pts[2], pts[2])) == Affine{}, "P - P = identity");
+        const Point sum01 = pchip.add(ctx, pts[0], pts[1]);          // z != 1
+        const Affine s01 = pchip.to_value(sum01);
+        o_smul(s01.data(), scs[0].data(), 1, w.data());
+        o_aff(w.data(), 1, wa.data());
+        expect(pchip.to_value(pchip.scalar_mul(ctx, scs[0], sum01)) == wa, "scalar_mul");
+    }
+    {   // multi_exp: the reference algorithm (n double-and-add products) on the same points
+        Affine want;
+        o_msm(aff_flat.data(), sc_flat.data(), pts.size(), want.data());
+        expect(pchip.to_value(pchip.multi_exp(ctx, pts, scs)) == want, "multi_exp");
+        expect(ctx.point_list.size() == pts.size() && ctx.display() == "(total points: 40)", "ctx.point_list / Display");
+        try {
+            pchip.multi_exp(ctx, {}, {});
+            expect(false, "empty multi_exp must fail");
+        } catch (const ChipError& e) {
+            expect(e.code == H2AGG_ERR_EMPTY, "empty multi_exp code");
+        }
+    }
+    if (fails) {
+        std::fprintf(stderr, "%d mismatches\n", fails);
+        return 1;
+    }
+    std::printf("chips ok\n");
+    return 0;
+}
