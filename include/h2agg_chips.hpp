@@ -201,4 +201,97 @@ class GpuEccChip {
     const Gpu& g_;
 };
 
+// ---- EvaluationQuerySchema (halo2-snark-aggregator-api/src/systems/halo2/evaluation.rs:15-330) --------------------
+// The AST with the reference's constructors and operators: commit!(cq) / eval!(cq) / scalar!(s) (:41-60), `impl Add` /
+// `impl Mul` (:62-84), EvaluationQuery::new (:100-118), estimate (:295-330) and eval (:172-203).  Nodes live in an arena
+// owned by a SchemaArena (one per verification, like the reference's short-lived trees); the scalar bookkeeping of
+// eval_prepare runs as a tape on the device and feeds the multi_exp directly.
+class SchemaArena;
+class EvaluationQuerySchema {
+  public:
+    EvaluationQuerySchema operator+(const EvaluationQuerySchema& r) const;   // evaluation.rs:62-72
+    EvaluationQuerySchema operator*(const EvaluationQuerySchema& r) const;   // :74-84
+    size_t estimate() const;                                                 // estimate(None), :295-330
+    // eval(): (point, Some(scalar) / None).  Errors as the reference's assert! / panic (H2AGG_ERR_INVALID / _EMPTY).
+    struct Evaluated {
+        Point point;
+        bool has_scalar;
+        Scalar scalar;
+    };
+    Evaluated eval() const;
+    uint32_t node() const { return id_; }
+
+  private:
+    friend class SchemaArena;
+    EvaluationQuerySchema(SchemaArena* a, uint32_t id) : a_(a), id_(id) {}
+    SchemaArena* a_;
+    uint32_t id_;
+};
+
+class SchemaArena {
+  public:
+    explicit SchemaArena(const Gpu& g) : g_(g) { g_.check(h2agg_schema_create(g_.ctx(), &s_)); }
+    ~SchemaArena() { h2agg_schema_destroy(s_); }
+    SchemaArena(const SchemaArena&) = delete;
+    SchemaArena& operator=(const SchemaArena&) = delete;
+    // commit!(x): CommitQuerySchema { key, commitment: Some(point), eval: .. }
+    EvaluationQuerySchema commit(const std::string& key, const Affine& point) {
+        uint32_t id;
+        g_.check(h2agg_schema_node_commitment(s_, key.c_str(), point.data(), &id));
+        return EvaluationQuerySchema(this, id);
+    }
+    EvaluationQuerySchema eval(const Scalar& e) {      // eval!(x)
+        uint32_t id;
+        g_.check(h2agg_schema_node_eval(s_, e.data(), &id));
+        return EvaluationQuerySchema(this, id);
+    }
+    EvaluationQuerySchema scalar(const Scalar& v) {    // scalar!(x)
+        uint32_t id;
+        g_.check(h2agg_schema_node_scalar(s_, v.data(), &id));
+        return EvaluationQuerySchema(this, id);
+    }
+    // EvaluationQuery::new(rotation, point, key, commitment, eval).s = commit!(cq) + eval!(cq)   (:100-118)
+    EvaluationQuerySchema query(const std::string& key, const Affine& commitment, const Scalar& e) {
+        const char* k = key.c_str();
+        uint32_t id;
+        g_.check(h2agg_schema_evaluation_queries(s_, 1, &k, commitment.data(), e.data(), &id));
+        return EvaluationQuerySchema(this, id);
+    }
+    // names of the last eval (evaluation.rs:183)
+    std::vector<std::string> names() const {
+        std::vector<std::string> out;
+        for (size_t i = 0; i < h2agg_schema_name_count(s_); ++i) out.emplace_back(h2agg_schema_name(s_, i));
+        return out;
+    }
+    h2agg_schema* raw() const { return s_; }
+    const Gpu& gpu() const { return g_; }
+
+  private:
+    const Gpu& g_;
+    h2agg_schema* s_ = nullptr;
+};
+
+inline EvaluationQuerySchema EvaluationQuerySchema::operator+(const EvaluationQuerySchema& r) const {
+    uint32_t id;
+    a_->gpu().check(h2agg_schema_node_add(a_->raw(), id_, r.id_, &id));
+    return EvaluationQuerySchema(a_, id);
+}
+inline EvaluationQuerySchema EvaluationQuerySchema::operator*(const EvaluationQuerySchema& r) const {
+    uint32_t id;
+    a_->gpu().check(h2agg_schema_node_mul(a_->raw(), id_, r.id_, &id));
+    return EvaluationQuerySchema(a_, id);
+}
+inline size_t EvaluationQuerySchema::estimate() const {
+    size_t n = 0;
+    a_->gpu().check(h2agg_schema_estimate(a_->raw(), id_, &n));
+    return n;
+}
+inline EvaluationQuerySchema::Evaluated EvaluationQuerySchema::eval() const {
+    Evaluated e{};
+    int has = 0;
+    a_->gpu().check(h2agg_schema_eval(a_->raw(), id_, e.point.data(), &has, e.scalar.data()));
+    e.has_scalar = has != 0;
+    return e;
+}
+
 }  // namespace h2agg_chips

@@ -166,6 +166,28 @@ int main(int argc, char** argv) {
             expect(e.code == H2AGG_ERR_EMPTY, "empty multi_exp code");
         }
     }
+    {   // EvaluationQuerySchema: s1 * ([P] + e1) + s2 * ([Q] + e2) + [T]  (the shape batch_multi_open_proofs builds):
+        //   eval() = multi_exp over the commitments that carry a scalar + the scalar-less point, scalar = s1 e1 + s2 e2,
+        //   checked against the same expression evaluated with the chips (themselves checked against the oracle above)
+        SchemaArena arena(gpu);
+        const Affine P = pchip.to_value(pts[0]), Q = pchip.to_value(pts[1]), T = pchip.to_value(pts[2]);
+        const Scalar e1 = rand_fr(), e2 = rand_fr(), s1 = rand_fr(), s2 = rand_fr();
+        const EvaluationQuerySchema tree = arena.scalar(s1) * arena.query("p", P, e1) + arena.scalar(s2) * arena.query("q", Q, e2) +
+                                           arena.commit("t", T);
+        expect(tree.estimate() == 5, "estimate");   // evaluation.rs:295-330: a commitment counts 1, an eval term under a scalar 1
+        const EvaluationQuerySchema::Evaluated ev = tree.eval();
+        const Point want_pt = pchip.add(ctx, pchip.add(ctx, pchip.scalar_mul(ctx, s1, pts[0]), pchip.scalar_mul(ctx, s2, pts[1])), pts[2]);
+        const Scalar want_sc = schip.add(ctx, schip.mul(ctx, s1, e1), schip.mul(ctx, s2, e2));
+        expect(pchip.to_value(ev.point) == pchip.to_value(want_pt), "schema eval: point");
+        expect(ev.has_scalar && ev.scalar == want_sc, "schema eval: scalar");
+        expect(arena.names().size() == 4, "schema eval: names");   // p, "", q, t (the pure-scalar entry has the empty key)
+        try {   // Mul of two commitment-carrying sides: the reference's assert!
+            (arena.commit("a", P) * arena.commit("b", Q)).eval();
+            expect(false, "commitment * commitment must fail");
+        } catch (const ChipError& e) {
+            expect(e.code == H2AGG_ERR_INVALID, "commitment * commitment code");
+        }
+    }
     if (fails) {
         std::fprintf(stderr, "%d mismatches\n", fails);
         return 1;
