@@ -41,9 +41,7 @@ def main(prefix):
         "csrc_sha": bench.csrc_sha(),
         "fetch_kb": fetch[0], "write_kb": write[0],
         "bytes_per_launch": int((fetch[0] + write[0]) * 1024),
-        "correction": "none applied: MI355X_MICROARCH.md's x2 FETCH_SIZE correction is calibrated for wide coalesced "
-                      "16-B/lane streams; this kernel's reads are 64-B gathers + 4-B run walks, for which the guide says "
-                      "the counter is uncalibrated. WRITE_SIZE matches 524288 buckets x 144 B = 75.5 MB + partial lines.",
+        "correction": "none applied, by calibration (tools/ubench_gather.hip under rocprofv3 --pmc FETCH_SIZE, profiles/r02_sweeps.txt): per-lane gathers of whole 64-byte records \u2014 this kernel's reads of its bases \u2014 are counted 1.00x (1 GiB gathered from a 1-GiB table: FETCH_SIZE 1 051 229 KB; from a 64-MiB table: 979 964 KB, the difference being L2 hits), while a coalesced 16-B/lane stream is counted at exactly 1/2 (524 290 KB for 1 GiB), the x2 case of MI355X_MICROARCH.md.  The 4-byte run walks (64 MiB of entries, 4 % of the reads) are not calibrated.  WRITE_SIZE matches 524 288 buckets x 144 B = 75.5 MB + partial lines + 36 MB of scratch from the peeled second insertion.",
         "valu_insts": insts, "duration_us": dur_us, "shader_clock_hz": clk_hz,
         "wave_instructions_per_mixed_add": insts / wave_adds,
         "ideal_cpi": 3.57,
