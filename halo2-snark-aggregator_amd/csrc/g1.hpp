@@ -215,6 +215,36 @@ FP_INLINE G1XYZZ xyzz_add(const G1XYZZ& a, const G1XYZZ& b) {
     return o;
 }
 
+// a + b as xyzz_add, with the multiplications as side-by-side chains (fp_mont_chain2): fewer instructions (no merges of
+// partial sums), but one dependent chain per product — for kernels that have other waves to fill the wait states
+// (the row / column sums of the bucket reduction), not for the lone-wave tails.
+FP_INLINE G1XYZZ xyzz_add_chains(const G1XYZZ& a, const G1XYZZ& b) {
+    if (a.is_identity()) return b;
+    if (b.is_identity()) return a;
+    Fq u1, u2, s1, s2;
+    fp_mul_dual<FqParams>(a.x, b.zz, b.x, a.zz, u1, u2);        // 16 -> [2], [2]
+    fp_mul_dual<FqParams>(a.y, b.zzz, b.y, a.zzz, s1, s2);      // 8 -> [2], [2]
+    Fq p = FQ_SUB(2, u2, u1);                                   // [4]
+    Fq r = FQ_SUB(2, s2, s1);                                   // [4]
+    if (fp_maybe_zero_mod<4, FqParams>(p)) {
+        if (fp_is_zero_mod<4, FqParams>(p)) {
+            if (fp_is_zero_mod<4, FqParams>(r)) return xyzz_double(a);
+            return G1XYZZ::identity();
+        }
+    }
+    G1XYZZ o;
+    fq_fence(p);
+    fq_fence(r);
+    Fq pp, rr, ppp, q, zz12, zzz12;
+    fp_sqr_dual<FqParams>(p, r, pp, rr);                        // 16 -> [2], [2]
+    fp_mul_dual<FqParams>(a.zz, b.zz, a.zzz, b.zzz, zz12, zzz12);
+    fp_mul_dual<FqParams>(p, pp, u1, pp, ppp, q);               // [2], [2]
+    o.x = fp_sub_sub2<6, FqParams>(rr, ppp, q);                 // [8]
+    // R*(Q - X3 + 8p) + (2p - S1)*PPP: (4*10 + 2*2)/169 + 1 -> [2]
+    fp_mul2_mul_mul<FqParams>(r, FQ_SUB(8, q, o.x), fp_neg<2, FqParams>(s1), ppp, zz12, pp, zzz12, ppp, o.y, o.zz, o.zzz);
+    return o;
+}
+
 FP_INLINE G1XYZZ xyzz_neg(const G1XYZZ& a) {
     G1XYZZ r = a;
     if (!a.is_identity()) r.y = fp_neg<4, FqParams>(a.y);  // [4]

@@ -347,7 +347,7 @@ __global__ void __launch_bounds__(64) k_msm_reduce2d_parts(const uint8_t* __rest
         const G1XYZZ cur = r2d_own(blk[i & 1], lane);
         __syncthreads();
         if (i + 1 < R2D_L) r2d_fetch(B, off, step * (i + 1), blk[(i + 1) & 1]);
-        acc = xyzz_add(acc, cur);
+        acc = xyzz_add_chains(acc, cur);
     }
     if (g < total) xyzz_store(parts + XYZZ_BYTES * (size_t)g, acc);
 }
