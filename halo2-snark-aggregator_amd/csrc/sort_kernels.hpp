@@ -906,8 +906,9 @@ FP_INLINE uint32_t dm_entry(uint32_t it, const DmPlan& dp, uint32_t idxmask) {
 
 // level 2, one workgroup per partition (w, pl).  Key k of the partition (k < total) lives in tile t with
 // rpre[t] <= k < rpre[t + 1]; runs are nearly equal, so t is guessed from k and corrected by a step or two.
+// (waves_per_eu 6: PER = 16 then fits 66 VGPRs without scratch — three workgroups per CU alone, two beside the row / column sums)
 template <int PER>
-__global__ void __launch_bounds__(DM_TB2) k_dm_bucket_sort(const uint32_t* __restrict__ pstart,
+__global__ void __launch_bounds__(DM_TB2) __attribute__((amdgpu_waves_per_eu(6, 6))) k_dm_bucket_sort(const uint32_t* __restrict__ pstart,
                                                            const uint32_t* __restrict__ toff,
                                                            const uint32_t* __restrict__ items, DmPlan dp, uint32_t NB,
                                                            uint32_t* __restrict__ hist, uint32_t* __restrict__ offs,
