@@ -10,6 +10,7 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <functional>
 #include <map>
 #include <memory>
 #include <new>
@@ -131,6 +132,11 @@ struct h2agg_ctx {
     int parity = 0;   // slot of the next MSM
     // overlap level 3: the bucket accumulation of MSM k runs on its own stream, under the sort of MSM k+1 (which stays on the
     // context's stream, ordered after whatever the caller queued there).  The sort's outputs exist twice.
+    // Deferred tail (overlap level >= 2): the tail of MSM k is launched from the NEXT MSM's call, behind that MSM's sort —
+    // beside the sort it slows the sort's latency chains by 2x, beside the accumulation it only costs its own instructions.
+    // Whoever needs the results first (join_tails) launches it at once.
+    std::function<int(bool)> deferred_tail;   // argument: true = wait for the event just recorded behind a sort
+    hipEvent_t ev_sortdone = nullptr;
     hipStream_t acc_stream = nullptr;
     hipEvent_t ev_sorted[2] = {}, ev_accdone[2] = {};
     bool accdone_pending[2] = {};
@@ -167,10 +173,17 @@ int fail(h2agg_ctx* c, int code, const std::string& msg) {
             return fail(ctx, H2AGG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));         \
     } while (0)
 
+int flush_deferred_tail(h2agg_ctx* c, bool behind_sort);
+
 int ensure(h2agg_ctx* c, DevBuf& b, size_t bytes) {
     if (bytes <= b.cap) return H2AGG_OK;
     if (b.p) {
         // a grow-only buffer is replaced: nothing queued on ANY stream of the device may still refer to the old one
+        // (nor anything not yet queued: a deferred tail goes out first)
+        {
+            const int rc_ = flush_deferred_tail(c, false);
+            if (rc_ != H2AGG_OK) return rc_;
+        }
         HIP_TRY(c, hipDeviceSynchronize());
         HIP_TRY(c, hipFree(b.p));
     }
@@ -313,7 +326,15 @@ void profile_harvest_all(h2agg_ctx* c) {
 }
 
 // make everything queued on the tail stream visible to the main stream
+int flush_deferred_tail(h2agg_ctx* c, bool behind_sort) {
+    if (!c->deferred_tail) return H2AGG_OK;
+    std::function<int(bool)> f;
+    f.swap(c->deferred_tail);
+    return f(behind_sort);
+}
+
 int join_tails(h2agg_ctx* c) {
+    TRY(flush_deferred_tail(c, false));
     for (int k = 0; k < h2agg_ctx::TAIL_SLOTS; ++k) {
         if (c->tail_pending[k]) {
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->ev_tail[k], 0));
@@ -597,6 +618,10 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
                            bin_cursor);
         hipLaunchKernelGGL(k_size_scatter, dim3(g), dim3(BLOCK), 0, st, hist, p.NBT, bin_cursor, order);
     }
+    if (c->deferred_tail) {   // the previous MSM's tail goes out now, behind this MSM's sort
+        HIP_TRY(c, hipEventRecord(c->ev_sortdone, st));
+        TRY(flush_deferred_tail(c, true));
+    }
     if (piped) {   // from here on: the accumulation stream
         HIP_TRY(c, hipEventRecord(c->ev_sorted[sq], st));
         HIP_TRY(c, hipStreamWaitEvent(c->acc_stream, c->ev_sorted[sq], 0));
@@ -633,7 +658,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     // with alternating sort outputs they leave the bulk stream and go in front of the bucket reduction on the tail stream,
     // followed by the zeroing of this slot's counters for the MSM after next.
     const bool tail_big = altbuf && c->overlap_level >= 2 && lpb == 1;
-    auto big_kernels = [&](hipStream_t bs) {
+    auto big_kernels = [=](hipStream_t bs) {
         StageTimer t(c, ST_ACCUM_BIG, bs);
         size_t grid = max_slots;
         const size_t cap = (size_t)c->cu_count * 4;
@@ -656,72 +681,92 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     }
     if (altbuf) c->sort_par ^= 1;
     // Everything after the bucket accumulation is latency-shaped (one wave per SIMD or less): bucket
-    // reduction, per-window sums, Horner tail.  In overlap mode it runs on the context's second stream,
-    // under the sort + accumulation of the next MSM; results are picked up by join_tails().
-    hipStream_t ts = st;
-    if (c->tail_overlap && c->overlap_level >= 2) {
-        HIP_TRY(c, hipEventRecord(c->ev_bulk[par], st));
-        HIP_TRY(c, hipStreamWaitEvent(c->tail_streams[par], c->ev_bulk[par], 0));
-        ts = c->tail_streams[par];
-    }
-    if (tail_big) {
-        big_kernels(ts);
-        HIP_TRY(c, hipMemsetAsync(meta, 0, M_WORDS * 4, ts));
-        c->meta_clean[sq] = true;
-        HIP_TRY(c, hipEventRecord(c->ev_accdone[sq], ts));
-        c->accdone_pending[sq] = true;
-    }
+    // reduction, per-window sums, Horner tail.  In overlap mode it runs on one of the context's tail streams, under the
+    // accumulation of the next MSM (launched from that MSM's call, behind its sort: `deferred_tail`); results are picked
+    // up by join_tails().
     static const int dbg_skip = getenv("H2AGG_DBG_SKIP") ? atoi(getenv("H2AGG_DBG_SKIP")) : 0;   // measurement only: 1 reduce, 2 + window sums, 4 + final
     // two-dimensional bucket reduction for 16-bit windows (msm_kernels.hpp); H2AGG_REDUCE=segments keeps the segment kernels
     static const bool r2d_env_off = getenv("H2AGG_REDUCE") && !strcmp(getenv("H2AGG_REDUCE"), "segments");
     const bool r2d = !r2d_env_off && !c->cfg_seg && !pre && p.NB == (uint32_t)(R2D_ROWS * R2D_COLS);
+    uint32_t* ticket = nullptr;
     if (r2d) {
         DevBuf& tk = c->r2d_ticket[par];   // arrival counters of the two half-window workgroups: zero between MSMs
         if ((size_t)WT * 4 > tk.cap) {
             TRY(ensure(c, tk, (size_t)WT * 4));
             HIP_TRY(c, hipMemset(tk.p, 0, tk.cap));
         }
-        if (!(dbg_skip & 1)) {
-            StageTimer t(c, ST_REDUCE, ts);
-            const uint32_t total = WT * (uint32_t)R2D_THREADS;
-            hipLaunchKernelGGL(k_msm_reduce2d_parts, dim3(total / 64), dim3(64), 0, ts, (const uint8_t*)buckets, total, segsum);
+        ticket = (uint32_t*)tk.p;
+    }
+    const bool tails_off_stream = c->tail_overlap && c->overlap_level >= 2;
+    const bool final_off_stream = c->tail_overlap;
+    uint8_t* const res_xyzz = c->d_res_xyzz;
+    if (tails_off_stream) HIP_TRY(c, hipEventRecord(c->ev_bulk[par], st));
+    // `from`: the stream the accumulation ran on.  behind_sort: the tail stream also waits for c->ev_sortdone.
+    auto tail_fn = [=](bool behind_sort) -> int {
+        hipStream_t ts = st;
+        if (tails_off_stream) {
+            ts = c->tail_streams[par];
+            HIP_TRY(c, hipStreamWaitEvent(ts, c->ev_bulk[par], 0));
+            if (behind_sort) HIP_TRY(c, hipStreamWaitEvent(ts, c->ev_sortdone, 0));
         }
-        if (!(dbg_skip & 2)) {
-            StageTimer t(c, ST_WINDOW_SUM, ts);
-            hipLaunchKernelGGL(k_msm_reduce2d_window, dim3(WT, 2), dim3(R2D_TB), 0, ts, (const uint8_t*)segsum,
-                               segsum + XYZZ_BYTES * (size_t)WT * R2D_THREADS, (uint32_t*)tk.p, wsum);
+        if (tail_big) {
+            big_kernels(ts);
+            HIP_TRY(c, hipMemsetAsync(meta, 0, M_WORDS * 4, ts));
+            c->meta_clean[sq] = true;
+            HIP_TRY(c, hipEventRecord(c->ev_accdone[sq], ts));
+            c->accdone_pending[sq] = true;
         }
+        if (r2d) {
+            if (!(dbg_skip & 1)) {
+                StageTimer t(c, ST_REDUCE, ts);
+                const uint32_t total = WT * (uint32_t)R2D_THREADS;
+                hipLaunchKernelGGL(k_msm_reduce2d_parts, dim3(total / 64), dim3(64), 0, ts, (const uint8_t*)buckets, total, segsum);
+            }
+            if (!(dbg_skip & 2)) {
+                StageTimer t(c, ST_WINDOW_SUM, ts);
+                hipLaunchKernelGGL(k_msm_reduce2d_window, dim3(WT, 2), dim3(R2D_TB), 0, ts, (const uint8_t*)segsum,
+                                   segsum + XYZZ_BYTES * (size_t)WT * R2D_THREADS, ticket, wsum);
+            }
+        } else {
+            if (!(dbg_skip & 1)) {
+                StageTimer t(c, ST_REDUCE, ts);
+                if (par4)
+                    hipLaunchKernelGGL(k_msm_reduce_segments_par4, dim3((4 * nseg_total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ts,
+                                       buckets, p.NB, p.seg, p.spw, nseg_total, segsum);
+                else
+                    hipLaunchKernelGGL(k_msm_reduce_segments, dim3((nseg_total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ts, buckets,
+                                       p.NB, p.seg, p.spw, nseg_total, segsum);
+            }
+            if (!(dbg_skip & 2)) {
+                StageTimer t(c, ST_WINDOW_SUM, ts);
+                if (par4)
+                    hipLaunchKernelGGL(k_msm_window_sum_par4, dim3(WT), dim3(PAR4_THREADS), 0, ts, segsum, p.spw, wsum);
+                else
+                    hipLaunchKernelGGL(k_msm_window_sum, dim3(WT), dim3(BLOCK), 0, ts, segsum, p.spw, wsum);
+            }
+        }
+        if (final_off_stream && !tails_off_stream) {   // overlap level 1: only the Horner tail leaves the stream
+            HIP_TRY(c, hipEventRecord(c->ev_bulk[par], st));
+            HIP_TRY(c, hipStreamWaitEvent(c->tail_streams[par], c->ev_bulk[par], 0));
+            ts = c->tail_streams[par];
+        }
+        if (!(dbg_skip & 4)) {
+            StageTimer t(c, ST_FINAL, ts);
+            hipLaunchKernelGGL(k_msm_final, dim3(batch), dim3(64), 0, ts, wsum, p.c, W1, batch > 1 ? (uint8_t*)nullptr : res_xyzz,
+                               d_out_jac);
+        }
+        if (final_off_stream) {
+            HIP_TRY(c, hipEventRecord(c->ev_tail[par], c->tail_streams[par]));
+            c->tail_pending[par] = true;
+        }
+        return H2AGG_OK;
+    };
+    // deferral needs another MSM to carry it; a full per-stage profiling pass keeps every stage inside its own call
+    static const bool defer_env_off = getenv("H2AGG_DEFER_TAILS") && !strcmp(getenv("H2AGG_DEFER_TAILS"), "0");
+    if (tails_off_stream && !defer_env_off && !(c->profiling && c->prof_only < 0)) {
+        c->deferred_tail = tail_fn;
     } else {
-    if (!(dbg_skip & 1)) {
-        StageTimer t(c, ST_REDUCE, ts);
-        if (par4)
-            hipLaunchKernelGGL(k_msm_reduce_segments_par4, dim3((4 * nseg_total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ts,
-                               buckets, p.NB, p.seg, p.spw, nseg_total, segsum);
-        else
-            hipLaunchKernelGGL(k_msm_reduce_segments, dim3((nseg_total + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, ts, buckets,
-                               p.NB, p.seg, p.spw, nseg_total, segsum);
-    }
-    if (!(dbg_skip & 2)) {
-        StageTimer t(c, ST_WINDOW_SUM, ts);
-        if (par4)
-            hipLaunchKernelGGL(k_msm_window_sum_par4, dim3(WT), dim3(PAR4_THREADS), 0, ts, segsum, p.spw, wsum);
-        else
-            hipLaunchKernelGGL(k_msm_window_sum, dim3(WT), dim3(BLOCK), 0, ts, segsum, p.spw, wsum);
-    }
-    }
-    if (c->tail_overlap && c->overlap_level < 2) {
-        HIP_TRY(c, hipEventRecord(c->ev_bulk[par], st));
-        HIP_TRY(c, hipStreamWaitEvent(c->tail_streams[par], c->ev_bulk[par], 0));
-        ts = c->tail_streams[par];
-    }
-    if (!(dbg_skip & 4)) {
-        StageTimer t(c, ST_FINAL, ts);
-        hipLaunchKernelGGL(k_msm_final, dim3(batch), dim3(64), 0, ts, wsum, p.c, W1, batch > 1 ? (uint8_t*)nullptr : c->d_res_xyzz,
-                           d_out_jac);
-    }
-    if (c->tail_overlap) {
-        HIP_TRY(c, hipEventRecord(c->ev_tail[par], c->tail_streams[par]));
-        c->tail_pending[par] = true;
+        TRY(tail_fn(false));
     }
     // the slot (buckets / segsum / wsum / XYZZ result) rotates on every MSM, overlap or not: a caller may queue
     // two MSMs and read both results afterwards (evaluate_multiopen_proof does)
@@ -801,6 +846,7 @@ int h2agg_create(int device_ordinal, h2agg_ctx** out) try {
         h2agg_destroy(c);
         return H2AGG_ERR_HIP;
     }
+    hipEventCreateWithFlags(&c->ev_sortdone, EV_SYNC_FLAGS);
     for (int q = 0; q < 2; ++q) {
         hipEventCreateWithFlags(&c->ev_sorted[q], EV_SYNC_FLAGS);
         hipEventCreateWithFlags(&c->ev_accdone[q], EV_SYNC_FLAGS);
@@ -826,6 +872,7 @@ void h2agg_destroy(h2agg_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     comm_release(c);
+    flush_deferred_tail(c, false);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->acc_stream) hipStreamSynchronize(c->acc_stream);
     for (int k = 0; k < h2agg_ctx::TAIL_SLOTS; ++k)
@@ -861,6 +908,7 @@ void h2agg_destroy(h2agg_ctx* c) {
         if (c->ev_tail[k]) hipEventDestroy(c->ev_tail[k]);
         if (c->tail_streams[k]) hipStreamDestroy(c->tail_streams[k]);
     }
+    if (c->ev_sortdone) hipEventDestroy(c->ev_sortdone);
     for (int q = 0; q < 2; ++q) {
         if (c->ev_sorted[q]) hipEventDestroy(c->ev_sorted[q]);
         if (c->ev_accdone[q]) hipEventDestroy(c->ev_accdone[q]);
@@ -1222,6 +1270,7 @@ int h2agg_bases_free(h2agg_ctx* c, uint64_t handle) try {
     TRY(bind(c));
     auto it = c->tables.find(handle);
     if (it == c->tables.end()) return fail(c, H2AGG_ERR_INVALID, "unknown base-table handle");
+    TRY(join_tails(c));   // tails and accumulations on the context's other streams (and a deferred tail) may still read the table
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     hipFree(it->second.d);
     if (it->second.endo_x) hipFree(it->second.endo_x);
