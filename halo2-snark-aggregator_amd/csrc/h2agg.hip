@@ -661,12 +661,12 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     auto big_kernels = [=](hipStream_t bs) {
         StageTimer t(c, ST_ACCUM_BIG, bs);
         size_t grid = max_slots;
-        const size_t cap = (size_t)c->cu_count * 4;
+        const size_t cap = (size_t)c->cu_count * 8;   // one-wave workgroups, grid-stride over the (usually empty) lists
         if (grid > cap) grid = cap;
-        hipLaunchKernelGGL(k_msm_accumulate_big, dim3((unsigned)grid), dim3(BLOCK), 0, bs, d_bases, d_endo_x, entries, offs, hist,
+        hipLaunchKernelGGL(k_msm_accumulate_big, dim3((unsigned)grid), dim3(64), 0, bs, d_bases, d_endo_x, entries, offs, hist,
                            acc_out, lpb, big_part, big_list, big_count);
         size_t gk = max_keys < cap ? max_keys : cap;
-        hipLaunchKernelGGL(k_msm_big_combine, dim3((unsigned)gk), dim3(BLOCK), 0, bs, big_part, big_keys, big_count,
+        hipLaunchKernelGGL(k_msm_big_combine, dim3((unsigned)gk), dim3(64), 0, bs, big_part, big_keys, big_count,
                            acc_out, lpb);
         if (lpb > 1)
             hipLaunchKernelGGL(k_msm_bucket_combine, dim3((p.NBT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, bs,

@@ -72,12 +72,12 @@ __global__ void __launch_bounds__(BLOCK) k_bases_shift(const uint8_t* __restrict
 // window or skewed scalars can put a large share of all points into a handful of buckets — a 2-bit top
 // window at c = 14 holds n/4 points per bucket).  big_list: 3 words per chunk slot {key, chunk, nchunks};
 // big_keys: 3 words per multi-chunk bucket {key, first slot, nchunks}.
-constexpr uint32_t BIG_CHUNK = 2048;       // smallest chunk
-constexpr uint32_t BIG_CHUNK_MAX = 16384;  // largest: 64 additions per lane amortise the workgroup's LDS tree (8 levels)
-// chunk size of an over-long bucket: ~64 chunks per bucket (a bucket holding a million entries — all scalars equal — is
-// then 64 workgroups of 64 additions per lane, not 512 workgroups of 8 additions + a tree each)
+constexpr uint32_t BIG_CHUNK = 512;        // smallest chunk (a one-wave workgroup walks it: 8 additions per lane)
+constexpr uint32_t BIG_CHUNK_MAX = 4096;   // largest: 64 additions per lane amortise the wave's LDS tree (6 levels)
+// chunk size of an over-long bucket: ~256 chunks per bucket (a bucket holding a million entries — all scalars equal — is
+// then 256 one-wave workgroups of 64 additions per lane, not 2048 of 8 additions + a tree each)
 FP_INLINE uint32_t big_chunk_size(uint32_t len) {
-    uint32_t cs = len / 64;
+    uint32_t cs = len / 256;
     cs = cs < BIG_CHUNK ? BIG_CHUNK : (cs > BIG_CHUNK_MAX ? BIG_CHUNK_MAX : cs);
     return cs;
 }
@@ -174,17 +174,54 @@ __global__ void __launch_bounds__(BLOCK) k_msm_bucket_combine(const uint8_t* __r
     xyzz_store(buckets + XYZZ_BYTES * (size_t)key, acc);
 }
 
-// one workgroup per chunk of an over-long bucket
-__global__ void __launch_bounds__(BLOCK) k_msm_accumulate_big(const uint8_t* __restrict__ bases,
-                                                              const uint8_t* __restrict__ endo_x,
-                                                              const uint32_t* __restrict__ entries,
-                                                              const uint32_t* __restrict__ offs,
-                                                              const uint32_t* __restrict__ hist,
-                                                              uint8_t* __restrict__ buckets, uint32_t stride /* lpb */,
-                                                              uint8_t* __restrict__ big_part,
-                                                              const uint32_t* __restrict__ big_list,
-                                                              const uint32_t* __restrict__ counters) {
-    __shared__ uint32_t lds[XYZZ_WORDS * BLOCK];
+// Sum of one XYZZ point per lane over a ONE-WAVE workgroup (result valid in lane 0); lds: XYZZ_WORDS * 64 words.
+// The over-long-bucket kernels run as one-wave workgroups on purpose: they sit at the head of the tail, beside the next
+// MSM's accumulation, and a 256-thread workgroup of ~190-VGPR waves only finds room when that kernel is nearly over
+// (it held the whole tail back by 0.9 ms although its lists are empty for uniform scalars); a single wave slips into the
+// first slot a retiring accumulate wave leaves.
+__device__ __noinline__ G1XYZZ wave_sum_xyzz(G1XYZZ v, uint32_t* lds) {
+    const int lane = threadIdx.x;
+    auto put = [&](int slot, const G1XYZZ& p) {
+#pragma unroll
+        for (int i = 0; i < NL; ++i) {
+            lds[i * 64 + slot] = p.x.l[i];
+            lds[(NL + i) * 64 + slot] = p.y.l[i];
+            lds[(2 * NL + i) * 64 + slot] = p.zz.l[i];
+            lds[(3 * NL + i) * 64 + slot] = p.zzz.l[i];
+        }
+    };
+    put(lane, v);
+    __syncthreads();
+#pragma unroll 1
+    for (int s2 = 32; s2 >= 1; s2 >>= 1) {
+        if (lane < s2) {
+            G1XYZZ o;
+#pragma unroll
+            for (int i = 0; i < NL; ++i) {
+                o.x.l[i] = lds[i * 64 + lane + s2];
+                o.y.l[i] = lds[(NL + i) * 64 + lane + s2];
+                o.zz.l[i] = lds[(2 * NL + i) * 64 + lane + s2];
+                o.zzz.l[i] = lds[(3 * NL + i) * 64 + lane + s2];
+            }
+            v = xyzz_add(v, o);
+            put(lane, v);
+        }
+        __syncthreads();
+    }
+    return v;
+}
+
+// one (one-wave) workgroup per chunk of an over-long bucket
+__global__ void __launch_bounds__(64) k_msm_accumulate_big(const uint8_t* __restrict__ bases,
+                                                           const uint8_t* __restrict__ endo_x,
+                                                           const uint32_t* __restrict__ entries,
+                                                           const uint32_t* __restrict__ offs,
+                                                           const uint32_t* __restrict__ hist,
+                                                           uint8_t* __restrict__ buckets, uint32_t stride /* lpb */,
+                                                           uint8_t* __restrict__ big_part,
+                                                           const uint32_t* __restrict__ big_list,
+                                                           const uint32_t* __restrict__ counters) {
+    __shared__ uint32_t lds[XYZZ_WORDS * 64];
     const uint32_t nslots = counters[0];
     for (uint32_t b = blockIdx.x; b < nslots; b += gridDim.x) {
         const uint32_t key = big_list[3 * b], chunk = big_list[3 * b + 1], nch = big_list[3 * b + 2];
@@ -194,27 +231,27 @@ __global__ void __launch_bounds__(BLOCK) k_msm_accumulate_big(const uint8_t* __r
         const uint32_t* run = entries + offs[key];
         G1XYZZ acc = G1XYZZ::identity();
 #pragma unroll 1
-        for (uint32_t k = lo + threadIdx.x; k < hi; k += BLOCK) xyzz_add_affine(acc, msm_gather(bases, endo_x, run[k]));
-        G1XYZZ tot = block_sum_xyzz(acc, lds);
+        for (uint32_t k = lo + threadIdx.x; k < hi; k += 64) xyzz_add_affine(acc, msm_gather(bases, endo_x, run[k]));
+        G1XYZZ tot = wave_sum_xyzz(acc, lds);
         if (threadIdx.x == 0)
             xyzz_store(nch == 1 ? buckets + XYZZ_BYTES * (size_t)key * stride : big_part + XYZZ_BYTES * (size_t)b, tot);
         __syncthreads();
     }
 }
 // sum the chunk partials of every multi-chunk bucket
-__global__ void __launch_bounds__(BLOCK) k_msm_big_combine(const uint8_t* __restrict__ big_part,
-                                                           const uint32_t* __restrict__ big_keys,
-                                                           const uint32_t* __restrict__ counters,
-                                                           uint8_t* __restrict__ buckets, uint32_t stride /* lpb */) {
-    __shared__ uint32_t lds[XYZZ_WORDS * BLOCK];
+__global__ void __launch_bounds__(64) k_msm_big_combine(const uint8_t* __restrict__ big_part,
+                                                        const uint32_t* __restrict__ big_keys,
+                                                        const uint32_t* __restrict__ counters,
+                                                        uint8_t* __restrict__ buckets, uint32_t stride /* lpb */) {
+    __shared__ uint32_t lds[XYZZ_WORDS * 64];
     const uint32_t nkeys = counters[1];
     for (uint32_t k = blockIdx.x; k < nkeys; k += gridDim.x) {
         const uint32_t key = big_keys[3 * k], base = big_keys[3 * k + 1], nch = big_keys[3 * k + 2];
         G1XYZZ acc = G1XYZZ::identity();
 #pragma unroll 1
-        for (uint32_t j = threadIdx.x; j < nch; j += BLOCK)
+        for (uint32_t j = threadIdx.x; j < nch; j += 64)
             acc = xyzz_add(acc, xyzz_load(big_part + XYZZ_BYTES * (size_t)(base + j)));
-        G1XYZZ tot = block_sum_xyzz(acc, lds);
+        G1XYZZ tot = wave_sum_xyzz(acc, lds);
         if (threadIdx.x == 0) xyzz_store(buckets + XYZZ_BYTES * (size_t)key * stride, tot);
         __syncthreads();
     }

@@ -904,6 +904,76 @@ FP_INLINE uint32_t dm_entry(uint32_t it, const DmPlan& dp, uint32_t idxmask) {
     return e | idx;
 }
 
+// h[b] += 1 for every valid lane; returns the lane's slot (old value + its rank among the lanes counted with it).  The
+// two most frequent-looking buckets of the wave (the first lane's, then the first remaining lane's) take one LDS atomic
+// each, whatever is left goes lane by lane: skew collapses, spread buckets cost two wave-uniform rounds more.
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
+FP_INLINE uint32_t dm_wave_agg_add(lds_u32* h, uint32_t b, bool valid) {
+    const uint32_t lane = __lane_id();
+    uint64_t todo = __ballot(valid);
+    uint32_t res = 0;
+    bool pending = valid;
+#pragma unroll 1
+    for (int round = 0; round < 2 && todo; ++round) {
+        const int lead = __ffsll((unsigned long long)todo) - 1;
+        const uint32_t bl = __shfl(b, lead);
+        const bool mine = pending && b == bl;
+        const uint64_t same = __ballot(mine);
+        uint32_t base = 0;
+        if ((int)lane == lead)
+            base = __hip_atomic_fetch_add(&h[bl], (uint32_t)__popcll(same), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        base = __shfl(base, lead);
+        if (mine) {
+            res = base + (uint32_t)__popcll(same & ((1ull << lane) - 1ull));
+            pending = false;
+        }
+        todo &= ~same;
+    }
+    if (pending) res = __hip_atomic_fetch_add(&h[b], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return res;
+}
+
+// One pass over an over-long partition (skewed scalars: it does not fit the level-2 stage), tile-major: a wave per
+// level-1 run, eight keys per lane in flight, one LDS atomic for a wave's dominant buckets (dm_wave_agg_add) — with all scalars equal a
+// whole row lands in one bucket, where per-lane atomics on the one address serialise (and where the even-runs guess of
+// the fast path's key -> tile lookup is off by half the row under GLV).  PLACE = false counts into h[], PLACE = true
+// takes slots from h[] (bucket starts) and writes the entries.  Kept out of line: inlined, its registers cost the
+// fast path its load batching (1.29 -> 1.55 ms per 2^20-point step, profiles/r02_sweeps.txt).
+template <bool PLACE>
+__device__ __attribute__((noinline)) void dm_long_pass(const uint32_t* __restrict__ rowp, const lds_u32* rstart,
+                                                       const lds_u32* rpre, lds_u32* h, uint32_t* __restrict__ out,
+                                                       uint32_t ntile, int idx_bits, uint32_t n_pts) {
+    constexpr int LB = 8;
+    const uint32_t lane = threadIdx.x & 63u, wv = threadIdx.x >> 6;
+    const int sh = idx_bits + 1;
+    const uint32_t idxmask = (1u << idx_bits) - 1u;
+    for (uint32_t t = wv; t < ntile; t += DM_TB2 / 64) {
+        const uint32_t len = rpre[t + 1] - rpre[t];
+        const uint32_t* src = rowp + (size_t)t * DM_T1 + rstart[t];
+        for (uint32_t k0 = 0; k0 < len; k0 += 64 * LB) {
+            uint32_t v[LB];
+#pragma unroll
+            for (int j = 0; j < LB; ++j) {
+                const uint32_t k = k0 + j * 64 + lane;
+                v[j] = k < len ? src[k] : 0u;
+            }
+#pragma unroll
+            for (int j = 0; j < LB; ++j) {
+                const bool ok = k0 + j * 64 + lane < len;
+                const uint32_t at = dm_wave_agg_add(h, v[j] >> sh, ok);
+                if (PLACE && ok) {
+                    uint32_t idx = v[j] & idxmask, e = ((v[j] >> idx_bits) & 1u) << 31;
+                    if (idx >= n_pts) {
+                        idx -= n_pts;
+                        e |= ENT_ENDO;
+                    }
+                    out[at] = e | idx;
+                }
+            }
+        }
+    }
+}
+
 // level 2, one workgroup per partition (w, pl).  Key k of the partition (k < total) lives in tile t with
 // rpre[t] <= k < rpre[t + 1]; runs are nearly equal, so t is guessed from k and corrected by a step or two.
 // (waves_per_eu 6: PER = 16 then fits 66 VGPRs without scratch — three workgroups per CU alone, two beside the row / column sums)
@@ -919,7 +989,8 @@ __global__ void __launch_bounds__(DM_TB2) __attribute__((amdgpu_waves_per_eu(6, 
     __shared__ uint32_t rpre[DM_MAX_TILES + 8];         // run lengths, then their exclusive scan
     constexpr int DM_STAGE = PER * DM_TB2;
     __shared__ __attribute__((aligned(16))) uint32_t stage[DM_STAGE];
-    const uint32_t p = blockIdx.x, w = p / dp.ppw, pl = p - w * dp.ppw;
+    // last window first: its partitions are the long ones (14 bits: four times the keys), they should not be the kernel's tail
+    const uint32_t p = gridDim.x - 1u - blockIdx.x, w = p / dp.ppw, pl = p - w * dp.ppw;
     const int tid = threadIdx.x;
     const uint32_t start = pstart[p], total = pstart[p + 1] - start;
     for (uint32_t b = tid; b <= dp.SB; b += TB) h[b] = 0;
@@ -967,17 +1038,41 @@ __global__ void __launch_bounds__(DM_TB2) __attribute__((amdgpu_waves_per_eu(6, 
         for (uint32_t k = tid; k < total; k += TB) entries[start + k] = stage[k];
         return;
     }
-    // over-long partition (skewed scalars: it does not fit the stage): count, scan, place straight into entries[]
-    for (uint32_t k = tid; k < total; k += TB) atomicAdd(&h[*locate(k) >> sh], 1u);
+    if (total <= 8u * (uint32_t)DM_STAGE) {
+        // over-long partition with buckets still spread (the top window's: its 14 bits give four times the keys per
+        // bucket): count, scan, place straight into entries[]
+        constexpr int MB = 4;   // keys per thread in flight
+        for (uint32_t k0 = tid; k0 < total; k0 += MB * TB) {
+            uint32_t v[MB];
+#pragma unroll
+            for (int j = 0; j < MB; ++j) v[j] = k0 + j * TB < total ? *locate(k0 + j * TB) : 0u;
+#pragma unroll
+            for (int j = 0; j < MB; ++j)
+                if (k0 + j * TB < total) atomicAdd(&h[v[j] >> sh], 1u);
+        }
+        __syncthreads();
+        for (uint32_t b = tid; b < dp.SB; b += TB) hist[key0 + b] = h[b];
+        dm_block_scan(h, dp.SB);
+        for (uint32_t b = tid; b < dp.SB; b += TB) offs[key0 + b] = start + h[b];
+        __syncthreads();
+        for (uint32_t k0 = tid; k0 < total; k0 += MB * TB) {
+            uint32_t v[MB];
+#pragma unroll
+            for (int j = 0; j < MB; ++j) v[j] = k0 + j * TB < total ? *locate(k0 + j * TB) : 0u;
+#pragma unroll
+            for (int j = 0; j < MB; ++j)
+                if (k0 + j * TB < total) entries[start + atomicAdd(&h[v[j] >> sh], 1u)] = dm_entry(v[j], dp, idxmask);
+        }
+        return;
+    }
+    // more than eight stages: skewed scalars (dm_long_pass)
+    dm_long_pass<false>(rowp, (const lds_u32*)rstart, (const lds_u32*)rpre, (lds_u32*)h, nullptr, dp.ntile, dp.idx_bits, dp.n_pts);
     __syncthreads();
     for (uint32_t b = tid; b < dp.SB; b += TB) hist[key0 + b] = h[b];
     dm_block_scan(h, dp.SB);
     for (uint32_t b = tid; b < dp.SB; b += TB) offs[key0 + b] = start + h[b];
     __syncthreads();
-    for (uint32_t k = tid; k < total; k += TB) {
-        const uint32_t v = *locate(k);
-        entries[start + atomicAdd(&h[v >> sh], 1u)] = dm_entry(v, dp, idxmask);
-    }
+    dm_long_pass<true>(rowp, (const lds_u32*)rstart, (const lds_u32*)rpre, (lds_u32*)h, entries + start, dp.ntile, dp.idx_bits, dp.n_pts);
 }
 
 // ------------------------------------------------------------------ order buckets by length (descending)

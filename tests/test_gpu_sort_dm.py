@@ -91,6 +91,26 @@ def test_skewed_partitions(eng):
     _run(eng, ks, [s % R for s in ss])
 
 
+@pytest.mark.parametrize("frac", [1.0, 0.5, 0.05])
+def test_equal_scalars(eng, frac):
+    """all / half / a twentieth of the scalars equal: one bucket per window holds that share of the row — the skew pass of
+    level 2 (dm_long_pass: tile-major, wave-aggregated slots) and the over-long-bucket kernels; under GLV the two halves
+    of the split put their runs in opposite halves of the row"""
+    n = (1 << 18) + 333
+    ks, rnd = _rand(n, 31), _rand(n, 32)
+    m = int(n * frac)
+    _run(eng, ks, [rnd[0] if i < m else rnd[i] for i in range(n)])
+
+
+def test_moderately_long_partitions(eng):
+    """digits confined to a sixteenth of the range in every window: partitions two to eight stages long with spread
+    buckets (the path the top window's partitions take on random scalars)"""
+    n = 1 << 18
+    ks, rnd = _rand(n, 33), _rand(n, 34)
+    mask = sum(0x0fff << (16 * w) for w in range(16))
+    _run(eng, ks, [(r & mask) % R for r in rnd])
+
+
 def test_reduction_paths_agree(eng):
     """16-bit windows take the two-dimensional bucket reduction (k_msm_reduce2d_*); an explicit reduce_segment keeps the
     segment kernels: same bytes, with and without GLV (8 / 16 windows), one MSM after another on rotating tail slots"""
