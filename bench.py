@@ -354,6 +354,9 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="run the Horner tail in-stream (latency mode)")
     ap.add_argument("--overlap-level", type=int, default=2, help="1: only the Horner tail overlaps; 2: + bucket reduction")
     ap.add_argument("--agg-proofs", type=int, default=4, help="proofs per GPU in the aggregation leg (0 = skip)")
+    ap.add_argument("--secondary-timeout", type=int, default=420,
+                    help="seconds the legs after the headline measurement (aggregation, PCIe, CPU baseline) may take before "
+                         "the headline-only line is printed and the process ends")
     ap.add_argument("--agg-commitments", type=int, default=300, help="advice commitments per synthetic proof")
     ap.add_argument("--no-fixed-base", action="store_true",
                     help="do not precompute fixed-base levels for the g_lagrange stand-in (h2agg_bases_precompute)")
@@ -486,29 +489,7 @@ def main():
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
     dt_max = float(t_all.item())
 
-    agg_info = None
-    if args.agg_proofs > 0:
-        g_table = None
-        if args.agg_instance_log2:     # stands in for ParamsKZG.g_lagrange: the SAME table on every rank
-            gen = torch.Generator(device="cpu").manual_seed(0x6C61)
-            gk = torch.randint(0, 256, (1 << args.agg_instance_log2, 32), dtype=torch.uint8, generator=gen)
-            gk[:, 31] &= 0x1F
-            gk = gk.to(dev)
-            g_table = eng.bases_generate(gk.data_ptr(), 1 << args.agg_instance_log2)
-            if args.agg_instance_log2 <= 18 and not args.no_fixed_base:
-                eng.bases_precompute(g_table)          # g_lagrange is fixed per circuit size: one-off SRS-style setup
-        agg_info = aggregation_leg(pkg, eng, args, rank, world, dist, (dev, coll_dev), g_table)  # configs[2]/[3]: 4 proofs per GPU
-        big = argparse.Namespace(**vars(args))
-        big.agg_proofs = 4 * args.agg_proofs                                       # configs[4]: 16 proofs per GPU
-        more = None
-        if args.agg_instance_log2 < 20:     # (a config-5 run, --agg-proofs 16 --agg-instance-log2 22, is one leg only)
-            more = aggregation_leg(pkg, eng, big, rank, world, dist, (dev, coll_dev), g_table)
-        if agg_info is not None and more is not None:
-            agg_info["at_%d_proofs_per_gpu" % big.agg_proofs] = {
-                k: more[k] for k in ("proofs_per_sec", "proofs", "seconds_per_aggregation")}
-        if agg_info is not None and world == 1 and g_table is not None and args.agg_instance_log2 <= 18:
-            agg_info["full_pipeline"] = full_pipeline_leg(pkg, eng, args, g_table)
-
+    out = None
     if rank == 0:
         stages = stages_all
         dom_ms, dom_cnt = eng.profile_stages()[dom_name]          # measured inside the timed region
@@ -564,93 +545,149 @@ def main():
                                "the timed region only the dominant kernel is bracketed (avg_kernel_ms)",
             },
         }
+    # ---- secondary legs.  The headline line above is complete; nothing below may cost it: an exception becomes an
+    # "error" entry, and a watchdog thread (it runs while the main thread is blocked inside a collective or a C call)
+    # prints the headline-only line and ends the process if the legs have not finished after --secondary-timeout seconds
+    # (the RCCL exchange of the aggregation leg has only ever run with one-rank communicators before the driver's runs).
+    import threading
+    printed = threading.Event()
+
+    def emit(extra=None):
+        if rank == 0 and not printed.is_set():
+            printed.set()
+            if extra:
+                out.update(extra)
+            print(json.dumps(out), flush=True)
+
+    def on_timeout():
+        emit({"secondary_leg_error": "the legs after the headline measurement did not finish within %d s" % args.secondary_timeout})
+        os._exit(0)
+
+    watchdog = threading.Timer(args.secondary_timeout, on_timeout)
+    watchdog.daemon = True
+    watchdog.start()
+    agg_info = None
+    try:
+        if args.agg_proofs > 0:
+            g_table = None
+            if args.agg_instance_log2:     # stands in for ParamsKZG.g_lagrange: the SAME table on every rank
+                gen = torch.Generator(device="cpu").manual_seed(0x6C61)
+                gk = torch.randint(0, 256, (1 << args.agg_instance_log2, 32), dtype=torch.uint8, generator=gen)
+                gk[:, 31] &= 0x1F
+                gk = gk.to(dev)
+                g_table = eng.bases_generate(gk.data_ptr(), 1 << args.agg_instance_log2)
+                if args.agg_instance_log2 <= 18 and not args.no_fixed_base:
+                    eng.bases_precompute(g_table)          # g_lagrange is fixed per circuit size: one-off SRS-style setup
+            agg_info = aggregation_leg(pkg, eng, args, rank, world, dist, (dev, coll_dev), g_table)  # configs[2]/[3]: 4 proofs per GPU
+            big = argparse.Namespace(**vars(args))
+            big.agg_proofs = 4 * args.agg_proofs                                       # configs[4]: 16 proofs per GPU
+            more = None
+            if args.agg_instance_log2 < 20:     # (a config-5 run, --agg-proofs 16 --agg-instance-log2 22, is one leg only)
+                more = aggregation_leg(pkg, eng, big, rank, world, dist, (dev, coll_dev), g_table)
+            if agg_info is not None and more is not None:
+                agg_info["at_%d_proofs_per_gpu" % big.agg_proofs] = {
+                    k: more[k] for k in ("proofs_per_sec", "proofs", "seconds_per_aggregation")}
+            if agg_info is not None and world == 1 and g_table is not None and args.agg_instance_log2 <= 18:
+                agg_info["full_pipeline"] = full_pipeline_leg(pkg, eng, args, g_table)
+
+    except Exception as ex:          # noqa: BLE001 - the headline must survive any failure of a secondary leg
+        import traceback
+        traceback.print_exc()
+        agg_info = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
+    if rank == 0:
         if agg_info is not None:
             out["aggregate"] = agg_info
-        if world == 1 and not args.no_pcie_leg:
-            # PCIe-inclusive rate: what a host that hands over HOST buffers sees (the drop-in's multi_exp call marshals
-            # points / scalars into page-locked buffers from h2agg_host_alloc): h2agg_g1_msm, 96 B/point over PCIe per
-            # call, bases converted to Montgomery form on the device, slices crossing PCIe under the previous slice's
-            # compute.  Never `value` (inputs resident in HBM), reported beside it.
-            import ctypes
-            hb = eng.host_alloc(64 * n)
-            hs = eng.host_alloc(32 * n)
-            try:
-                ctypes.memmove(hb, eng.bases_download(table, 0, n), 64 * n)
-                ctypes.memmove(hs, bytes(s_np.tobytes()), 32 * n)
-                eng.msm_set_tail_overlap(0)
-                r0 = eng.g1_msm(hb, hs, n)
-                t0 = time.perf_counter()
-                reps_h = 5
-                for _ in range(reps_h):
-                    r1 = eng.g1_msm(hb, hs, n)
-                t_h = (time.perf_counter() - t0) / reps_h
-                same = eng.g1_batch_to_affine(r1) == eng.g1_batch_to_affine(bytes(d_out[0].cpu().numpy().tobytes()))
-            finally:
-                eng.host_free(hb)
-                eng.host_free(hs)
-                if not args.no_overlap:
-                    eng.msm_set_tail_overlap(args.overlap_level)
-            out["pcie_inclusive"] = {"value": n / t_h, "unit": "points/s", "ms_per_msm": t_h * 1e3, "matches_resident": same,
-                                     "note": "h2agg_g1_msm from page-locked host buffers, synchronous call, 96 B/point "
-                                             "host->device per call (not `value`: that one has inputs resident in HBM)"}
-        if world == 1 and not args.no_cpu_baseline:
-            import shutil
-            import subprocess
-            tool = {}
-            for exe in ("cargo", "rustc"):                      # probe, do not assume
-                path = shutil.which(exe)
-                ver = None
-                if path:
-                    try:
-                        ver = subprocess.run([path, "--version"], capture_output=True, text=True, timeout=20).stdout.strip()
-                    except (OSError, subprocess.SubprocessError):
-                        ver = "present but not runnable"
-                tool[exe] = ver
-            ref_note = ("cargo / rustc probed on this box: %s — the reference (Rust nightly-2022-08-23 + unvendored git "
-                        "dependencies, no network) cannot run here" % (
-                            ", ".join("%s: %s" % (k, v or "not found") for k, v in tool.items())))
-            sample = min(args.cpu_sample, n)
-            bases_aff = eng.bases_download(table, 0, sample)
-            rate, secs, cpu_out = cpu_baseline(bases_aff, bytes(s_np[:sample].tobytes()), sample)
-            gpu_same = eng.g1_batch_to_affine(eng.g1_msm_preloaded(table, bytes(s_np[:sample].tobytes())))
-            out["cpu_baseline"] = {
-                "value": rate,
-                "unit": "points/s",
-                "cores": 1,
-                "kind": "port",
-                "sample": "first %d points of the same workload, oracle/bn254_ref.c oracle_multi_exp_naive "
-                          "(restated reference algorithm: n double-and-add scalar muls, 1 thread), %.1f s; "
-                          "host shows %d logical CPUs, %d usable under the container's CPU quota; %s" % (
-                              sample, secs, usable_cores()[0], usable_cores()[2], ref_note),
-                "reference_toolchain": tool,
-                "matches_gpu": cpu_out == gpu_same,
-            }
-            # BASELINE.md "B1": not the reference's algorithm — a multi-threaded CPU Pippenger (oracle/) on the FULL
-            # workload and on ALL host cores ((window, point-range) jobs from a shared counter), so the headline is not only
-            # compared with the naive loop
-            from oracle import cref
-            full_bases = eng.bases_download(table, 0, n)
-            logical, quota, usable = usable_cores()
-            out["cpu_baseline"]["host"] = {"logical_cpus": logical, "cgroup_cpu_quota_cores": quota, "usable_cores": usable}
-            gpu_aff = eng.g1_batch_to_affine(bytes(d_out[0].cpu().numpy().tobytes()))
-            tries = []
-            for c_cpu, threads in ((16, usable), (13, 2 * usable), (13, logical)):   # best of: one window per core / finer jobs / every logical CPU
-                t0 = time.perf_counter()
-                b1 = cref.msm_pippenger(full_bases, bytes(s_np.tobytes()), n, c_cpu, threads)
-                tries.append({"window_bits": c_cpu, "threads": threads, "seconds": time.perf_counter() - t0,
-                              "matches_gpu": b1 == gpu_aff})
-            best = min(tries, key=lambda t: t["seconds"])
-            out["cpu_baseline"]["fair_cpu_pippenger"] = {
-                "value": n / best["seconds"], "unit": "points/s", "threads": best["threads"], "seconds": best["seconds"],
-                "matches_gpu": all(t["matches_gpu"] for t in tries), "tried": tries,
-                "note": "oracle_msm_pippenger on ALL the cores this container may use (%d: %d logical CPUs under a cgroup "
-                        "quota of %s), (window, point-range) jobs from a shared counter, full 2^%d points, 4 x 64-bit "
-                        "Montgomery + Jacobian mixed additions; the best of the configurations tried; NOT the reference "
-                        "algorithm" % (usable, logical, quota, args.log2n),
-            }
-        print(json.dumps(out))
+        try:
+            if world == 1 and not args.no_pcie_leg:
+                # PCIe-inclusive rate: what a host that hands over HOST buffers sees (the drop-in's multi_exp call marshals
+                # points / scalars into page-locked buffers from h2agg_host_alloc): h2agg_g1_msm, 96 B/point over PCIe per
+                # call, bases converted to Montgomery form on the device, slices crossing PCIe under the previous slice's
+                # compute.  Never `value` (inputs resident in HBM), reported beside it.
+                import ctypes
+                hb = eng.host_alloc(64 * n)
+                hs = eng.host_alloc(32 * n)
+                try:
+                    ctypes.memmove(hb, eng.bases_download(table, 0, n), 64 * n)
+                    ctypes.memmove(hs, bytes(s_np.tobytes()), 32 * n)
+                    eng.msm_set_tail_overlap(0)
+                    r0 = eng.g1_msm(hb, hs, n)
+                    t0 = time.perf_counter()
+                    reps_h = 5
+                    for _ in range(reps_h):
+                        r1 = eng.g1_msm(hb, hs, n)
+                    t_h = (time.perf_counter() - t0) / reps_h
+                    same = eng.g1_batch_to_affine(r1) == eng.g1_batch_to_affine(bytes(d_out[0].cpu().numpy().tobytes()))
+                finally:
+                    eng.host_free(hb)
+                    eng.host_free(hs)
+                    if not args.no_overlap:
+                        eng.msm_set_tail_overlap(args.overlap_level)
+                out["pcie_inclusive"] = {"value": n / t_h, "unit": "points/s", "ms_per_msm": t_h * 1e3, "matches_resident": same,
+                                         "note": "h2agg_g1_msm from page-locked host buffers, synchronous call, 96 B/point "
+                                                 "host->device per call (not `value`: that one has inputs resident in HBM)"}
+            if world == 1 and not args.no_cpu_baseline:
+                import shutil
+                import subprocess
+                tool = {}
+                for exe in ("cargo", "rustc"):                      # probe, do not assume
+                    path = shutil.which(exe)
+                    ver = None
+                    if path:
+                        try:
+                            ver = subprocess.run([path, "--version"], capture_output=True, text=True, timeout=20).stdout.strip()
+                        except (OSError, subprocess.SubprocessError):
+                            ver = "present but not runnable"
+                    tool[exe] = ver
+                ref_note = ("cargo / rustc probed on this box: %s — the reference (Rust nightly-2022-08-23 + unvendored git "
+                            "dependencies, no network) cannot run here" % (
+                                ", ".join("%s: %s" % (k, v or "not found") for k, v in tool.items())))
+                sample = min(args.cpu_sample, n)
+                bases_aff = eng.bases_download(table, 0, sample)
+                rate, secs, cpu_out = cpu_baseline(bases_aff, bytes(s_np[:sample].tobytes()), sample)
+                gpu_same = eng.g1_batch_to_affine(eng.g1_msm_preloaded(table, bytes(s_np[:sample].tobytes())))
+                out["cpu_baseline"] = {
+                    "value": rate,
+                    "unit": "points/s",
+                    "cores": 1,
+                    "kind": "port",
+                    "sample": "first %d points of the same workload, oracle/bn254_ref.c oracle_multi_exp_naive "
+                              "(restated reference algorithm: n double-and-add scalar muls, 1 thread), %.1f s; "
+                              "host shows %d logical CPUs, %d usable under the container's CPU quota; %s" % (
+                                  sample, secs, usable_cores()[0], usable_cores()[2], ref_note),
+                    "reference_toolchain": tool,
+                    "matches_gpu": cpu_out == gpu_same,
+                }
+                # BASELINE.md "B1": not the reference's algorithm — a multi-threaded CPU Pippenger (oracle/) on the FULL
+                # workload and on ALL host cores ((window, point-range) jobs from a shared counter), so the headline is not only
+                # compared with the naive loop
+                from oracle import cref
+                full_bases = eng.bases_download(table, 0, n)
+                logical, quota, usable = usable_cores()
+                out["cpu_baseline"]["host"] = {"logical_cpus": logical, "cgroup_cpu_quota_cores": quota, "usable_cores": usable}
+                gpu_aff = eng.g1_batch_to_affine(bytes(d_out[0].cpu().numpy().tobytes()))
+                tries = []
+                for c_cpu, threads in ((16, usable), (13, 2 * usable), (13, logical)):   # best of: one window per core / finer jobs / every logical CPU
+                    t0 = time.perf_counter()
+                    b1 = cref.msm_pippenger(full_bases, bytes(s_np.tobytes()), n, c_cpu, threads)
+                    tries.append({"window_bits": c_cpu, "threads": threads, "seconds": time.perf_counter() - t0,
+                                  "matches_gpu": b1 == gpu_aff})
+                best = min(tries, key=lambda t: t["seconds"])
+                out["cpu_baseline"]["fair_cpu_pippenger"] = {
+                    "value": n / best["seconds"], "unit": "points/s", "threads": best["threads"], "seconds": best["seconds"],
+                    "matches_gpu": all(t["matches_gpu"] for t in tries), "tried": tries,
+                    "note": "oracle_msm_pippenger on ALL the cores this container may use (%d: %d logical CPUs under a cgroup "
+                            "quota of %s), (window, point-range) jobs from a shared counter, full 2^%d points, 4 x 64-bit "
+                            "Montgomery + Jacobian mixed additions; the best of the configurations tried; NOT the reference "
+                            "algorithm" % (usable, logical, quota, args.log2n),
+                }
+        except Exception as ex:          # noqa: BLE001 - same rule: report, keep the headline
+            import traceback
+            traceback.print_exc()
+            out["secondary_leg_error"] = "%s: %s" % (type(ex).__name__, str(ex)[:300])
+        emit()
     if dist is not None:
         dist.destroy_process_group()
+    watchdog.cancel()
 
 
 if __name__ == "__main__":
