@@ -684,7 +684,11 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     // reduction, per-window sums, Horner tail.  In overlap mode it runs on one of the context's tail streams, under the
     // accumulation of the next MSM (launched from that MSM's call, behind its sort: `deferred_tail`); results are picked
     // up by join_tails().
-    static const int dbg_skip = getenv("H2AGG_DBG_SKIP") ? atoi(getenv("H2AGG_DBG_SKIP")) : 0;   // measurement only: 1 reduce, 2 + window sums, 4 + final
+#ifdef H2AGG_MEASURE_KNOBS   // timing experiments only (WRONG results): 1 skips the bucket reduction, 2 the window sums, 4 the Horner tail
+    static const int dbg_skip = getenv("H2AGG_DBG_SKIP") ? atoi(getenv("H2AGG_DBG_SKIP")) : 0;
+#else
+    constexpr int dbg_skip = 0;   // (a shipped library has no switch that changes results)
+#endif
     // two-dimensional bucket reduction for 16-bit windows (msm_kernels.hpp); H2AGG_REDUCE=segments keeps the segment kernels
     static const bool r2d_env_off = getenv("H2AGG_REDUCE") && !strcmp(getenv("H2AGG_REDUCE"), "segments");
     const bool r2d = !r2d_env_off && !c->cfg_seg && !pre && p.NB == (uint32_t)(R2D_ROWS * R2D_COLS);

@@ -1,6 +1,7 @@
 """timing only (no verification): K asynchronous 2^log2n-point MSMs in overlap mode, three repetitions.
     python tools/steps_time.py [log2n] [K] [bracket the accumulation with events: 0|1]
-Used with H2AGG_DBG_SKIP=1|3|7 (skip bucket reduction / + window sums / + Horner tail: WRONG results, timing only) to price the tails."""
+Used with H2AGG_DBG_SKIP=1|3|7 (skip bucket reduction / + window sums / + Horner tail: WRONG results, timing only; needs a
+library built with -DH2AGG_MEASURE_KNOBS) to price the tails."""
 import sys, time, numpy as np, torch
 sys.path.insert(0, '.')
 import __graft_entry__ as e
