@@ -211,12 +211,15 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
             proof, q0 = syn.build_proof(b, mo.MultiOpenProof, specs[i])
             first.append(q0)
             out.append(proof)
-        if n_inst and idx:
-            aff = eng.g1_batch_to_affine_device(d_inst_out.data_ptr(), len(idx))
-            for j, q in enumerate(first):
-                b.query_set_commitment(q, aff[64 * j:64 * j + 64])
-                last_commits[idx[j]] = aff[64 * j:64 * j + 64]
-        return out
+        def finish():
+            # called after the fold is built and the evaluation's host half is done (h2agg_evaluate_multiopen_prepare):
+            # only now wait for the instance commitments and patch them into the first query of every proof
+            if n_inst and idx:
+                aff = eng.g1_batch_to_affine_device(d_inst_out.data_ptr(), len(idx))
+                for j, q in enumerate(first):
+                    b.query_set_commitment(q, aff[64 * j:64 * j + 64])
+                    last_commits[idx[j]] = aff[64 * j:64 * j + 64]
+        return out, finish
 
     pair = agg.aggregate_sharded(backend, build, n_total, lam, dist=dist, device=coll_dev, comm=comm,
                                  rank_world=(rank, world))     # warm-up

@@ -110,6 +110,7 @@ def load_library():
                                                 C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
         "h2agg_schema_eval": (i32, [C.c_void_p, C.c_uint32, vp, C.POINTER(i32), vp]),
         "h2agg_evaluate_multiopen_proof": (i32, [C.c_void_p, C.c_uint32, C.c_uint32, vp, vp]),
+        "h2agg_evaluate_multiopen_prepare": (i32, [C.c_void_p, C.c_uint32, C.c_uint32]),
         "h2agg_schema_name_count": (C.c_size_t, [C.c_void_p]),
         "h2agg_schema_name": (C.c_char_p, [C.c_void_p, C.c_size_t]),
         "h2agg_g1_msm_device_batch_async": (C.c_int, [C.c_void_p, C.c_uint64, C.c_void_p, C.c_size_t, C.c_size_t, C.c_void_p]),
@@ -665,6 +666,11 @@ class SchemaBuilder:
         left, right = C.create_string_buffer(64), C.create_string_buffer(64)
         self.eng._check(self._lib.h2agg_evaluate_multiopen_proof(self._s, w_x.node, w_g.node, left, right))
         return left.raw, right.raw, self.names()
+
+    def evaluate_multiopen_prepare(self, w_x: "EvaluationQuerySchema", w_g: "EvaluationQuerySchema"):
+        """the host half of evaluate_multiopen_proof(w_x, w_g) ahead of time (no device work): commitments may still be
+        replaced (query_set_commitment) before the evaluation itself"""
+        self.eng._check(self._lib.h2agg_evaluate_multiopen_prepare(self._s, w_x.node, w_g.node))
 
     def names(self):
         need = self._lib.h2agg_schema_names_joined(self._s, None, 0)

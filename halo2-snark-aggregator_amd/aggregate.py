@@ -103,6 +103,10 @@ class GpuBackend:
     def new_builder(self):
         return self.pkg.SchemaBuilder(self.eng)
 
+    def prepare(self, b, proof: MultiOpenProof):
+        """host half of evaluate() ahead of time (h2agg_evaluate_multiopen_prepare): no device work, no wait"""
+        b.evaluate_multiopen_prepare(proof.w_x, proof.w_g)
+
     def evaluate(self, b, proof: MultiOpenProof):
         left, right, _names = b.evaluate_multiopen_proof(proof.w_x, proof.w_g)
         return left, right
@@ -121,7 +125,10 @@ def aggregate_sharded(backend, build_local_proofs, n_total: int, lam: bytes, dis
                       rank_world=None):
     """Returns the final pair (left_aff, right_aff), identical on every rank.
 
-    build_local_proofs(builder, indices) -> list of MultiOpenProof for those global proof indices.
+    build_local_proofs(builder, indices) -> list of MultiOpenProof for those global proof indices, or (list, finish):
+          `finish()` is then called once the fold is built and the evaluation's host half is done (backend.prepare),
+          right before the evaluation — the place to wait for commitments the device is still computing and to patch
+          them in (query_set_commitment).
     dist: torch.distributed (initialised) or None for a single process.
     comm: an H2Agg engine holding an RCCL communicator (comm_init_rank): the exchange then happens INSIDE the C ABI
           (h2agg_allgather_add_points: all-gather over RCCL + local EC adds) — what a non-Python host binds; rank / world
@@ -134,8 +141,13 @@ def aggregate_sharded(backend, build_local_proofs, n_total: int, lam: bytes, dis
         rank = dist.get_rank() if dist is not None else 0
     idx = shard_indices(n_total, world, rank)
     b = backend.new_builder()
-    proofs = build_local_proofs(b, idx)
+    built = build_local_proofs(b, idx)
+    proofs, finish = built if isinstance(built, tuple) else (built, None)
     local = local_weighted_proof(b, proofs, idx, n_total, lam)
+    if local is not None and finish is not None and hasattr(backend, "prepare"):
+        backend.prepare(b, local)
+    if finish is not None:
+        finish()
     if local is None:
         left, right = IDENTITY_AFF, IDENTITY_AFF
     else:

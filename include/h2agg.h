@@ -226,6 +226,14 @@ int h2agg_schema_eval(h2agg_schema* s, uint32_t node, uint8_t out_jac[96], int* 
  * (halo2-snark-aggregator-circuit/src/fs.rs:187-190). */
 int h2agg_evaluate_multiopen_proof(h2agg_schema* s, uint32_t w_x, uint32_t w_g, uint8_t left_aff[64],
                                    uint8_t right_aff[64]);
+/* The host half of h2agg_evaluate_multiopen_proof(s, w_x, w_g, ...) done ahead of time: both eval_prepare walks
+ * (evaluation.rs:207-330) recorded on the Fr tape and the tape ordered by dependency level — no device work, no wait.
+ * A following h2agg_evaluate_multiopen_proof with the same roots on an otherwise unchanged schema starts at the upload.
+ * Commitment POINTS may still be replaced in between (h2agg_schema_query_set_commitment: the evaluation reads them
+ * when it runs), so a host can prepare while the device is still computing the instance commitments (verify.rs:574-649).
+ * Any other change to the schema (new nodes, another eval) simply makes the evaluation do its own host half again.
+ * Same errors as the evaluation would report for the host half (H2AGG_ERR_INVALID, H2AGG_ERR_EMPTY). */
+int h2agg_evaluate_multiopen_prepare(h2agg_schema* s, uint32_t w_x, uint32_t w_g);
 /* names returned by the last eval (evaluation.rs:183) / points_wx ++ points_wg (verify.rs:711-712), and the
  * length MockChipCtx::point_list would have after the last multi_exp (mock/arith/ecc.rs:112-116). */
 size_t h2agg_schema_name_count(h2agg_schema* s);

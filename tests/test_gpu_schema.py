@@ -199,3 +199,71 @@ def test_random_schema_trees_vs_oracle(eng, pkg, seed):
     assert eng.g1_batch_to_affine(jac) == O.aff_to_bytes(want_p)
     assert b.point_list_len() == len(ctx.point_list)
     b.close()
+
+
+def test_evaluate_multiopen_prepare(eng, pkg):
+    """h2agg_evaluate_multiopen_prepare: the host half ahead of time.  Same pair and names as the plain call; a
+    commitment replaced BETWEEN prepare and the evaluation (the instance commitment the device was still computing) is
+    the one that counts; a schema changed after the prepare is evaluated from scratch; errors surface at prepare."""
+    rng = O.SplitMix64(0x9E9A)
+
+    def build(b, first_commit):
+        """two proofs folded with lambda; returns (acc_x, acc_g, first query node, oracle pair, oracle names)"""
+        got, want_proofs = [], []
+        q0 = None
+        r = O.SplitMix64(0x51DE)
+        for i in range(2):
+            key = "p%d" % i
+            x = r.fr()
+            rp = {0: x, 1: x * 5 % O.R}
+            rots = [0, 0, 1, 0, 1]
+            spec = [(rot, "%s_q%d" % (key, k), rp[rot], O.scalar_mul(r.fr(), O.G1), r.fr()) for k, rot in enumerate(rots)]
+            if i == 0:
+                spec[0] = spec[0][:3] + (first_commit,) + spec[0][4:]
+            w = [O.scalar_mul(r.fr(), O.G1) for _ in range(2)]
+            v, u = r.fr(), r.fr()
+            want_proofs.append(S.batch_multi_open_proofs(key, [S.evaluation_query(*q) for q in spec], w, v, u))
+            qn = b.evaluation_queries([k for _r, k, _z, _c, _e in spec], b"".join(O.aff_to_bytes(c) for *_x, c, _e in spec),
+                                      b"".join(O.fe_to_bytes(e) for *_x, e in spec))
+            if i == 0:
+                q0 = qn[0]
+            got.append(b.batch_multi_open(key, [rr for rr, *_x in spec], b"".join(O.fe_to_bytes(z) for _r, _k, z, _c, _e in spec),
+                                          qn, b"".join(O.aff_to_bytes(p) for p in w), O.fe_to_bytes(v), O.fe_to_bytes(u)))
+        lam = r.fr()
+        agg = S.aggregate_fold(want_proofs, lam)
+        want = S.evaluate_multiopen_proof(S.OracleCtx(), S.OracleFieldChip(), S.OracleEccChip(), agg)
+        lam_b = O.fe_to_bytes(lam)
+        acc_x, acc_g = got[0]
+        acc_x, acc_g = acc_x * b.scalar(lam_b) + got[1][0], acc_g * b.scalar(lam_b) + got[1][1]
+        return acc_x, acc_g, q0, S.final_pair_bytes(want[0], want[1]), want[2]
+
+    real, placeholder = O.scalar_mul(rng.fr(), O.G1), O.scalar_mul(rng.fr(), O.G1)
+    # 1. prepare, then evaluate: equal to the plain call
+    b1 = pkg.SchemaBuilder(eng)
+    ax, ag, _q0, want_pair, want_names = build(b1, real)
+    b1.evaluate_multiopen_prepare(ax, ag)
+    left, right, names = b1.evaluate_multiopen_proof(ax, ag)
+    assert left + right == want_pair and names == want_names
+    # ... and once more on the same schema (the first evaluation left the tape as the preparation found it)
+    left, right, names = b1.evaluate_multiopen_proof(ax, ag)
+    assert left + right == want_pair and names == want_names
+    # 2. built around a placeholder, prepared, THEN the real commitment patched in
+    b2 = pkg.SchemaBuilder(eng)
+    ax, ag, q0, _wrong_pair, _n = build(b2, placeholder)
+    b2.evaluate_multiopen_prepare(ax, ag)
+    b2.query_set_commitment(q0, O.aff_to_bytes(real))
+    left, right, names = b2.evaluate_multiopen_proof(ax, ag)
+    assert left + right == want_pair and names == want_names
+    # 3. the schema grows after the prepare: the evaluation of the NEW roots does its own host half
+    b3 = pkg.SchemaBuilder(eng)
+    ax, ag, _q0, _p, _n = build(b3, real)
+    b3.evaluate_multiopen_prepare(ax, ag)
+    two = b3.scalar(O.fe_to_bytes(2))
+    l2, r2, _ = b3.evaluate_multiopen_proof(ax * two, ag * two)
+    dbl = lambda aff: O.aff_to_bytes(O.add(O.aff_from_bytes(aff), O.aff_from_bytes(aff)))   # noqa: E731
+    assert l2 == dbl(want_pair[:64]) and r2 == dbl(want_pair[64:])
+    # 4. the host half's errors come out of prepare: a Mul of two commitment-carrying sides (evaluation.rs:282)
+    b4 = pkg.SchemaBuilder(eng)
+    cp = b4.commit(pkg.CommitQuery("a", O.aff_to_bytes(real)))
+    with pytest.raises(pkg.H2AggError):
+        b4.evaluate_multiopen_prepare(cp * cp, cp)
