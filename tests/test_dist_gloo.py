@@ -197,3 +197,38 @@ def test_shard_and_lambda_helpers():
         node = agg.lambda_power(b, O.fe_to_bytes(lam), e)
         out = node.eval_prepare(S.OracleCtx(), S.OracleFieldChip(), 1, None)
         assert len(out) == 1 and out[0][2] == pow(lam, e, O.R)
+
+
+def test_build_with_finish_callback_single_process():
+    """aggregate_sharded's (proofs, finish) form: the fold is built, the backend's prepare (if it has one) runs, THEN finish,
+    then the evaluation — the order bench.py relies on to patch late commitments (h2agg_schema_query_set_commitment) after
+    the evaluation's host half; same pair as the plain list form"""
+    import importlib
+    import __graft_entry__ as entry
+    entry.load_package()
+    agg = importlib.import_module(entry.PKG_NAME + ".aggregate")
+    mo = importlib.import_module(entry.PKG_NAME + ".multiopen")
+    from oracle import bn254 as O
+    n_total, lam = 3, 0xABCDEF0123456789 % O.R
+    order = []
+
+    class Backend(OracleBackend):
+        def prepare(self, b, proof):
+            order.append("prepare")
+
+        def evaluate(self, b, proof):
+            order.append("evaluate")
+            return OracleBackend.evaluate(self, b, proof)
+
+    backend = Backend()
+
+    def build(b, idx):
+        order.append("build")
+        return make_proofs(mo, backend, b, idx, n_total), lambda: order.append("finish")
+
+    pair = agg.aggregate_sharded(backend, build, n_total, O.fe_to_bytes(lam))
+    assert order == ["build", "prepare", "finish", "evaluate"]
+    assert pair[0] + pair[1] == reference_final_pair(n_total, lam)
+    plain = agg.aggregate_sharded(OracleBackend(), lambda b, idx: make_proofs(mo, backend, b, idx, n_total), n_total,
+                                  O.fe_to_bytes(lam))
+    assert plain == pair
