@@ -767,7 +767,9 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     };
     // deferral needs another MSM to carry it; a full per-stage profiling pass keeps every stage inside its own call
     static const bool defer_env_off = getenv("H2AGG_DEFER_TAILS") && !strcmp(getenv("H2AGG_DEFER_TAILS"), "0");
-    if (tails_off_stream && !defer_env_off && !(c->profiling && c->prof_only < 0)) {
+    // (and it only pays from 2^20 points on — measured, profiles/r02_sweeps.txt: below that the tail is a large share of the
+    // MSM and wants to start at once; the two multi_exps of an evaluation in particular)
+    if (tails_off_stream && !defer_env_off && !(c->profiling && c->prof_only < 0) && n >= ((size_t)1 << 20)) {
         c->deferred_tail = tail_fn;
     } else {
         TRY(tail_fn(false));

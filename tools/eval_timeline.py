@@ -1,0 +1,19 @@
+"""timeline of the LAST evaluate_multiopen_proof of a rocprofv3 --kernel-trace CSV directory (tools/agg_phases.py under
+rocprofv3 --kernel-trace --output-format csv -d DIR): python tools/eval_timeline.py DIR"""
+import csv, glob, sys
+rows = []
+for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]),
+                     r["Kernel_Name"].split("(")[0].replace("h2agg::", "").replace("void ", ""), r.get("Queue_Id", "?")))
+rows.sort()
+i1 = max(i for i, r in enumerate(rows) if r[2].startswith("k_eval_tail_affine2"))
+i0 = max(i for i, r in enumerate(rows[:i1]) if r[2].startswith("k_tape_load_consts"))
+t0 = rows[i0][0]
+busy_end, idle = t0, 0
+for s, e, n, q in rows[i0:i1 + 1]:
+    if s > busy_end:
+        idle += s - busy_end
+    busy_end = max(busy_end, e)
+    print("%8.1f %8.1f %7.1f q%-2s %s" % ((s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, q, n[:50]))
+print("span %.1f us, device idle inside it %.1f us" % ((rows[i1][1] - t0) / 1e3, idle / 1e3))
