@@ -391,8 +391,9 @@ int h2agg_msm_configure_sort(h2agg_ctx* ctx, int sub_bits, int tile);
  * sums + Horner; 3: as 2, and the bucket accumulation itself leaves the context's stream, so that the NEXT MSM's sort runs
  * under it — measured: a loss at 2^20 points (1.39 -> 1.55 ms per MSM: both kernels slow each other down), +3 % at 2^22) with the bulk kernels of the next ones: the tail runs on one of three tail streams of the context.  With overlap on, a result written by
  * h2agg_g1_msm_device_async is complete after h2agg_synchronize() (or after the next synchronous call on
- * the context), not merely after the caller's stream has drained: the tail of the LAST MSM queued is only launched by the next
- * call on the context (behind that MSM's sort, where it costs least) or by h2agg_synchronize().  Default: off. */
+ * the context), not merely after the caller's stream has drained: from 2^20 points on, the tail of the LAST MSM queued is only launched by
+ * the next call on the context (behind that MSM's sort, where it costs least) or by h2agg_synchronize(); smaller MSMs launch
+ * theirs at once (there the tail is a large share of the MSM: waiting costs more than the next sort gains).  Default: off. */
 int h2agg_msm_set_tail_overlap(h2agg_ctx* ctx, int enable);
 /* When enabled, every MSM stage is bracketed by HIP events on the context's stream and per-stage times
  * are accumulated.  enable: 0 = off, 1 = every stage, 2 + s = only stage s (one event pair per MSM: the event
