@@ -658,8 +658,12 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     // with alternating sort outputs they leave the bulk stream and go in front of the bucket reduction on the tail stream,
     // followed by the zeroing of this slot's counters for the MSM after next.
     const bool tail_big = altbuf && c->overlap_level >= 2 && lpb == 1;
+    // (no bucket can hold more keys than its bucket set receives: a multi_exp of a dozen points skips the two launches,
+    // ~35 us at the head of its tail)
+    const bool big_possible = nent / WT > p.big;
     auto big_kernels = [=](hipStream_t bs) {
         StageTimer t(c, ST_ACCUM_BIG, bs);
+        if (!big_possible && lpb == 1) return;
         size_t grid = max_slots;
         const size_t cap = (size_t)c->cu_count * 8;   // one-wave workgroups, grid-stride over the (usually empty) lists
         if (grid > cap) grid = cap;
