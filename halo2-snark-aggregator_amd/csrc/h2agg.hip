@@ -371,7 +371,8 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         p.W = 1;                              // one bucket set per MSM
         p.NB = 1u << (p.c - 1);
         p.NBT = batch * p.NB;
-        p.seg = c->cfg_seg ? (uint32_t)c->cfg_seg : 8u;
+        // measured (tools/instance_seg_sweep.py, 2^17-point columns): 16-bucket segments up to 8 MSMs per batch, 32 beyond
+        p.seg = c->cfg_seg ? (uint32_t)c->cfg_seg : (batch >= 16 ? 32u : 16u);
         if (p.seg > p.NB) p.seg = p.NB;
         p.spw = p.NB / p.seg;
         d_bases = pre->d;
