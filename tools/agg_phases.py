@@ -8,9 +8,11 @@ import __graft_entry__ as entry
 R_MOD = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 ap = argparse.ArgumentParser(); ap.add_argument("--proofs", type=int, default=4); ap.add_argument("--commitments", type=int, default=280)
 ap.add_argument("--reps", type=int, default=10); ap.add_argument("--overlap", type=int, default=2)
+ap.add_argument("--window", type=int, default=0, help="force the Pippenger window of every MSM (0 = the measured table)")
 args = ap.parse_args()
 pkg = entry.load_package(); eng = pkg.H2Agg(0)
 if args.overlap: eng.msm_set_tail_overlap(args.overlap)
+if args.window: eng.msm_configure(args.window, 0, 0)
 agg = importlib.import_module(entry.PKG_NAME + ".aggregate"); mo = importlib.import_module(entry.PKG_NAME + ".multiopen")
 rng = np.random.Generator(np.random.PCG64(1))
 fr = lambda: (int.from_bytes(rng.bytes(64), "little") % R_MOD).to_bytes(32, "little")
