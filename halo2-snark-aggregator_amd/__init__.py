@@ -128,6 +128,7 @@ def load_library():
         "h2agg_comm_create": (i32, [C.POINTER(i32), i32, C.POINTER(ctxp)]),
         "h2agg_comm_size": (i32, [ctxp]),
         "h2agg_comm_rank": (i32, [ctxp]),
+        "h2agg_comm_last_error": (C.c_char_p, []),
         "h2agg_allgather_add_points": (i32, [C.POINTER(ctxp), i32, u8p, sz, vp]),
         "h2agg_pairing_check": (i32, [ctxp, u8p, u8p, sz, C.POINTER(i32)]),
         "h2agg_g2_batch_decompress": (i32, [ctxp, u8p, sz, vp]),
@@ -434,7 +435,8 @@ class H2Agg:
         out = C.create_string_buffer(128)
         rc = load_library().h2agg_comm_unique_id(out)
         if rc != OK:
-            raise H2AggError(rc, "h2agg_comm_unique_id failed (RCCL not available?)")
+            why = load_library().h2agg_comm_last_error() or b""
+            raise H2AggError(rc, "h2agg_comm_unique_id failed: " + (why.decode(errors="replace") or "RCCL error"))
         return out.raw
 
     def comm_init_rank(self, unique_id: bytes, rank: int, nranks: int):
@@ -442,7 +444,12 @@ class H2Agg:
         self._check(self._lib.h2agg_comm_init_rank(self._ctx, unique_id, rank, nranks))
 
     def comm_size(self) -> int:
+        """ranks of this context's communicator (0 = none)"""
         return self._lib.h2agg_comm_size(self._ctx)
+
+    def comm_rank(self) -> int:
+        """this context's rank in its communicator (-1 = none)"""
+        return self._lib.h2agg_comm_rank(self._ctx)
 
     def allgather_add_points(self, partial_jac: bytes) -> bytes:
         """this rank's partial accumulators (96 B each) -> affine sums over all ranks (64 B each), same on every rank:

@@ -135,7 +135,15 @@ def aggregate_sharded(backend, build_local_proofs, n_total: int, lam: bytes, dis
           come from `rank_world` or, if that is None, from the communicator / dist."""
     if comm is not None:
         world = comm.comm_size()
-        rank = rank_world[0] if rank_world is not None else (dist.get_rank() if dist is not None else 0)
+        if world < 1:
+            raise ValueError("aggregate_sharded: `comm` holds no communicator (comm_init_rank was not called)")
+        # the communicator knows its own rank (h2agg_comm_rank); an explicit rank_world / dist must agree with it — every
+        # process silently taking shard 0 would sum `world` copies of it into a wrong pair (ADVICE r2)
+        rank = comm.comm_rank()
+        claimed = rank_world[0] if rank_world is not None else (dist.get_rank() if dist is not None else rank)
+        if rank < 0 or claimed != rank or (rank_world is not None and rank_world[1] != world):
+            raise ValueError("aggregate_sharded: rank/world (%r) disagree with the communicator's (%d, %d)"
+                             % (rank_world if rank_world is not None else claimed, rank, world))
     else:
         world = dist.get_world_size() if dist is not None else 1
         rank = dist.get_rank() if dist is not None else 0

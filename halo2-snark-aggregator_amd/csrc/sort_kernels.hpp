@@ -20,6 +20,14 @@
 
 namespace h2agg {
 
+// Experiment knob (A/B builds only): -DH2AGG_SORT_SETPRIO raises the issue priority of the sort's waves, so that beside the
+// VALU-saturating accumulation of the previous MSM (overlap level 3) their latency chains are served first.
+#ifdef H2AGG_SORT_SETPRIO
+#define SORT_PRIO() __builtin_amdgcn_s_setprio(3)
+#else
+#define SORT_PRIO() ((void)0)
+#endif
+
 constexpr int SORT_MAX_PW = 2048;   // partitions (LDS counters in level 1)
 constexpr int SORT_SUB_BITS = 9;    // default low bucket bits resolved in level 2 (tunable, <= 12; sweep: profiles/r01_sweeps.txt)
 constexpr int SORT_MAX_SUB_BITS = 12;
@@ -340,6 +348,7 @@ __global__ void __launch_bounds__(BLOCK) k_part_count(const uint8_t* __restrict_
 // cursor (optional) receives a copy of out[0..n)
 __global__ void __launch_bounds__(BLOCK) k_scan_small(const uint32_t* __restrict__ in, uint32_t n,
                                                       uint32_t* __restrict__ out, uint32_t* __restrict__ cursor) {
+    SORT_PRIO();
     __shared__ uint32_t lds[BLOCK];
     constexpr int PER = 2 * SORT_MAX_PW / BLOCK;  // 8
     const uint32_t base = threadIdx.x * PER;
@@ -716,6 +725,7 @@ constexpr int DM_DIG_PER = 8;   // scalars per thread: few, long-lived waves (wa
                                 // kernel of the previous MSM's tail shares the SIMDs: 113 us instead of 20 with one scalar each)
 __global__ void __launch_bounds__(BLOCK) k_dm_digits(const uint8_t* __restrict__ scalars, uint32_t n, uint32_t n_pad,
                                                      uint16_t* __restrict__ codes, uint32_t* flags) {
+    SORT_PRIO();
     const uint32_t i0 = blockIdx.x * (BLOCK * DM_DIG_PER) + threadIdx.x;
     U256 nxt;
     if (i0 < n) nxt = u256_load(scalars + 32 * (size_t)i0);
@@ -744,6 +754,7 @@ __global__ void __launch_bounds__(BLOCK) k_dm_digits(const uint8_t* __restrict__
 // windows; row w holds the first halves' digits at [0, n) and the second halves' at [n, 2n).
 __global__ void __launch_bounds__(BLOCK) k_dm_digits_glv(const uint8_t* __restrict__ words, uint32_t n, uint32_t n_pad,
                                                          uint16_t* __restrict__ codes) {
+    SORT_PRIO();
     const uint32_t i0 = blockIdx.x * (BLOCK * DM_DIG_PER) + threadIdx.x;
 #pragma unroll 1
     for (int k = 0; k < DM_DIG_PER; ++k) {
@@ -807,6 +818,7 @@ FP_INLINE void dm_block_scan(uint32_t* v, uint32_t cnt) {
 
 // out[i] = sum_{j<i} in[j] for i <= n (n <= DM_MAX_PW = 8192): one 1024-thread workgroup, 8 values per thread, wave scans
 __global__ void __launch_bounds__(1024) k_dm_scan(const uint32_t* __restrict__ in, uint32_t n, uint32_t* __restrict__ out) {
+    SORT_PRIO();
     __shared__ uint32_t wsum[16];
     const uint32_t tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     uint32_t x[8], sum = 0;
@@ -834,6 +846,7 @@ __global__ void __launch_bounds__(1024) k_dm_scan(const uint32_t* __restrict__ i
 __global__ void __launch_bounds__(DM_TB1) k_dm_partition(const uint16_t* __restrict__ codes, DmPlan dp,
                                                          uint32_t* __restrict__ pcount, uint32_t* __restrict__ toff,
                                                          uint32_t* __restrict__ items) {
+    SORT_PRIO();
     __shared__ uint32_t cnt[DM_MAX_PPW + 1];
     __shared__ __attribute__((aligned(16))) uint32_t stage[DM_T1];
     const uint32_t tile = blockIdx.x, w = blockIdx.y;
@@ -983,6 +996,7 @@ __global__ void __launch_bounds__(DM_TB2) __attribute__((amdgpu_waves_per_eu(6, 
                                                            const uint32_t* __restrict__ items, DmPlan dp, uint32_t NB,
                                                            uint32_t* __restrict__ hist, uint32_t* __restrict__ offs,
                                                            uint32_t* __restrict__ entries) {
+    SORT_PRIO();
     constexpr int TB = DM_TB2;
     __shared__ uint32_t h[DM_MAX_PPW + 8];              // [SB + 1]
     __shared__ uint32_t rstart[DM_MAX_TILES];
@@ -1080,6 +1094,7 @@ FP_INLINE uint32_t size_bin(uint32_t len) { return (SIZE_BINS - 1) - (len < SIZE
 
 __global__ void __launch_bounds__(BLOCK) k_size_count(const uint32_t* __restrict__ hist, uint32_t nbt,
                                                       uint32_t* __restrict__ bin_count) {
+    SORT_PRIO();
     __shared__ uint32_t cnt[SIZE_BINS];
     for (uint32_t b = threadIdx.x; b < SIZE_BINS; b += BLOCK) cnt[b] = 0;
     __syncthreads();
@@ -1091,6 +1106,7 @@ __global__ void __launch_bounds__(BLOCK) k_size_count(const uint32_t* __restrict
 }
 __global__ void __launch_bounds__(BLOCK) k_size_scatter(const uint32_t* __restrict__ hist, uint32_t nbt,
                                                         uint32_t* __restrict__ bin_cursor, uint32_t* __restrict__ order) {
+    SORT_PRIO();
     __shared__ uint32_t cnt[SIZE_BINS];
     __shared__ uint32_t baseb[SIZE_BINS];
     for (uint32_t b = threadIdx.x; b < SIZE_BINS; b += BLOCK) cnt[b] = 0;

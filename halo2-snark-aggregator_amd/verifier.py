@@ -86,6 +86,9 @@ class VerifyingKey:
         self._lib = eng._lib
         self._vk = C.c_void_p()
         eng._check(self._lib.h2agg_vk_create(eng._ctx, blob, len(blob), C.byref(self._vk)))
+        # header words of the accepted blob (include/h2agg.h): magic, version, k, num_advice, num_instance, ...
+        self.k, self.num_advice_columns, self.num_instance_columns = (
+            int.from_bytes(blob[8 + 4 * i:12 + 4 * i], "little") for i in range(3))
 
     def close(self):
         if self._vk:
@@ -111,7 +114,12 @@ def verify_aggregation(eng, circuits: Sequence[Tuple[VerifyingKey, str, int, Seq
         tr = (C.c_char_p * max(n, 1))(*[t for _cols, t in proofs])
         tl = (C.c_size_t * max(n, 1))(*[len(t) for _cols, t in proofs])
         inst = (C.c_char_p * max(n, 1))(*[b"".join(cols) for cols, _t in proofs])
-        ncol = len(proofs[0][0]) if proofs else 0
+        ncol = vk.num_instance_columns
+        for cols, _t in proofs:   # the C side indexes instance_lens[i * num_instance_columns + col]: no ragged input reaches it
+            if len(cols) != ncol:
+                raise ValueError("circuit %r: a proof carries %d instance columns, the verifying key has %d" % (name, len(cols), ncol))
+            if any(len(col) % 32 for col in cols):
+                raise ValueError("circuit %r: instance columns are 32 bytes per value" % name)
         lens = (C.c_uint32 * max(n * ncol, 1))(*[len(col) // 32 for cols, _t in proofs for col in cols])
         nm = name.encode()
         keep += [tr, tl, inst, lens, nm]

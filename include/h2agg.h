@@ -327,7 +327,10 @@ int h2agg_comm_unique_id(uint8_t out[128]);
 int h2agg_comm_init_rank(h2agg_ctx* ctx, const uint8_t id[128], int rank, int nranks);
 int h2agg_comm_create(const int* devices, int ndev, h2agg_ctx** ctxs_out);
 int h2agg_comm_size(h2agg_ctx* ctx);   /* 0 = no communicator */
-int h2agg_comm_rank(h2agg_ctx* ctx);
+int h2agg_comm_rank(h2agg_ctx* ctx);   /* -1 = no communicator */
+/* why the last context-less comm call failed (h2agg_comm_unique_id, or h2agg_comm_create before a context exists):
+ * e.g. the dlopen error of librccl.  Thread-local storage; valid until the thread's next call of this function. */
+const char* h2agg_comm_last_error(void);
 int h2agg_allgather_add_points(h2agg_ctx** ctxs, int nctx, const uint8_t* partial_jac, size_t npts, uint8_t* out_aff);
 
 /* ---- pairing check (host arithmetic, no device work) ---------------------------
