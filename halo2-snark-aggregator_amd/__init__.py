@@ -123,6 +123,10 @@ def load_library():
         "h2agg_vk_create": (i32, [ctxp, u8p, sz, C.POINTER(C.c_void_p)]),
         "h2agg_vk_destroy": (None, [C.c_void_p]),
         "h2agg_verify_aggregation": (i32, [ctxp, vp, sz, u8p, u8p, vp, vp, vp, C.POINTER(i32)]),   # see verifier.py
+        "h2agg_verify_aggregation_ex": (i32, [ctxp, vp, sz, u8p, u8p, vp, vp, vp, C.POINTER(i32), vp, sz]),
+        "h2agg_transcript_configure": (i32, [ctxp, i32]),
+        "h2agg_poseidon_squeeze_batch_host": (i32, [u8p, sz, sz, C.POINTER(C.c_uint32), sz, vp, i32]),
+        "h2agg_host_threads": (i32, []),
         "h2agg_comm_unique_id": (i32, [vp]),
         "h2agg_comm_init_rank": (i32, [ctxp, u8p, i32, i32]),
         "h2agg_comm_create": (i32, [C.POINTER(i32), i32, C.POINTER(ctxp)]),
@@ -411,6 +415,10 @@ class H2Agg:
         self._check(self._lib.h2agg_poseidon_squeeze_batch(self._ctx, elems, nproofs, nelem, arr, nsq, out))
         return out.raw[:32 * nproofs * nsq]
 
+    def transcript_configure(self, backend: str = "auto"):
+        """which backend runs the Poseidon sponges of this context: "auto" (by batch size), "device", "host" (worker threads)"""
+        self._check(self._lib.h2agg_transcript_configure(self._ctx, {"auto": 0, "device": 1, "host": 2}[backend]))
+
     def transcript_read_batch(self, proofs: Sequence[bytes], script: str, consts: bytes = b"", ext_points_aff: bytes = b""):
         """PoseidonTranscriptRead over same-layout proofs -> (points [proof] bytes, challenges [proof] bytes)"""
         nproofs = len(proofs)
@@ -534,6 +542,25 @@ class H2Agg:
             self._check(self._lib.h2agg_profile_stage_get(self._ctx, i, C.byref(ms), C.byref(cnt)))
             out[self._lib.h2agg_profile_stage_name(self._ctx, i).decode()] = (ms.value, cnt.value)
         return out
+
+
+def poseidon_squeeze_batch_host(elems: bytes, nproofs: int, upto: Sequence[int], max_threads: int = 0) -> bytes:
+    """the host backend of H2Agg.poseidon_squeeze_batch on its own (h2agg_poseidon_squeeze_batch_host: no context, no device)"""
+    lib = load_library()
+    nelem = (len(elems) // 32) // max(nproofs, 1)
+    _need(elems, 32 * nelem * nproofs, "elems")
+    nsq = len(upto)
+    arr = (C.c_uint32 * max(nsq, 1))(*upto)
+    out = C.create_string_buffer(32 * max(nproofs * nsq, 1))
+    rc = lib.h2agg_poseidon_squeeze_batch_host(elems, nproofs, nelem, arr, nsq, out, max_threads)
+    if rc != OK:
+        raise H2AggError(rc, "h2agg_poseidon_squeeze_batch_host: " + ("element >= r" if rc == ERR_NONCANONICAL else "invalid arguments"))
+    return out.raw[:32 * nproofs * nsq]
+
+
+def host_threads() -> int:
+    """worker threads the library may use for per-proof host work (h2agg_host_threads)"""
+    return load_library().h2agg_host_threads()
 
 
 class H2AggGroup:

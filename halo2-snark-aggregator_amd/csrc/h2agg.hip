@@ -10,7 +10,12 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <functional>
+#include <mutex>
+#include <thread>
+#include <sched.h>
 #include <map>
 #include <memory>
 #include <new>
@@ -20,6 +25,7 @@
 #include "scalar_mul_kernels.hpp"
 #include "pairing.hpp"
 #include "poseidon_host.hpp"
+#include "poseidon_sponge_host.hpp"
 #include "poseidon_kernels.hpp"
 
 using namespace h2agg;
@@ -79,6 +85,8 @@ struct h2agg_ctx {
     // decompressed points, element streams and challenges of the last transcript batch
     DevBuf psd_spec, tr_in, tr_points, tr_elems, tr_chal;
     bool psd_ready = false;
+    int cfg_transcript = 0;            // sponge backend: 0 = auto, 1 = device, 2 = host threads (h2agg_transcript_configure)
+    std::vector<uint8_t> h_elems;      // element streams downloaded for the host backend
     // verifier pipeline (csrc/verifier.inc): instance values / commitments of a circuit's proofs, the aggregation transcript
     DevBuf inst_vals, inst_jac, inst_aff, agg_elems;
     DevBuf hist[2], offs[2], pmeta[2], order[2], entries[2];   // what the accumulation reads: one set per sort slot (overlap level 3)
@@ -228,11 +236,14 @@ int flags_to_status(h2agg_ctx* c, uint32_t f, bool earlier) {
 }
 
 // synchronise and translate device status flags (this call's, then any left behind by earlier asynchronous calls)
-int finish(h2agg_ctx* c) {
+// host_flags: FLAG_* bits raised by host-side halves of the call (the host sponge's canonicity check): merged into the
+// call's device flags so that the order of precedence of the errors does not depend on where a check ran
+int finish(h2agg_ctx* c, uint32_t host_flags = 0) {
     HIP_TRY(c, hipMemcpyAsync(c->h_pinned + 2048, c->d_flags, 12, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     uint32_t f[3];
     memcpy(f, c->h_pinned + 2048, 12);
+    f[0] |= host_flags;
     if (f[0] | f[2]) HIP_TRY(c, hipMemsetAsync(c->d_flags, 0, 12, c->stream));   // reported once, here
     if (f[0]) return flags_to_status(c, f[0], false);
     return flags_to_status(c, f[2], true);

@@ -103,9 +103,10 @@ class VerifyingKey:
 
 
 def verify_aggregation(eng, circuits: Sequence[Tuple[VerifyingKey, str, int, Sequence[Tuple[Sequence[bytes], bytes]]]],
-                       s_g2: Optional[bytes] = None, g2: Optional[bytes] = None):
+                       s_g2: Optional[bytes] = None, g2: Optional[bytes] = None, with_commits: bool = False):
     """circuits: [(vk, name, g_lagrange_handle, [(instance columns as bytes (32 B per value), transcript bytes), ...])].
-    -> (left_aff, right_aff, lambda, pairing_ok or None)"""
+    -> (left_aff, right_aff, lambda, pairing_ok or None); with_commits: a fifth element, the advice commitments per proof
+    in aggregation order ([[64-byte affine point per advice column] per proof]: `commits` of verify.rs:852-856)"""
     lib = eng._lib
     arr = (_CircuitProofs * len(circuits))()
     keep = []
@@ -126,9 +127,17 @@ def verify_aggregation(eng, circuits: Sequence[Tuple[VerifyingKey, str, int, Seq
         arr[k] = _CircuitProofs(vk._vk, nm, g_lagrange, n, tr, tl, inst, lens)
     left, right, lam = C.create_string_buffer(64), C.create_string_buffer(64), C.create_string_buffer(32)
     ok = C.c_int(-1)
-    if s_g2 is not None:
-        rc = lib.h2agg_verify_aggregation(eng._ctx, C.cast(arr, C.c_void_p), len(circuits), s_g2, g2, left, right, lam, C.byref(ok))
-    else:
-        rc = lib.h2agg_verify_aggregation(eng._ctx, C.cast(arr, C.c_void_p), len(circuits), None, None, left, right, lam, None)
+    ncommit = [vk.num_advice_columns for vk, _n, _g, proofs in circuits for _p in proofs]
+    cap = 64 * sum(ncommit) if with_commits else 0
+    adv = C.create_string_buffer(max(cap, 1)) if with_commits else None
+    rc = lib.h2agg_verify_aggregation_ex(eng._ctx, C.cast(arr, C.c_void_p), len(circuits), s_g2, g2 if s_g2 is not None else None,
+                                         left, right, lam, C.byref(ok) if s_g2 is not None else None, adv, cap)
     eng._check(rc)
-    return left.raw, right.raw, lam.raw, (bool(ok.value) if s_g2 is not None else None)
+    res = (left.raw, right.raw, lam.raw, (bool(ok.value) if s_g2 is not None else None))
+    if not with_commits:
+        return res
+    commits, off = [], 0
+    for n in ncommit:
+        commits.append([adv.raw[off + 64 * j: off + 64 * (j + 1)] for j in range(n)])
+        off += 64 * n
+    return res + (commits,)

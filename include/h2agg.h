@@ -257,6 +257,17 @@ int h2agg_poseidon_squeeze_batch(h2agg_ctx* ctx, const uint8_t* elems, size_t np
  * proof_len must equal 32 x (number of 'P' and 'S'): the reader's read_exact.  points_out: [nproofs][#P] decoded points
  * (canonical affine); challenges_out: [nproofs][#Q].  A point that does not decode -> H2AGG_ERR_BAD_POINT ("invalid point
  * encoding in proof"), a scalar >= r -> H2AGG_ERR_NONCANONICAL ("invalid field element encoding in proof"). */
+/* The sponges are sequential chains (~136 permutations per proof): on the device a chain runs at one wave's latency whatever
+ * the batch, on a host core ~an order of magnitude faster — so small batches run on host threads (one proof per thread, the
+ * same generated constants, bit-identical challenges) and large ones on the device.  backend: 0 = auto (by batch size and
+ * usable host threads; environment H2AGG_TRANSCRIPT=device|host overrides), 1 = device, 2 = host.  Applies to
+ * h2agg_poseidon_squeeze_batch, h2agg_transcript_read_batch and h2agg_verify_aggregation(_ex) on this context.
+ * h2agg_poseidon_squeeze_batch_host: the host backend on its own (no context, no device): max_threads <= 0 = all usable.
+ * h2agg_host_threads: worker threads the library may use (affinity mask, cgroup CPU quota, H2AGG_HOST_THREADS; <= 32). */
+int h2agg_transcript_configure(h2agg_ctx* ctx, int backend);
+int h2agg_poseidon_squeeze_batch_host(const uint8_t* elems, size_t nproofs, size_t nelem, const uint32_t* upto, size_t nsq,
+                                      uint8_t* out, int max_threads);
+int h2agg_host_threads(void);
 int h2agg_transcript_read_batch(h2agg_ctx* ctx, const uint8_t* proofs, size_t proof_len, size_t nproofs, const char* script,
                                 size_t script_len, const uint8_t* consts, size_t nconsts, const uint8_t* ext_points_aff,
                                 size_t next, uint8_t* points_out, uint8_t* challenges_out);
@@ -309,6 +320,14 @@ typedef struct {
 int h2agg_verify_aggregation(h2agg_ctx* ctx, const h2agg_circuit_proofs* circuits, size_t ncircuits, const uint8_t* s_g2,
                              const uint8_t* g2, uint8_t left_aff[64], uint8_t right_aff[64], uint8_t lambda_out[32],
                              int* pairing_ok);
+/* as above, plus the fourth return value of verify_aggregation_proofs_in_chip (`commits`: every proof's advice
+ * commitments, halo2-snark-aggregator-api/src/systems/halo2/verify.rs:852-856,927-939, which the production caller hands to
+ * `coherent`, halo2-snark-aggregator-circuit/src/verify_circuit.rs:487-492): advice_out (optional) receives, in aggregation
+ * order, num_advice_columns x 64 B per proof (canonical affine, column order); advice_cap = bytes available (too small ->
+ * H2AGG_ERR_INVALID before any work). */
+int h2agg_verify_aggregation_ex(h2agg_ctx* ctx, const h2agg_circuit_proofs* circuits, size_t ncircuits, const uint8_t* s_g2,
+                                const uint8_t* g2, uint8_t left_aff[64], uint8_t right_aff[64], uint8_t lambda_out[32],
+                                int* pairing_ok, uint8_t* advice_out, size_t advice_cap);
 
 /* ---- multi-GPU exchange -----------------------------------------------------------
  * The one collective of a sharded aggregation: every rank holds partial accumulators (the sharded form of the fold

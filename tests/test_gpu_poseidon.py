@@ -50,6 +50,23 @@ def test_sponge_interleaved_squeezes(eng):
         assert got[128 * i:128 * i + 128] == fe(want), i
 
 
+def test_backends_agree(eng, pkg):
+    """device kernel == host worker threads, through the same entry point (h2agg_transcript_configure), and the automatic
+    choice returns the same bytes; the transcript reader likewise"""
+    rng = O.SplitMix64(0x90B)
+    nproofs = 9
+    rows = [[rng.fr() for _ in range(37)] for _ in range(nproofs)]
+    blob, upto = b"".join(fe(r) for r in rows), [0, 5, 16, 16, 37]
+    got = {}
+    try:
+        for be in ("device", "host", "auto"):
+            eng.transcript_configure(be)
+            got[be] = eng.poseidon_squeeze_batch(blob, nproofs, upto)
+    finally:
+        eng.transcript_configure("auto")
+    assert got["device"] == got["host"] == got["auto"] == pkg.poseidon_squeeze_batch_host(blob, nproofs, upto)
+
+
 def test_sponge_rejects_non_canonical_elements(eng, pkg):
     bad = O.R.to_bytes(32, "little")
     with pytest.raises(pkg.H2AggError) as ei:

@@ -21,7 +21,15 @@ from tests.test_verifier_pipeline import SHAPES, make_batch
 pytestmark = pytest.mark.gpu
 
 
-def run_product(pkg, eng, setup, circuits, with_pairing=True):
+@pytest.fixture(params=["device", "host"])
+def backend(request, eng):
+    """both sponge backends (h2agg_transcript_configure): the device kernel and the host worker threads"""
+    eng.transcript_configure(request.param)
+    yield request.param
+    eng.transcript_configure("auto")
+
+
+def run_product(pkg, eng, setup, circuits, with_pairing=True, with_commits=False):
     ver = importlib.import_module(entry.PKG_NAME + ".verifier")
     table = eng.bases_upload(b"".join(O.aff_to_bytes(p) for p in setup.g_lagrange))
     vks, arg = [], []
@@ -35,8 +43,8 @@ def run_product(pkg, eng, setup, circuits, with_pairing=True):
                 proofs.append(([b"".join(O.fe_to_bytes(v) for v in col) for col in inst[0]], data))
             arg.append((vk, c.name, table, proofs))
         if with_pairing:
-            return ver.verify_aggregation(eng, arg, g2b(setup.s_g2), g2b(setup.g2))
-        return ver.verify_aggregation(eng, arg)
+            return ver.verify_aggregation(eng, arg, g2b(setup.s_g2), g2b(setup.g2), with_commits=with_commits)
+        return ver.verify_aggregation(eng, arg, with_commits=with_commits)
     finally:
         for vk in vks:
             vk.close()
@@ -44,17 +52,45 @@ def run_product(pkg, eng, setup, circuits, with_pairing=True):
 
 
 @pytest.mark.parametrize("shape_ids,nproofs", [((0,), 1), ((0,), 3), ((1,), 2), ((2,), 2), ((0, 1, 2), 2)])
-def test_product_pipeline_matches_oracle_and_is_accepted(eng, pkg, shape_ids, nproofs):
+def test_product_pipeline_matches_oracle_and_is_accepted(eng, pkg, backend, shape_ids, nproofs):
     setup, circuits = make_batch(0x70 + len(shape_ids) * 8 + nproofs, [SHAPES[i] for i in shape_ids], nproofs)
-    want_l, want_r, _plain, _commits, want_lam = V.verify_aggregation_proofs_in_chip(S.OracleEccChip(), circuits)
-    left, right, lam, ok = run_product(pkg, eng, setup, circuits)
+    want_l, want_r, _plain, want_commits, want_lam = V.verify_aggregation_proofs_in_chip(S.OracleEccChip(), circuits)
+    left, right, lam, ok, commits = run_product(pkg, eng, setup, circuits, with_commits=True)
     assert lam == O.fe_to_bytes(want_lam)
     assert left + right == S.final_pair_bytes(want_l, want_r)
     assert ok is True
     assert E.pairing_check([(want_l, setup.s_g2), (want_r, E.g2_neg(setup.g2))])
+    # the fourth return value of verify_aggregation_proofs_in_chip: every proof's advice commitments (verify.rs:852-856)
+    flat_want = [[O.aff_to_bytes(p) for p in per_proof] for per_proof in want_commits]
+    assert commits == flat_want
 
 
-def test_tampered_inputs_are_rejected(eng, pkg):
+def test_commit_buffer_too_small_is_refused(eng, pkg):
+    import ctypes as C
+    setup, circuits = make_batch(0x7A, [SHAPES[0]], 1)
+    ver = importlib.import_module(entry.PKG_NAME + ".verifier")
+    table = eng.bases_upload(b"".join(O.aff_to_bytes(p) for p in setup.g_lagrange))
+    vk = ver.VerifyingKey(eng, ver.encode_vk(circuits[0].cs, O.aff_to_bytes))
+    try:
+        inst, data = circuits[0].proofs[0]
+        cols = [b"".join(O.fe_to_bytes(v) for v in col) for col in inst[0]]
+        arr = (ver._CircuitProofs * 1)()
+        tr, tl = (C.c_char_p * 1)(data), (C.c_size_t * 1)(len(data))
+        ins = (C.c_char_p * 1)(b"".join(cols))
+        lens = (C.c_uint32 * len(cols))(*[len(c) // 32 for c in cols])
+        nm = circuits[0].name.encode()
+        arr[0] = ver._CircuitProofs(vk._vk, nm, table, 1, tr, tl, ins, lens)
+        left, right = C.create_string_buffer(64), C.create_string_buffer(64)
+        small = C.create_string_buffer(64)
+        rc = eng._lib.h2agg_verify_aggregation_ex(eng._ctx, C.cast(arr, C.c_void_p), 1, None, None, left, right, None, None,
+                                                  small, 64 * vk.num_advice_columns - 1)
+        assert rc == pkg.ERR_INVALID
+    finally:
+        vk.close()
+        eng.bases_free(table)
+
+
+def test_tampered_inputs_are_rejected(eng, pkg, backend):
     setup, circuits = make_batch(0x7B, [SHAPES[0]], 2)
     inst, data = circuits[0].proofs[1]
     # an evaluation changed

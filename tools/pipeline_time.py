@@ -1,0 +1,47 @@
+"""h2agg_verify_aggregation end to end (proof bytes in, pairing verdict out) at several batch sizes, on both sponge backends.
+    python tools/pipeline_time.py [proofs ...]      (default 4 16 64)
+Same synthetic P = 347 key as bench.py's `aggregate.full_pipeline` leg; prints ms per aggregation and proofs/s, and checks
+that the two backends return the same pair and lambda."""
+import importlib, sys, time, types
+sys.path.insert(0, '.')
+import torch
+import __graft_entry__ as entry
+pkg = entry.load_package()
+eng = pkg.H2Agg(0)
+syn = importlib.import_module(entry.PKG_NAME + ".synthetic")
+ver = importlib.import_module(entry.PKG_NAME + ".verifier")
+from bench import gen_scalars
+sizes = [int(a) for a in sys.argv[1:]] or [4, 16, 64]
+dev = torch.device('cuda', 0)
+_, gk = gen_scalars(7, 1 << 17)
+g_table = eng.bases_generate(torch.from_numpy(gk.copy()).to(dev).data_ptr(), 1 << 17)
+eng.bases_precompute(g_table)
+pool = syn.point_pool(eng, 0xA66)
+comp = eng.g1_batch_compress(b"".join(pool))
+pool_c = [comp[32 * i:32 * i + 32] for i in range(len(pool))]
+shape = syn.CircuitShape(17, 300, pool)
+vk = ver.VerifyingKey(eng, ver.encode_vk(shape, lambda p: p))
+fr = syn.fr_stream(0xF00D)
+proofs_all = [([b"".join(fr() for _ in range(64))], shape.random_transcript(pool_c, 100 + i)) for i in range(max(sizes))]
+g2 = bytes.fromhex(
+    "edf692d95cbdde46ddda5ef7d422436779445c5e66006a42761e1f12efde0018c212f3aeb785e49712e7a9353349aaf1255dfb31b7bf60723a480d9293938e19"
+    "aa7dfa6601cce64c7bd3430c69e7d1e38f40cb8d8071ab4aeb6d8cdba55ec8125b9722d1dcdaac55f38eb37033314bbc95330c69ad999eec75f05f58d0890609")
+print("host worker threads:", pkg.host_threads())
+for n in sizes:
+    arg = [(vk, "syn", g_table, proofs_all[:n])]
+    res = {}
+    for be in ("device", "host", "auto"):
+        eng.transcript_configure(be)
+        for pair in (True, False):
+            a = ver.verify_aggregation(eng, arg, g2 if pair else None, g2 if pair else None)
+            reps = 5
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                b = ver.verify_aggregation(eng, arg, g2 if pair else None, g2 if pair else None)
+            dt = (time.perf_counter() - t0) / reps
+            assert a[:3] == b[:3]
+            res[be] = a[:3]
+            print("%3d proofs  %-6s  %s  %8.3f ms  %8.1f proofs/s" % (n, be, "with pairing" if pair else "no pairing  ", dt * 1e3, n / dt), flush=True)
+    assert res["device"] == res["host"] == res["auto"], "backends disagree"
+eng.transcript_configure("auto")
+vk.close()
