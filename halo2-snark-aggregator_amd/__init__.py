@@ -127,6 +127,7 @@ def load_library():
         "h2agg_transcript_configure": (i32, [ctxp, i32]),
         "h2agg_poseidon_squeeze_batch_host": (i32, [u8p, sz, sz, C.POINTER(C.c_uint32), sz, vp, i32]),
         "h2agg_host_threads": (i32, []),
+        "h2agg_host_sponge_kind": (i32, []),
         "h2agg_comm_unique_id": (i32, [vp]),
         "h2agg_comm_init_rank": (i32, [ctxp, u8p, i32, i32]),
         "h2agg_comm_create": (i32, [C.POINTER(i32), i32, C.POINTER(ctxp)]),
@@ -544,9 +545,17 @@ class H2Agg:
         return out
 
 
-def poseidon_squeeze_batch_host(elems: bytes, nproofs: int, upto: Sequence[int], max_threads: int = 0) -> bytes:
-    """the host backend of H2Agg.poseidon_squeeze_batch on its own (h2agg_poseidon_squeeze_batch_host: no context, no device)"""
+def host_sponge_kind() -> str:
+    """arithmetic the host sponge runs on here: "ifma" (AVX-512 IFMA) or "scalar" (portable 4 x 64-bit)"""
+    return "ifma" if load_library().h2agg_host_sponge_kind() == 1 else "scalar"
+
+
+def poseidon_squeeze_batch_host(elems: bytes, nproofs: int, upto: Sequence[int], max_threads: int = 0,
+                                kernel: Optional[str] = None) -> bytes:
+    """the host backend of H2Agg.poseidon_squeeze_batch on its own (h2agg_poseidon_squeeze_batch_host: no context, no device);
+    kernel: None = the process-wide choice, "scalar" / "ifma" = force one for this call (ifma only where the CPU has it)"""
     lib = load_library()
+    max_threads = (max_threads & 0xffff) | {None: 0, "scalar": 0x10000, "ifma": 0x20000}[kernel]
     nelem = (len(elems) // 32) // max(nproofs, 1)
     _need(elems, 32 * nelem * nproofs, "elems")
     nsq = len(upto)

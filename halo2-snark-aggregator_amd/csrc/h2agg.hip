@@ -26,6 +26,7 @@
 #include "pairing.hpp"
 #include "poseidon_host.hpp"
 #include "poseidon_sponge_host.hpp"
+#include "poseidon_ifma_host.hpp"
 #include "poseidon_kernels.hpp"
 
 using namespace h2agg;

@@ -262,12 +262,16 @@ int h2agg_poseidon_squeeze_batch(h2agg_ctx* ctx, const uint8_t* elems, size_t np
  * same generated constants, bit-identical challenges) and large ones on the device.  backend: 0 = auto (by batch size and
  * usable host threads; environment H2AGG_TRANSCRIPT=device|host overrides), 1 = device, 2 = host.  Applies to
  * h2agg_poseidon_squeeze_batch, h2agg_transcript_read_batch and h2agg_verify_aggregation(_ex) on this context.
- * h2agg_poseidon_squeeze_batch_host: the host backend on its own (no context, no device): max_threads <= 0 = all usable.
+ * h2agg_poseidon_squeeze_batch_host: the host backend on its own (no context, no device): max_threads 0 = all usable.
  * h2agg_host_threads: worker threads the library may use (affinity mask, cgroup CPU quota, H2AGG_HOST_THREADS; <= 32). */
 int h2agg_transcript_configure(h2agg_ctx* ctx, int backend);
 int h2agg_poseidon_squeeze_batch_host(const uint8_t* elems, size_t nproofs, size_t nelem, const uint32_t* upto, size_t nsq,
                                       uint8_t* out, int max_threads);
 int h2agg_host_threads(void);
+/* arithmetic of the host sponge: 1 = AVX-512 IFMA (chosen at run time when the CPU has avx512ifma), 0 = portable 4 x 64-bit.
+ * In h2agg_poseidon_squeeze_batch_host, max_threads bit 16 forces the portable kernel and bit 17 the IFMA one for that call
+ * (bits 0..15 stay the thread cap): the two are differential partners in tests/test_host_sponge.py. */
+int h2agg_host_sponge_kind(void);
 int h2agg_transcript_read_batch(h2agg_ctx* ctx, const uint8_t* proofs, size_t proof_len, size_t nproofs, const char* script,
                                 size_t script_len, const uint8_t* consts, size_t nconsts, const uint8_t* ext_points_aff,
                                 size_t next, uint8_t* points_out, uint8_t* challenges_out);

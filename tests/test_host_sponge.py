@@ -48,6 +48,21 @@ def test_interleaved_squeezes_and_threads(pkg):
         assert got[128 * i:128 * i + 128] == fe(oracle_squeezes(rows[i], upto)), i
 
 
+def test_scalar_and_ifma_kernels_agree(pkg):
+    """the portable 4 x 64-bit permutation and the AVX-512 IFMA one (taken when the CPU has avx512ifma) are differential
+    partners: same challenges on long streams, including the chunk edges"""
+    rng = O.SplitMix64(0xA07)
+    rows = [[rng.fr() for _ in range(203)] for _ in range(6)]
+    rows[0][:8] = [0] * 8
+    rows[1][:9] = [O.R - 1] * 9
+    blob, upto = b"".join(fe(r) for r in rows), [0, 0, 1, 8, 9, 64, 64, 203]
+    a = pkg.poseidon_squeeze_batch_host(blob, len(rows), upto, kernel="scalar")
+    b = pkg.poseidon_squeeze_batch_host(blob, len(rows), upto, kernel="ifma")
+    assert a == b
+    assert a[:32 * len(upto)] == fe(oracle_squeezes(rows[0], upto))
+    assert pkg.host_sponge_kind() in ("ifma", "scalar")
+
+
 def test_extreme_values(pkg):
     """all-zero, all r-1 and 2^k-shaped elements: every conditional subtraction of the lazy dot products is exercised"""
     rows = [[0] * 24, [O.R - 1] * 24, [(1 << (11 * k % 253)) % O.R for k in range(24)], [O.R - 1 - k for k in range(24)]]
