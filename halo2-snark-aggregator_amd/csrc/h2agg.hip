@@ -1812,7 +1812,14 @@ int h2agg_pairing_product(h2agg_ctx* c, const uint8_t* g1_aff, const uint8_t* g2
     std::vector<pairing::G1Affine> ps;
     std::vector<pairing::G2Affine> qs;
     TRY(pairing_load(c, g1_aff, g2_aff, n, ps, qs));
-    pairing::f12_to_bytes(pairing::final_exponentiation(pairing::multi_miller_loop(ps, qs)), out_gt);
+    // (prepared lines: a G2 point that comes back — [s]_2, [1]_2 of one ParamsKZG — pays its doubling / addition steps once)
+    std::vector<std::shared_ptr<const pairing::G2Prepared>> keep(n);
+    std::vector<const pairing::G2Prepared*> preps(n);
+    for (size_t i = 0; i < n; ++i) {
+        keep[i] = pairing::g2_prepared_cached(g2_aff + 128 * i, false, qs[i]);
+        preps[i] = keep[i].get();
+    }
+    pairing::f12_to_bytes(pairing::final_exponentiation(pairing::multi_miller_loop_prepared(ps, preps)), out_gt);
     return H2AGG_OK;
 } catch (const std::bad_alloc&) {
     return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
@@ -1866,7 +1873,10 @@ int h2agg_final_pair_check(h2agg_ctx* c, const uint8_t left_aff[64], const uint8
     std::vector<pairing::G2Affine> qs;
     TRY(pairing_load(c, g1s, g2s, 2, ps, qs));
     if (!qs[1].inf) qs[1].y = pairing::f2_neg(qs[1].y);
-    *ok = pairing::f12_is_one(pairing::final_exponentiation(pairing::multi_miller_loop(ps, qs))) ? 1 : 0;
+    const std::shared_ptr<const pairing::G2Prepared> keep[2] = {pairing::g2_prepared_cached(s_g2, false, qs[0]),
+                                                                pairing::g2_prepared_cached(g2, true, qs[1])};
+    const std::vector<const pairing::G2Prepared*> preps = {keep[0].get(), keep[1].get()};
+    *ok = pairing::f12_is_one(pairing::final_exponentiation(pairing::multi_miller_loop_prepared(ps, preps))) ? 1 : 0;
     return H2AGG_OK;
 } catch (const std::bad_alloc&) {
     return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI

@@ -16,11 +16,12 @@
 // (Costello-Lange-Naehrig 2010 formulas), two Frobenius corrections, final exponentiation = easy part
 // (p^6 - 1)(p^2 + 1) then the EXACT hard part (p^4 - p^2 + 1)/r by Scott et al.'s decomposition
 // lambda_3 p^3 + lambda_2 p^2 + lambda_1 p + lambda_0 — so the GT element equals the textbook e(P, Q) and can be compared
-// coefficient by coefficient with the oracle's flat-basis implementation (tests/test_gpu_pairing.py), not only as a boolean.
+// coefficient by coefficient with the oracle's flat-basis implementation (tests/test_pairing_capi.py), not only as a boolean.
 #pragma once
 #include <stdint.h>
 #include <string.h>
 
+#include <memory>
 #include <vector>
 
 namespace h2agg {
@@ -50,32 +51,45 @@ static inline void fq_sub_mod(uint64_t* a) {
         b = (t >> 64) & 1;
     }
 }
+// a + b mod p and a - b mod p for values < p, branch-free (the tower spends as many additions as multiplications: a
+// mispredicted compare-and-subtract per addition was ~40 % of the Miller loop's time)
 static inline Fq fq_add(const Fq& a, const Fq& b) {
-    Fq r;
-    u128 c = 0;
+    uint64_t s[4], d[4];
+    unsigned char cy = 0, bw = 0;
+#pragma GCC unroll 4
     for (int i = 0; i < 4; ++i) {
-        c += (u128)a.l[i] + b.l[i];
-        r.l[i] = (uint64_t)c;
-        c >>= 64;
+        const u128 v = (u128)a.l[i] + b.l[i] + cy;
+        s[i] = (uint64_t)v;
+        cy = (unsigned char)(v >> 64);
     }
-    if (c || fq_geq_mod(r.l)) fq_sub_mod(r.l);   // p < 2^254: no carry out in practice
+#pragma GCC unroll 4
+    for (int i = 0; i < 4; ++i) {
+        const u128 v = (u128)s[i] - FQ_MOD[i] - bw;
+        d[i] = (uint64_t)v;
+        bw = (unsigned char)((v >> 64) & 1);
+    }
+    const uint64_t m = (uint64_t)0 - (uint64_t)(cy | !bw);   // sum >= p: take the difference
+    Fq r;
+#pragma GCC unroll 4
+    for (int i = 0; i < 4; ++i) r.l[i] = (d[i] & m) | (s[i] & ~m);
     return r;
 }
 static inline Fq fq_sub(const Fq& a, const Fq& b) {
-    Fq r;
-    u128 br = 0;
+    uint64_t d[4];
+    unsigned char bw = 0, cy = 0;
+#pragma GCC unroll 4
     for (int i = 0; i < 4; ++i) {
-        u128 t = (u128)a.l[i] - b.l[i] - (uint64_t)br;
-        r.l[i] = (uint64_t)t;
-        br = (t >> 64) & 1;
+        const u128 v = (u128)a.l[i] - b.l[i] - bw;
+        d[i] = (uint64_t)v;
+        bw = (unsigned char)((v >> 64) & 1);
     }
-    if (br) {
-        u128 c = 0;
-        for (int i = 0; i < 4; ++i) {
-            c += (u128)r.l[i] + FQ_MOD[i];
-            r.l[i] = (uint64_t)c;
-            c >>= 64;
-        }
+    const uint64_t m = (uint64_t)0 - (uint64_t)bw;   // negative: add p back
+    Fq r;
+#pragma GCC unroll 4
+    for (int i = 0; i < 4; ++i) {
+        const u128 v = (u128)d[i] + (FQ_MOD[i] & m) + cy;
+        r.l[i] = (uint64_t)v;
+        cy = (unsigned char)(v >> 64);
     }
     return r;
 }
@@ -309,11 +323,42 @@ static inline Fq12 f12_frobenius(const Fq12& a) {
     r.c1.c2 = f2_mul(f2_conj(a.c1.c2), F.g[5]);
     return r;
 }
-static inline Fq12 f12_pow_x(const Fq12& a) {   // a^x, x = 0x44e992b44a6909f1
+// a^2 for a in the cyclotomic subgroup G_{Phi_6(p^2)} (everything after the easy part of the final exponentiation): Granger and
+// Scott's squaring — Fq12 seen as three Fq4 = Fq2[y]/(y^2 - xi) pairs (c0.c0, c1.c1), (c1.c0, c0.c2), (c0.c1, c1.c2); 6 Fq2
+// products instead of 12.  Checked against f12_sqr on cyclotomic inputs by tests/test_pairing_capi.py (the GT element of every
+// pairing goes through it).
+static inline Fq12 f12_cyclotomic_sqr(const Fq12& a) {
+    auto fp4_sqr = [](const Fq2& x, const Fq2& y, Fq2& t0, Fq2& t1) {   // (x + y Y)^2 = t0 + t1 Y,  Y^2 = xi
+        const Fq2 xy = f2_mul(x, y);
+        t0 = f2_sub(f2_sub(f2_mul(f2_add(x, y), f2_add(x, f2_mul_xi(y))), xy), f2_mul_xi(xy));
+        t1 = f2_dbl(xy);
+    };
+    Fq2 t0, t1, t2, t3, t4, t5;
+    fp4_sqr(a.c0.c0, a.c1.c1, t0, t1);
+    fp4_sqr(a.c1.c0, a.c0.c2, t2, t3);
+    fp4_sqr(a.c0.c1, a.c1.c2, t4, t5);
+    auto three_minus_two = [](const Fq2& t, const Fq2& z) {   // 3 t - 2 z
+        const Fq2 d = f2_sub(t, z);
+        return f2_add(f2_dbl(d), t);
+    };
+    auto three_plus_two = [](const Fq2& t, const Fq2& z) {    // 3 t + 2 z
+        const Fq2 d = f2_add(t, z);
+        return f2_add(f2_dbl(d), t);
+    };
+    Fq12 r;
+    r.c0.c0 = three_minus_two(t0, a.c0.c0);
+    r.c1.c1 = three_plus_two(t1, a.c1.c1);
+    r.c1.c0 = three_plus_two(f2_mul_xi(t5), a.c1.c0);
+    r.c0.c2 = three_minus_two(t4, a.c0.c2);
+    r.c0.c1 = three_minus_two(t2, a.c0.c1);
+    r.c1.c2 = three_plus_two(t3, a.c1.c2);
+    return r;
+}
+static inline Fq12 f12_pow_x(const Fq12& a) {   // a^x, x = 0x44e992b44a6909f1; `a` in the cyclotomic subgroup
     const uint64_t x = 0x44e992b44a6909f1ull;
     Fq12 acc = a;
     for (int i = 61; i >= 0; --i) {   // bit 62 is the top bit
-        acc = f12_sqr(acc);
+        acc = f12_cyclotomic_sqr(acc);
         if ((x >> i) & 1) acc = f12_mul(acc, a);
     }
     return acc;
@@ -423,6 +468,78 @@ static inline Fq12 multi_miller_loop(const std::vector<G1Affine>& ps, const std:
         ell(f, g2_add_step(rs[k], q2), ps[live[k]].x, ps[live[k]].y);
     }
     return f;
+}
+
+// The line coefficients of a FIXED G2 point, in the order the Miller loop consumes them (the reference's `G2Prepared`,
+// verify.rs:733-737: s_g2_prepared / n_g2_prepared).  [s]_2 and -[1]_2 of one ParamsKZG come back with every batch: with the
+// lines cached, a pair costs its sparse multiplications only.
+struct G2Prepared {
+    std::vector<Line> lines;
+    bool inf = true;
+};
+static inline G2Prepared g2_prepare(const G2Affine& q) {
+    G2Prepared out;
+    out.inf = q.inf;
+    if (q.inf) return out;
+    const uint64_t lo = 0x9d797039be763ba8ull;
+    G2Proj r = {q.x, q.y, f2_one()};
+    for (int bit = 63; bit >= 0; --bit) {
+        out.lines.push_back(g2_double_step(r));
+        if ((lo >> bit) & 1) out.lines.push_back(g2_add_step(r, q));
+    }
+    const FrobConsts& F = frob();
+    G2Affine q1 = {f2_mul(f2_conj(q.x), F.g[2]), f2_mul(f2_conj(q.y), F.g[3]), false};
+    G2Affine q2 = {f2_mul(f2_conj(q1.x), F.g[2]), f2_neg(f2_mul(f2_conj(q1.y), F.g[3])), false};
+    out.lines.push_back(g2_add_step(r, q1));
+    out.lines.push_back(g2_add_step(r, q2));
+    return out;
+}
+// the same product of line evaluations as multi_miller_loop, from prepared lines
+static inline Fq12 multi_miller_loop_prepared(const std::vector<G1Affine>& ps, const std::vector<const G2Prepared*>& qs) {
+    const uint64_t lo = 0x9d797039be763ba8ull;
+    std::vector<size_t> live, idx;
+    for (size_t i = 0; i < ps.size(); ++i)
+        if (!ps[i].inf && !qs[i]->inf) {
+            live.push_back(i);
+            idx.push_back(0);
+        }
+    Fq12 f = f12_one();
+    for (int bit = 63; bit >= 0; --bit) {
+        f = f12_sqr(f);
+        for (size_t k = 0; k < live.size(); ++k) ell(f, qs[live[k]]->lines[idx[k]++], ps[live[k]].x, ps[live[k]].y);
+        if ((lo >> bit) & 1)
+            for (size_t k = 0; k < live.size(); ++k) ell(f, qs[live[k]]->lines[idx[k]++], ps[live[k]].x, ps[live[k]].y);
+    }
+    for (size_t k = 0; k < live.size(); ++k) {
+        ell(f, qs[live[k]]->lines[idx[k]++], ps[live[k]].x, ps[live[k]].y);
+        ell(f, qs[live[k]]->lines[idx[k]++], ps[live[k]].x, ps[live[k]].y);
+    }
+    return f;
+}
+// prepared lines of the last few G2 points seen by this thread (keyed by the point's 128-byte encoding + negation flag);
+// shared ownership: an entry evicted while a caller still holds it stays alive until that caller is done
+static inline std::shared_ptr<const G2Prepared> g2_prepared_cached(const uint8_t enc[128], bool negate, const G2Affine& q_as_used) {
+    struct Entry {
+        uint8_t key[129];
+        std::shared_ptr<const G2Prepared> prep;
+    };
+    static thread_local std::vector<Entry> cache;
+    static thread_local size_t next = 0;
+    uint8_t key[129];
+    memcpy(key, enc, 128);
+    key[128] = negate ? 1 : 0;
+    for (auto& e : cache)
+        if (memcmp(e.key, key, 129) == 0) return e.prep;
+    Entry e;
+    memcpy(e.key, key, 129);
+    e.prep = std::make_shared<const G2Prepared>(g2_prepare(q_as_used));
+    std::shared_ptr<const G2Prepared> r = e.prep;
+    if (cache.size() < 8) cache.push_back(std::move(e));
+    else {
+        cache[next] = std::move(e);
+        next = (next + 1) % 8;
+    }
+    return r;
 }
 
 // f^((p^12 - 1) / r), exact
