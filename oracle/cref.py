@@ -92,6 +92,16 @@ def msm_pippenger(bases: bytes, scalars: bytes, n: int, c: int = 0, nthreads: in
     return bytes(out)
 
 
+def msm_pippenger2(bases: bytes, scalars: bytes, n: int, c: int = 0, nthreads: int = 1, jobs_per_thread: int = 4) -> bytes:
+    """the competent CPU Pippenger (signed digits, XYZZ buckets with mixed additions, balanced (window, range) jobs)"""
+    if c == 0:
+        c = max(2, min(16, n.bit_length() - 4))
+    out = _buf(64)
+    rc = lib().oracle_msm_pippenger2(bases, scalars, C.c_size_t(n), c, nthreads, jobs_per_thread, out)
+    assert rc == 0
+    return bytes(out)
+
+
 def constants(which: int):
     mod, r1, r2 = _buf(32), _buf(32), _buf(32)
     inv = C.c_uint64()

@@ -78,6 +78,7 @@ def test_msm_fixtures():
         assert cref.multi_exp_naive(bases, scalars, k["n"]) == want
         for c in (3, 7):
             assert cref.msm_pippenger(bases, scalars, k["n"], c, 2) == want
+            assert cref.msm_pippenger2(bases, scalars, k["n"], max(c, 2), 3, 2) == want   # signed digits / XYZZ buckets
         assert cref.eval_flat(bases, scalars, bytes([1]) * k["n"], k["n"]) == want
 
 
@@ -113,6 +114,8 @@ def test_c_oracle_vs_identity_at_scale():
     bases = points_from_scalars(ks)
     want = O.aff_to_bytes(O.scalar_mul(sum(k * s for k, s in zip(ks, ss)) % O.R, O.G1))
     assert cref.msm_pippenger(bases, fr_bytes(ss), n, 8, 4) == want
+    for c2, thr, jpt in ((2, 1, 1), (8, 4, 4), (13, 2, 1), (16, 3, 2)):
+        assert cref.msm_pippenger2(bases, fr_bytes(ss), n, c2, thr, jpt) == want
     assert cref.multi_exp_naive(bases[:64 * 200], fr_bytes(ss[:200]), 200) == O.aff_to_bytes(
         O.scalar_mul(sum(k * s for k, s in zip(ks[:200], ss[:200])) % O.R, O.G1))
 
