@@ -176,6 +176,10 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
             if int(flag.item()) == 1:
                 comm = eng
                 exchange_how = "h2agg_allgather_add_points (RCCL all-gather of 192 B per rank inside the C ABI + local EC adds)"
+                # self-verifying on the first real multi-GPU run: the library's communicator must span every rank
+                if eng.comm_size() != world or eng.comm_rank() != rank:
+                    raise SystemExit("rank %d: h2agg communicator reports rank %d of %d, torch.distributed %d of %d"
+                                     % (rank, eng.comm_rank(), eng.comm_size(), rank, world))
     # per-proof data generated once (same on every rank: seeded); building the schemas is inside the timed region
     pool = syn.point_pool(eng, 0xA66)
     specs, lam = syn.make_proofs(pool, n_total, args.agg_commitments)
@@ -269,6 +273,7 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
         "instance_msm_fixed_base_levels": bool(n_inst and args.agg_instance_log2 <= 18 and not args.no_fixed_base),
         "final_pair_sha": __import__("hashlib").sha256(pair[0] + pair[1]).hexdigest()[:16],
         "exchange": exchange_how,
+        "rccl_ranks": eng.comm_size() if comm is not None else 0,   # ranks of the C-ABI communicator the exchange ran on (0 = not used)
         "verified": verified if verified else "sharded run: every rank's timed repetitions reproduce the warm-up pair "
                                               "(the single-rank run of the same proofs is cross-checked per proof)",
         "note": "synthetic shape-faithful schemas; per proof: the instance-column commitment MSM against the fixed "

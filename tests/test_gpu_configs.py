@@ -113,6 +113,20 @@ def test_evm_shaped_proofs_vs_oracle(eng, pkg, n_total, world):
     assert sharded_pair(pkg, eng, specs, lam, world) == want
 
 
+def test_config4_128_proofs_8_shards_literal_fold(eng, pkg):
+    """configs[4]'s literal fold: N = 128 proofs, world = 8, 16 proofs per shard (reduced query count so that the oracle's
+    naive multi_exp stays in seconds): the lambda powers lambda^(N-1-i) reach 127, every shard folds its sixteen, the eight
+    partial pairs are added — exact against the single-process reference semantics (verify.rs:926-938)"""
+    syn = importlib.import_module(entry.PKG_NAME + ".synthetic")
+    agg = importlib.import_module(entry.PKG_NAME + ".aggregate")
+    pool = syn.point_pool(eng, 0xA66)
+    specs, lam = syn.make_proofs(pool, 128, 4)
+    assert all(len(agg.shard_indices(128, 8, r)) == 16 for r in range(8))
+    want, _names = oracle_pair(specs, lam)
+    assert sharded_pair(pkg, eng, specs, lam, 8) == want
+    assert sharded_pair(pkg, eng, specs, lam, 1) == want
+
+
 @pytest.mark.parametrize("fixed_base", [False, True])
 def test_composed_flow_instance_commitment_to_final_pair(eng, pkg, fixed_base):
     """bench.py's aggregate leg end to end (verify.rs:835-942 in the reference's order): assign_instance_commitment for

@@ -1,0 +1,281 @@
+"""Golden vectors produced by the REFERENCE itself (tools/ref_dump, a Rust crate that runs the reference's own add_mul /
+lookup aggregation over its Mock chips — halo2-snark-aggregator-api/src/tests/systems/halo2/add_mul_test/
+verify_aggregation.rs:32-149 — and dumps transcripts, the H2VK blob, challenges, the final pair, ParamsKZG::write bytes,
+Poseidon State::default() and encoding samples into tests/golden/ref_*.json).
+
+This image has no Rust toolchain, so the files do not exist yet and every test here SKIPS — loudly: the oracle stays
+"parity unpinned"  until somebody runs the one command in tools/ref_dump/Cargo.toml.  The day the files
+are committed these tests pin, without further work:
+  CPU  (not gpu)  oracle/ against the reference: Poseidon defaults + sponge, point / scalar encodings, ParamsKZG layout,
+                  every transcript challenge, lambda, the final pair, the advice commitments, the pairing verdict;
+  GPU  (gpu)      the product through the C ABI against the same files (h2agg_verify_aggregation_ex from the reference's bytes)."""
+import glob
+import importlib
+import json
+import os
+import struct
+
+import pytest
+
+import __graft_entry__ as entry
+from oracle import bn254 as O
+from oracle import poseidon as P
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CIRCUITS = sorted(f for f in glob.glob(os.path.join(GOLDEN, "ref_*.json")) if not f.endswith("ref_primitives.json"))
+PRIMS = os.path.join(GOLDEN, "ref_primitives.json")
+WHY = ("tests/golden/ref_*.json not present: the reference cannot be built in this image (no cargo / rustc).  Run "
+       "tools/ref_dump (see its Cargo.toml) on a box with Rust nightly-2022-08-23 and commit the files — until then the oracle "
+       "is PARITY UNPINNED against the reference (pinned only by EIP-196/197 and Poseidon published vectors)")
+
+needs_prims = pytest.mark.skipif(not os.path.exists(PRIMS), reason=WHY)
+needs_circuits = pytest.mark.skipif(not CIRCUITS, reason=WHY)
+
+
+def decode_vk(blob: bytes):
+    """H2VK description (include/h2agg.h) -> oracle/verifier.py::ConstraintSystem: the inverse of verifier.encode_vk"""
+    from oracle import verifier as V
+    pos = [0]
+
+    def take(n):
+        b = blob[pos[0]:pos[0] + n]
+        assert len(b) == n
+        pos[0] += n
+        return b
+
+    def u32():
+        return struct.unpack("<I", take(4))[0]
+
+    def pad(n):
+        pos[0] += (4 - n % 4) % 4
+
+    assert u32() == 0x4B563248 and u32() == 1
+    k, nadv, ninst, nchal, degree, blinding = (u32() for _ in range(6))
+    adv_phase = list(take(nadv)); pad(nadv)
+    chal_phase = list(take(nchal)); pad(nchal)
+    queries = []
+    for _ in range(3):
+        n = u32()
+        queries.append([struct.unpack("<Ii", take(8)) for _ in range(n)])
+    kinds = {0: "advice", 1: "fixed", 2: "instance"}
+    perm_cols = [(kinds[a], b) for a, b in (struct.unpack("<II", take(8)) for _ in range(u32()))]
+    fixed = [O.aff_from_bytes(take(64)) for _ in range(u32())]
+    perm = [O.aff_from_bytes(take(64)) for _ in range(u32())]
+    vk_scalar = int.from_bytes(take(32), "little")
+
+    def expr(code):
+        st, i = [], 0
+        names = {1: "fixed", 2: "advice", 3: "instance", 4: "challenge"}
+        while i < len(code):
+            op = code[i]; i += 1
+            if op == 0:
+                st.append(("const", int.from_bytes(code[i:i + 32], "little"))); i += 32
+            elif op in names:
+                st.append((names[op], struct.unpack("<I", code[i:i + 4])[0])); i += 4
+            elif op == 5:
+                st.append(("neg", st.pop()))
+            elif op in (6, 7):
+                b = st.pop(); a = st.pop()
+                st.append(("sum" if op == 6 else "product", a, b))
+            elif op == 8:
+                st.append(("scaled", st.pop(), int.from_bytes(code[i:i + 32], "little"))); i += 32
+            else:
+                raise AssertionError(op)
+        assert len(st) == 1
+        return st[0]
+
+    def exprs():
+        out = []
+        for _ in range(u32()):
+            nb = u32()
+            out.append(expr(take(nb))); pad(nb)
+        return out
+
+    gates = [exprs() for _ in range(u32())]
+    lookups = [(exprs(), exprs()) for _ in range(u32())]
+    assert pos[0] == len(blob)
+    return V.ConstraintSystem(k=k, num_advice_columns=nadv, num_instance_columns=ninst, num_challenges=nchal,
+                              advice_column_phase=adv_phase, challenge_phase=chal_phase, advice_queries=queries[0],
+                              instance_queries=queries[1], fixed_queries=queries[2], gates=gates, lookups=lookups,
+                              permutation_columns=perm_cols, degree=degree, blinding_factors=blinding,
+                              fixed_commitments=fixed, permutation_commitments=perm, vk_scalar=vk_scalar)
+
+
+def test_decode_vk_inverts_encode_vk(pkg):
+    """(always runs) the decoder the golden tests rely on is the exact inverse of the encoder the product is fed through"""
+    ver = importlib.import_module(entry.PKG_NAME + ".verifier")
+    from tests import toy_prover as T
+    from tests.test_verifier_pipeline import SHAPES
+    for shape in SHAPES:
+        cs = T.make_constraint_system(O.SplitMix64(11), **shape)
+        blob = ver.encode_vk(cs, O.aff_to_bytes)
+        assert ver.encode_vk(decode_vk(blob), O.aff_to_bytes) == blob
+
+
+@needs_prims
+def test_primitives_against_the_reference():
+    g = json.load(open(PRIMS))
+    chip = P.PoseidonChip()
+    assert [O.fe_to_bytes(w).hex() for w in chip.state] == g["poseidon_state_default"]
+    outs = []
+    chip.update([1, 2, 3]); outs.append(chip.squeeze())
+    chip.update(list(range(8))); outs.append(chip.squeeze()); outs.append(chip.squeeze())
+    assert [O.fe_to_bytes(v).hex() for v in outs] == g["poseidon_squeezes"]
+    sp = P.spec(9, 8, 63)
+    assert [O.fe_to_bytes(v).hex() for v in sp.mds[0]] == g["poseidon_mds_row0"]
+    assert [O.fe_to_bytes(v).hex() for v in sp.start[0]] == g["poseidon_start0"]
+    for enc in g["g1_encodings"]:
+        pt = O.aff_from_bytes(bytes.fromhex(enc["affine"]))
+        assert O.compress(pt).hex() == enc["compressed"], enc["k"]
+        assert O.decompress(bytes.fromhex(enc["compressed"])) == pt
+    assert O.fe_to_bytes(5).hex() == g["fr_to_repr_of_5"]
+    from oracle import verifier as V
+    assert O.fe_to_bytes(V.FR_ROOT_OF_UNITY).hex() == g["fr_root_of_unity"] and O.fe_to_bytes(V.FR_DELTA).hex() == g["fr_delta"]
+
+
+def _circuit_inputs(g):
+    from oracle import verifier as V
+    cs = decode_vk(bytes.fromhex(g["vk_blob"]))
+    gl = bytes.fromhex(g["g_lagrange"])
+    g_lagrange = [O.aff_from_bytes(gl[64 * i:64 * i + 64]) for i in range(len(gl) // 64)]
+    proofs = []
+    for pr in g["proofs"]:
+        cols = [[int.from_bytes(bytes.fromhex(c)[32 * j:32 * j + 32], "little") for j in range(len(c) // 64)] for c in pr["instances"]]
+        proofs.append(([cols], bytes.fromhex(pr["transcript"])))
+    return V.CircuitProofs(g["circuit"], cs, g_lagrange, proofs)
+
+
+@needs_circuits
+@pytest.mark.parametrize("path", CIRCUITS, ids=[os.path.basename(p) for p in CIRCUITS])
+def test_oracle_reproduces_the_reference(pkg, path):
+    """the oracle's verify_aggregation_proofs_in_chip on the reference's bytes: every challenge, lambda, the pair, commits"""
+    check_oracle(json.load(open(path)))
+
+
+def check_oracle(g):
+    from oracle import pairing as E
+    from oracle import schema as S
+    from oracle import verifier as V
+    circ = _circuit_inputs(g)
+    logs = []
+
+    class Rec(P.PoseidonTranscriptRead):
+        def __init__(self, data):
+            super().__init__(data)
+            self.log = []
+            logs.append(self.log)
+
+        def squeeze_challenge_scalar(self):
+            v = super().squeeze_challenge_scalar()
+            self.log.append(v)
+            return v
+
+    left, right, _plain, commits, lam = V.verify_aggregation_proofs_in_chip(S.OracleEccChip(), [circ], make_transcript=Rec)
+    assert O.fe_to_bytes(lam).hex() == g["lambda"]
+    for i, pr in enumerate(g["proofs"]):                    # logs[0] is the aggregation transcript (created first)
+        assert [O.fe_to_bytes(v).hex() for v in logs[1 + i]] == pr["challenges"], i
+    assert S.final_pair_bytes(left, right).hex() == g["w_x"] + g["w_g"]
+    assert [[O.aff_to_bytes(p).hex() for p in per] for per in commits] == g["advice_commitments"]
+    fs = importlib.import_module(entry.PKG_NAME + ".fs")
+    s_g2, g2 = bytes.fromhex(g["s_g2"]), bytes.fromhex(g["g2"])
+
+    def g2_from_bytes(b):   # x.c0 || x.c1 || y.c0 || y.c1, the layout of tests/test_pairing_capi.py::g2b
+        v = [int.from_bytes(b[32 * i:32 * i + 32], "little") for i in range(4)]
+        return ((v[0], v[1]), (v[2], v[3]))
+
+    assert E.pairing_check([(left, g2_from_bytes(s_g2)), (right, E.g2_neg(g2_from_bytes(g2)))]) is g["pairing_ok"]
+    # ParamsKZG::write layout as fs.py reads it: k | g | g_lagrange (compressed, 32 B each) | g2 | s_g2 (compressed, 64 B each)
+    if g.get("params_bytes"):
+        params = fs.read_params(bytes.fromhex(g["params_bytes"]))
+        assert params.k == g["k"]
+        gl = bytes.fromhex(g["g_lagrange"])
+        for i in (0, 1, params.n - 1):
+            assert O.decompress(params.g_lagrange[32 * i:32 * i + 32]) == O.aff_from_bytes(gl[64 * i:64 * i + 64])
+
+
+@needs_circuits
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", CIRCUITS, ids=[os.path.basename(p) for p in CIRCUITS])
+def test_product_reproduces_the_reference(eng, pkg, path):
+    """the HIP product through the C ABI, fed the reference's own bytes (vk blob from aggregate::serialize_vk, transcripts,
+    instances, g_lagrange, [s]_2): same lambda, same final pair, same advice commitments, same verdict — on both sponge backends"""
+    check_product(eng, json.load(open(path)))
+
+
+def check_product(eng, g):
+    ver = importlib.import_module(entry.PKG_NAME + ".verifier")
+    table = eng.bases_upload(bytes.fromhex(g["g_lagrange"]))
+    vk = ver.VerifyingKey(eng, bytes.fromhex(g["vk_blob"]))
+    try:
+        proofs = [([bytes.fromhex(c) for c in pr["instances"]], bytes.fromhex(pr["transcript"])) for pr in g["proofs"]]
+        for backend in ("device", "host"):
+            eng.transcript_configure(backend)
+            left, right, lam, ok, commits = ver.verify_aggregation(eng, [(vk, g["circuit"], table, proofs)],
+                                                                   bytes.fromhex(g["s_g2"]), bytes.fromhex(g["g2"]), with_commits=True)
+            assert lam.hex() == g["lambda"]
+            assert (left + right).hex() == g["w_x"] + g["w_g"]
+            assert ok is g["pairing_ok"]
+            assert [[p.hex() for p in per] for per in commits] == g["advice_commitments"]
+    finally:
+        eng.transcript_configure("auto")
+        vk.close()
+        eng.bases_free(table)
+
+
+# ---- self-test of the loader: a file of the SAME schema made by the oracle's toy prover (NOT a reference output: it proves
+# that the day ref_*.json arrive, the two checks above run as written — nothing about parity)
+def oracle_made_golden(seed=0x6010, nproofs=2):
+    from oracle import schema as S
+    from oracle import verifier as V
+    from tests import toy_prover as T
+    from tests.test_pairing_capi import g2b
+    from tests.test_verifier_pipeline import SHAPES, make_batch
+    ver = importlib.import_module(entry.PKG_NAME + ".verifier")
+    fs = importlib.import_module(entry.PKG_NAME + ".fs")
+    setup, circuits = make_batch(seed, [SHAPES[1]], nproofs)
+    c = circuits[0]
+    logs = []
+
+    class Rec(P.PoseidonTranscriptRead):
+        def __init__(self, data):
+            super().__init__(data)
+            self.log = []
+            logs.append(self.log)
+
+        def squeeze_challenge_scalar(self):
+            v = super().squeeze_challenge_scalar()
+            self.log.append(v)
+            return v
+
+    left, right, _plain, commits, lam = V.verify_aggregation_proofs_in_chip(S.OracleEccChip(), circuits, make_transcript=Rec)
+    from oracle import pairing as E
+    from tests.test_fs import _g2_compress
+    k = c.cs.k
+    params_hex = ""          # (the toy setup keeps only the Lagrange bases its instance columns need: no full params file)
+    if len(setup.g_lagrange) == 1 << k:
+        params_hex = fs.write_params(fs.KzgParams(
+            k, b"".join(O.compress(O.scalar_mul(pow(setup.tau, i, O.R), O.G1)) for i in range(1 << k)),
+            b"".join(O.compress(p) for p in setup.g_lagrange), _g2_compress(setup.g2), _g2_compress(setup.s_g2))).hex()
+    pair = S.final_pair_bytes(left, right).hex()
+    return {
+        "circuit": c.name, "k": k, "nproofs": nproofs, "params_bytes": params_hex,
+        "g_lagrange": b"".join(O.aff_to_bytes(p) for p in setup.g_lagrange).hex(),
+        "s_g2": g2b(setup.s_g2).hex(), "g2": g2b(setup.g2).hex(),
+        "vk_blob": ver.encode_vk(c.cs, O.aff_to_bytes).hex(), "vk_scalar": O.fe_to_bytes(c.cs.vk_scalar).hex(),
+        "proofs": [{"transcript": data.hex(), "instances": [b"".join(O.fe_to_bytes(v) for v in col).hex() for col in inst[0]],
+                    "challenges": [O.fe_to_bytes(v).hex() for v in logs[1 + i]]} for i, (inst, data) in enumerate(c.proofs)],
+        "lambda": O.fe_to_bytes(lam).hex(), "w_x": pair[:128], "w_g": pair[128:],
+        "pairing_ok": E.pairing_check([(left, setup.s_g2), (right, E.g2_neg(setup.g2))]),
+        "advice_commitments": [[O.aff_to_bytes(p).hex() for p in per] for per in commits],
+    }
+
+
+def test_loader_selftest_oracle(pkg):
+    g = json.loads(json.dumps(oracle_made_golden()))     # through JSON, as a committed file would arrive
+    assert g["pairing_ok"] is True
+    check_oracle(g)
+
+
+@pytest.mark.gpu
+def test_loader_selftest_product(eng, pkg):
+    check_product(eng, json.loads(json.dumps(oracle_made_golden())))
