@@ -173,6 +173,15 @@ struct Tape {
         const_ids.emplace(k, nconst);
         return nconst++;
     }
+    // A constant whose VALUE arrives later (a transcript challenge still being squeezed while the host records what is done
+    // with it): a register of its own, never merged with equal-valued constants; set_const fills it in before the tape runs.
+    // Field arithmetic is exact and the recorder only compares register ids, so the results do not depend on when the value
+    // becomes known.
+    uint32_t add_const_placeholder() {
+        consts.insert(consts.end(), 32, (uint8_t)0);
+        return nconst++;
+    }
+    void set_const(uint32_t reg, const uint8_t v[32]) { memcpy(consts.data() + 32 * (size_t)reg, v, 32); }
     static bool is_const(uint32_t r) { return !(r & (OPBIT | LAZYBIT)); }
     uint32_t record(uint32_t opcode, uint32_t a, uint32_t b) {
         a = materialize(a);
