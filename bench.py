@@ -73,34 +73,47 @@ def usable_cores():
 
 
 def csrc_sha() -> str:
-    """hash of the kernel sources: committed PMC evidence is only valid for the sources it was collected on"""
+    """hash of the MSM's kernel sources (field / group arithmetic, sort and MSM kernels): committed PMC evidence for
+    k_msm_accumulate is only valid for the sources it was collected on.  (Host-side files — transcript, verifier, pairing,
+    the launch code in h2agg.hip — do not enter the kernel's instruction stream and are left out, so that work on the
+    pipeline around the MSM does not void the counter evidence.)"""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(entry.PKG_DIR, "csrc")
-    for name in sorted(os.listdir(d)):
-        if name.endswith((".hpp", ".hip", ".inc", ".hpp")):
-            with open(os.path.join(d, name), "rb") as f:
-                h.update(name.encode() + b"\0" + f.read())
+    for name in ("fp.hpp", "g1.hpp", "msm_kernels.hpp", "sort_kernels.hpp", "batch_kernels.hpp"):
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
 
 
 def pmc_evidence(stage_name: str, log2n: int):
     """HBM-side bytes per launch (FETCH_SIZE / WRITE_SIZE) and the VALU view (SQ_INSTS_VALU, shader clock) of the dominant
     kernel from the committed rocprofv3 --pmc passes (tools/profile_round.sh -> tools/make_traffic_json.py ->
-    profiles/r02_traffic.json).  The counters cannot be collected inside this process, so the file carries the hash of
+    profiles/rNN_*traffic.json, newest round whose source hash matches).  The counters cannot be collected inside this process, so the file carries the hash of
     the kernel sources it was measured on: a mismatch (kernel changed since) yields null + "stale" instead of silently
     reporting old numbers."""
-    path = os.path.join(ROOT, "profiles", "r02_traffic.json")
-    try:
-        with open(path) as f:
-            t = json.load(f)
-    except (OSError, ValueError):
+    import glob
+    t, path, newest = None, None, None
+    for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*traffic.json")), reverse=True):   # newest round first
+        try:
+            with open(cand) as f:
+                got = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if not isinstance(got, dict) or "csrc_sha" not in got:
+            continue
+        newest = newest or (cand, got)
+        if got.get("csrc_sha") == csrc_sha():
+            t, path = got, cand
+            break
+    if newest is None:
         return None, None, "no PMC evidence file"
+    if t is None:
+        return None, None, "stale: kernel sources changed since %s was collected (csrc_sha %s != %s)" % (
+            os.path.relpath(newest[0], ROOT), newest[1].get("csrc_sha"), csrc_sha())
     if not (t.get("log2n") == log2n and stage_name == "msm_accumulate" and t.get("kernel") == "k_msm_accumulate"):
         return None, None, "PMC evidence is for a different workload"
-    if t.get("csrc_sha") != csrc_sha():
-        return None, None, "stale: kernel sources changed since profiles/r02_traffic.json was collected (csrc_sha %s != %s)" % (
-            t.get("csrc_sha"), csrc_sha())
+    rel = os.path.relpath(path, ROOT)
     simds = 256 * 4
     # cycles per wave-instruction per SIMD from ONE run: the PMC pass's own duration and clock
     cpi = t["duration_us"] * 1e-6 * t["shader_clock_hz"] * simds / t["valu_insts"]
@@ -111,8 +124,7 @@ def pmc_evidence(stage_name: str, log2n: int):
             # ~5 cycles at even wave counts, not the nominal 4): what the instruction stream can reach at all
             "measured_rate_cycles_per_instruction": t.get("measured_rate_cpi"),
             "issue_frac_at_measured_rates": (t["measured_rate_cpi"] / cpi) if t.get("measured_rate_cpi") else None,
-            "source": "profiles/r02_traffic.json (rocprofv3 --pmc passes of this command; instruction count, clock AND "
-                      "duration from the same pass)"}
+            "source": rel + " (rocprofv3 --pmc passes of this command; instruction count, clock AND duration from the same pass)"}
     return t["bytes_per_launch"], valu, "csrc_sha " + t["csrc_sha"]
 
 
@@ -261,7 +273,13 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    cpu_ctx = None
+    if world == 1 and n_total <= 16:
+        cpu_ctx = {"specs": specs, "lam": lam, "commits": [last_commits[i] for i in range(n_total)] if n_inst else None,
+                   "pair": pair, "n_inst": n_inst,
+                   "inst0": bytes(d_inst[0].cpu().numpy().tobytes()) if n_inst else None}
     return {
+        "_cpu_ctx": cpu_ctx,
         "proofs_per_sec": n_total / dt,
         "proofs": n_total,
         "seconds_per_aggregation": dt,
@@ -283,6 +301,55 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
     }
 
 
+def cpu_baseline_aggregate(eng, g_table, ctx, gpu_seconds):
+    """The reference's CPU path for the SAME aggregation the `aggregate` leg timed (cpu_baseline leg: the only place outside
+    tests/ that may touch oracle/): per proof assign_instance_commitment's naive loop (verify.rs:623-635) and the folded
+    evaluate_multiopen_proof with MockEccChip::multi_exp's naive loop (mock/arith/ecc.rs:106-129), one thread, restated in
+    C (oracle_multi_exp_naive) under the oracle's Python Fr bookkeeping.  The evaluation runs in full and must reproduce the
+    GPU's final pair; the instance-column loop (n_inst scalar multiplications per proof) is SAMPLED on its first 2048
+    terms and scaled — stated in `sample`."""
+    from oracle import bn254 as O, cref, schema as S
+
+    class CEccChip(S.OracleEccChip):
+        def multi_exp(self, cx, points, scalars):
+            cx.point_list = [O.debug_fmt(p) for p in points]
+            out = cref.multi_exp_naive(b"".join(O.aff_to_bytes(p) for p in points), b"".join(O.fe_to_bytes(v) for v in scalars), len(points))
+            return O.aff_from_bytes(out)
+
+    specs, lam, commits = ctx["specs"], ctx["lam"], ctx["commits"]
+    t0 = time.perf_counter()
+    proofs = []
+    for j, sp in enumerate(specs):
+        qs = []
+        for k in range(sp.nq):
+            c = sp.commitments[64 * k:64 * k + 64]
+            if k == 0 and commits is not None:
+                c = commits[j]
+            qs.append(S.evaluation_query(sp.rotations[k], sp.keys[k], O.fe_from_bytes(sp.points[32 * k:32 * k + 32]),
+                                         O.aff_from_bytes(c), O.fe_from_bytes(sp.evals[32 * k:32 * k + 32])))
+        w = [O.aff_from_bytes(sp.w[64 * i:64 * i + 64]) for i in range(len(sp.w) // 64)]
+        proofs.append(S.batch_multi_open_proofs(sp.key, qs, w, O.fe_from_bytes(sp.v), O.fe_from_bytes(sp.u)))
+    agg = S.aggregate_fold(proofs, O.fe_from_bytes(lam))
+    left, right, _names = S.evaluate_multiopen_proof(S.OracleCtx(), S.OracleFieldChip(), CEccChip(), agg)
+    t_eval = time.perf_counter() - t0
+    same = S.final_pair_bytes(left, right) == ctx["pair"][0] + ctx["pair"][1]
+    t_inst, m = 0.0, 0
+    if ctx["n_inst"]:
+        m = min(2048, ctx["n_inst"])
+        bases = eng.bases_download(g_table, 0, m)
+        t0 = time.perf_counter()
+        cref.multi_exp_naive(bases, ctx["inst0"][:32 * m], m)
+        t_inst = (time.perf_counter() - t0) * ctx["n_inst"] / m
+    n = len(specs)
+    total = t_eval + n * t_inst
+    return {"value": n / total, "unit": "proofs/s", "cores": 1, "kind": "port", "seconds_per_aggregation": total,
+            "evaluation_seconds": t_eval, "instance_commitment_seconds_per_proof": t_inst, "matches_gpu": same,
+            "gpu_over_cpu": total / gpu_seconds,
+            "sample": "the folded evaluate_multiopen_proof of the same %d proofs in full (%.2f s, final pair %s the GPU's); "
+                      "assign_instance_commitment's %d-term naive loop per proof timed on its first %d terms and scaled"
+                      % (n, t_eval, "equal to" if same else "DIFFERENT from", ctx["n_inst"], m)}
+
+
 def full_pipeline_leg(pkg, eng, args, g_table):
     """Third figure: the WHOLE path of calc_verify_circuit_final_pair (verify_circuit.rs:114-201) through ONE C-ABI call,
     h2agg_verify_aggregation — instance-column MSMs, point decompression, one Poseidon transcript per proof (every
@@ -301,7 +368,7 @@ def full_pipeline_leg(pkg, eng, args, g_table):
     vk = ver.VerifyingKey(eng, ver.encode_vk(shape, lambda p: p))
     n_inst = 64                                                  # public inputs per proof (small: the 2^17-point case is the aggregate leg's)
     fr = syn.fr_stream(0xF00D)
-    n_more = 16 if args.agg_proofs < 16 else 0                  # the transcripts are per-proof chains: more proofs ride the same wall time
+    n_more = 16 if args.agg_proofs < 16 else 0                  # a second size: the sponges are per-proof chains, one worker thread each
     proofs_all = [([b"".join(fr() for _ in range(n_inst))], shape.random_transcript(pool_c, 100 + i))
                   for i in range(max(args.agg_proofs, n_more))]
     proofs = proofs_all[:args.agg_proofs]
@@ -337,8 +404,13 @@ def full_pipeline_leg(pkg, eng, args, g_table):
             "poseidon_permutations_per_proof": (2 * (n_pts + n_w + 1) + n_evals + 1 + 7) // 8 + 10,
             "pairing_check": "ran, rejected (synthetic transcripts)" if not ok else "accepted",
             "at_16_proofs_per_gpu": more,
+            "transcript_backend": {"selected": "auto (h2agg_transcript_configure): host worker threads for small batches, "
+                                               "the device sponge for large ones",
+                                   "host_threads": pkg.host_threads(), "host_sponge_kernel": pkg.host_sponge_kind()},
             "note": "h2agg_verify_aggregation end to end on one GPU, one call; inputs are host buffers (proof bytes, "
-                    "instance values); transcript-latency-bound (DESIGN.md section 5)"}
+                    "instance values); the sponges (one dependent chain of ~136 permutations per proof) run on host worker "
+                    "threads under the recording of the schema they feed, point decompression / expressions / multi_exps on the "
+                    "device, the pairing on the host (DESIGN.md section 5)"}
 
 
 def main():
@@ -587,16 +659,23 @@ def main():
                 if args.agg_instance_log2 <= 18 and not args.no_fixed_base:
                     eng.bases_precompute(g_table)          # g_lagrange is fixed per circuit size: one-off SRS-style setup
             agg_info = aggregation_leg(pkg, eng, args, rank, world, dist, (dev, coll_dev), g_table)  # configs[2]/[3]: 4 proofs per GPU
+            cpu_ctx = agg_info.pop("_cpu_ctx", None)
             big = argparse.Namespace(**vars(args))
             big.agg_proofs = 4 * args.agg_proofs                                       # configs[4]: 16 proofs per GPU
             more = None
             if args.agg_instance_log2 < 20:     # (a config-5 run, --agg-proofs 16 --agg-instance-log2 22, is one leg only)
                 more = aggregation_leg(pkg, eng, big, rank, world, dist, (dev, coll_dev), g_table)
+                more.pop("_cpu_ctx", None)
             if agg_info is not None and more is not None:
                 agg_info["at_%d_proofs_per_gpu" % big.agg_proofs] = {
                     k: more[k] for k in ("proofs_per_sec", "proofs", "seconds_per_aggregation")}
             if agg_info is not None and world == 1 and g_table is not None and args.agg_instance_log2 <= 18:
                 agg_info["full_pipeline"] = full_pipeline_leg(pkg, eng, args, g_table)
+            if cpu_ctx is not None and rank == 0 and not args.no_cpu_baseline:
+                try:
+                    agg_info["cpu_baseline_aggregate"] = cpu_baseline_aggregate(eng, g_table, cpu_ctx, agg_info["seconds_per_aggregation"])
+                except Exception as ex:      # noqa: BLE001 - a baseline must never cost the measured figures
+                    agg_info["cpu_baseline_aggregate"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
 
     except Exception as ex:          # noqa: BLE001 - the headline must survive any failure of a secondary leg
         import traceback

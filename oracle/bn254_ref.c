@@ -526,7 +526,7 @@ static void g1z_double_aff(g1z *o, const fe *x, const fe *y) {      /* mdbl-2008
     QS(&t, &s, &o->x); QM(&t, &m, &t); QM(&u, &w, y); QS(&o->y, &t, &u);
     o->zz = v; o->zzz = w;
 }
-static inline __attribute__((always_inline)) void g1z_add_aff(g1z *a, const fe *x2, const fe *y2) {   /* madd-2008-s; (x2, y2) finite */
+static __attribute__((noinline)) void g1z_add_aff(g1z *a, const fe *x2, const fe *y2) {   /* madd-2008-s; (x2, y2) finite; ONE copy: ten inlined products per site would not fit the L1 instruction cache twice */
     if (g1z_is_inf(a)) { a->x = *x2; a->y = *y2; a->zz = FQ.r1; a->zzz = FQ.r1; return; }
     fe u2, s2, p, r, pp, ppp, q, t, v;
     QM(&u2, x2, &a->zz); QM(&s2, y2, &a->zzz);
@@ -624,12 +624,13 @@ static void *pip2_worker(void *arg) {
             const int32_t d = dg[i];
             if (!d || J->bases[i].inf) continue;
             if (i + 8 < hi) __builtin_prefetch(&buckets[dg[i + 8] < 0 ? -dg[i + 8] : dg[i + 8]]);
-            if (d > 0) g1z_add_aff(&buckets[d], &J->bases[i].x, &J->bases[i].y);
-            else {
-                fe ny;
-                fe_neg(&FQ, &ny, &J->bases[i].y);
-                g1z_add_aff(&buckets[-d], &J->bases[i].x, &ny);
+            fe ny;
+            const fe *y = &J->bases[i].y;
+            if (d < 0) {
+                fe_neg(&FQ, &ny, y);
+                y = &ny;
             }
+            g1z_add_aff(&buckets[d < 0 ? -d : d], &J->bases[i].x, y);
         }
         g1z run, sum;
         g1z_set_inf(&run);

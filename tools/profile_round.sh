@@ -3,7 +3,7 @@
 # never combined with other traces) for the dominant kernel.  Run on the GPU box from the repo root:
 #   tools/profile_round.sh r01_final      -> gpurun_out/<tag>_*.txt  (copy the ones to keep into profiles/)
 set -u
-tag=${1:-r01_final}
+tag=${1:-r03_final}
 root=$(pwd)
 out=$root/gpurun_out
 mkdir -p $out
@@ -30,4 +30,11 @@ cd $root
 cd /tmp && rm -rf /tmp/prof_agg && rocprofv3 --kernel-trace --stats -d /tmp/prof_agg -o agg -- python $root/tools/agg_phases.py --reps 10 > $out/${tag}_agg_phases.txt 2>/dev/null
 python $root/tools/rocpd_summary.py /tmp/prof_agg/agg_results.db > $out/${tag}_agg_kernel_stats.txt 2>&1
 cd $root
+# the from-bytes pipeline (h2agg_verify_aggregation) on both sponge backends + its phase split
+python tools/pipeline_time.py 4 16 64 > $out/${tag}_pipeline_time.txt 2>&1
+H2AGG_TRACE_PHASES=1 H2AGG_TRANSCRIPT=host python tools/pipeline_time.py 4 16 64 2>&1 | grep "phases" | awk 'NR%9==3' > $out/${tag}_pipeline_phases.txt
+# the default bench line itself (no profiler attached)
+python bench.py > $out/${tag}_bench_default.json 2> $out/${tag}_bench_default.err
+# everything to keep goes to profiles/ in ONE step (commit once):
+mkdir -p profiles && cp $out/${tag}_* profiles/
 ls -la $out | grep $tag
