@@ -1571,6 +1571,8 @@ int msm_host(h2agg_ctx* c, const uint8_t* bases, size_t stride, const uint8_t* s
     const size_t MIN_SLICE = (size_t)1 << 19;
     size_t nslices = n / MIN_SLICE;
     if (nslices > MSM_MAX_SLICES) nslices = MSM_MAX_SLICES;
+    static const int env_slices = getenv("H2AGG_PCIE_SLICES") ? atoi(getenv("H2AGG_PCIE_SLICES")) : 0;   // measurement knob
+    if (env_slices >= 1 && env_slices <= MSM_MAX_SLICES && n >= ((size_t)1 << 16) * (size_t)env_slices) nslices = (size_t)env_slices;
     if (nslices < 2) {
         HIP_TRY(c, hipMemcpyAsync(c->in_a.p, bases, stride * n, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->in_b.p, scalars, 32 * n, hipMemcpyHostToDevice, c->stream));

@@ -20,9 +20,11 @@
 
 namespace h2agg {
 
-// Experiment knob (A/B builds only): -DH2AGG_SORT_SETPRIO raises the issue priority of the sort's waves, so that beside the
-// VALU-saturating accumulation of the previous MSM (overlap level 3) their latency chains are served first.
-#ifdef H2AGG_SORT_SETPRIO
+// The sort's kernels are latency chains (address arithmetic, loads, one returning LDS atomic per key); whatever shares their
+// SIMDs — the previous MSM's Horner tail and window sums on the tail streams — is VALU-bound.  Raising the issue priority of
+// the sort's waves serves the chains first: 1.281 -> 1.258 ms per 2^20-point step (profiles/r03_sweeps.txt; A/B build with
+// -DH2AGG_NO_SORT_SETPRIO).
+#ifndef H2AGG_NO_SORT_SETPRIO
 #define SORT_PRIO() __builtin_amdgcn_s_setprio(3)
 #else
 #define SORT_PRIO() ((void)0)
