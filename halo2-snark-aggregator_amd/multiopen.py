@@ -2,6 +2,11 @@
 `SchemaBuilder`, or any object with the same `commit / evalq / scalar` constructors whose nodes support
 `+` and `*`).  Pure AST construction — no field or group arithmetic happens here.
 
+Status: the PRODUCT implementation of this fold is C++ (`Schema::batch_multi_open(_regs)` in csrc/schema.hpp, reached
+through h2agg_schema_batch_multi_open and h2agg_verify_aggregation).  This Python twin is what the tests and bench.py's
+`aggregate` leg build their trees with, node by node through the C ABI — a second route to the same tree, kept for
+differential checks (tests/test_gpu_schema.py::test_cpp_batch_builders_match_oracle), not a second product path.
+
 Mirrors
   EvaluationQuery::new                          halo2-snark-aggregator-api/src/systems/halo2/evaluation.rs:100-118
   VerifierParams::get_point_schemas             .../multiopen.rs:23-69
