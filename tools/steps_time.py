@@ -3,7 +3,7 @@
 Used with H2AGG_DBG_SKIP=1|3|7 (skip bucket reduction / + window sums / + Horner tail: WRONG results, timing only; needs a
 library built with -DH2AGG_MEASURE_KNOBS) to price the tails."""
 import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as e
 pkg = e.load_package()
 eng = pkg.H2Agg(0)
