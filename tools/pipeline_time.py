@@ -11,7 +11,7 @@ eng = pkg.H2Agg(0)
 syn = importlib.import_module(entry.PKG_NAME + ".synthetic")
 ver = importlib.import_module(entry.PKG_NAME + ".verifier")
 from bench import gen_scalars
-sizes = [int(a) for a in sys.argv[1:]] or [4, 16, 64]
+sizes = [int(a) for a in sys.argv[1:] if a.isdigit()] or [4, 16, 64]
 dev = torch.device('cuda', 0)
 _, gk = gen_scalars(7, 1 << 17)
 g_table = eng.bases_generate(torch.from_numpy(gk.copy()).to(dev).data_ptr(), 1 << 17)
@@ -30,18 +30,22 @@ print("host worker threads:", pkg.host_threads())
 for n in sizes:
     arg = [(vk, "syn", g_table, proofs_all[:n])]
     res = {}
-    for be in ("device", "host", "auto"):
+    for be in (("device", "host", "auto") if "--host-first" not in sys.argv else ("host", "auto", "device", "host")):
         eng.transcript_configure(be)
         for pair in (True, False):
             a = ver.verify_aggregation(eng, arg, g2 if pair else None, g2 if pair else None)
-            reps = 5
-            t0 = time.perf_counter()
+            reps = 9
+            ts = []
             for _ in range(reps):
+                t0 = time.perf_counter()
                 b = ver.verify_aggregation(eng, arg, g2 if pair else None, g2 if pair else None)
-            dt = (time.perf_counter() - t0) / reps
+                ts.append(time.perf_counter() - t0)
+            ts.sort()
+            dt = ts[len(ts) // 2]          # median; min and max beside it (a box hiccup of 20 ms is not the rate)
             assert a[:3] == b[:3]
             res[be] = a[:3]
-            print("%3d proofs  %-6s  %s  %8.3f ms  %8.1f proofs/s" % (n, be, "with pairing" if pair else "no pairing  ", dt * 1e3, n / dt), flush=True)
+            print("%3d proofs  %-6s  %s  %8.3f ms  %8.1f proofs/s   (min %.3f max %.3f)" % (
+                n, be, "with pairing" if pair else "no pairing  ", dt * 1e3, n / dt, ts[0] * 1e3, ts[-1] * 1e3), flush=True)
     assert res["device"] == res["host"] == res["auto"], "backends disagree"
 eng.transcript_configure("auto")
 vk.close()

@@ -33,7 +33,8 @@ cd $root
 # the from-bytes pipeline (h2agg_verify_aggregation) on both sponge backends + its phase split
 python tools/pipeline_time.py 4 16 64 > $out/${tag}_pipeline_time.txt 2>&1
 H2AGG_TRACE_PHASES=1 H2AGG_TRANSCRIPT=host python tools/pipeline_time.py 4 16 64 2>&1 | grep "phases" | awk 'NR%9==3' > $out/${tag}_pipeline_phases.txt
-# the default bench line itself (no profiler attached)
+# the default bench line itself (no profiler attached); it reads the PMC evidence just collected from profiles/
+mkdir -p profiles && cp $out/${tag}_traffic.json profiles/
 python bench.py > $out/${tag}_bench_default.json 2> $out/${tag}_bench_default.err
 # everything to keep goes to profiles/ in ONE step (commit once):
 mkdir -p profiles && cp $out/${tag}_* profiles/
