@@ -457,26 +457,28 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     // digit-major sort (sort_kernels.hpp): plain 16-bit windows over one table, 2^16 .. 2^22 points
     static const bool dm_env_off = getenv("H2AGG_SORT") && !strcmp(getenv("H2AGG_SORT"), "packed");
     const size_t dm_row = p.glv ? 2 * n : n;   // keys per window (GLV: both halves of a scalar land in the same 8 windows)
+    // (c = 17, plain scalars: 15 windows of 2^16 buckets, 16-bit magnitude codes + sign / zero bit rows — k_dm_digits17, k_dm_partition<true>)
+    const bool dm17 = p.c == 17 && !p.glv;
     const bool dm = !dm_env_off && !c->cfg_no_dm && !c->cfg_no_stage && !c->cfg_stage_l1 && !c->cfg_sub_bits && !c->cfg_tile && !pre && batch == 1 &&
-                    p.c == 16 && dm_row >= ((size_t)1 << 16) && dm_row <= ((size_t)1 << 22);
-    const uint32_t dm_nwin = p.glv ? 8u : 16u;
+                    (p.c == 16 || dm17) && dm_row >= ((size_t)1 << 16) && dm_row <= ((size_t)1 << 22);
+    const uint32_t dm_nwin = p.glv ? 8u : (dm17 ? 15u : 16u);
     DmPlan dp{};
     if (dm) {
         const size_t n = dm_row;   // (shadows the point count inside this block)
         dp.n_pts = p.glv ? (uint32_t)(dm_row / 2) : 0xffffffffu;
         dp.n = (uint32_t)n;
-        dp.n_pad = (uint32_t)((n + 7) & ~(size_t)7);
+        dp.n_pad = dm17 ? (uint32_t)((n + 63) & ~(size_t)63) : (uint32_t)((n + 7) & ~(size_t)7);   // (17-bit windows: bit rows, 64 keys per word)
         dp.ntile = (uint32_t)((n + DM_T1 - 1) / DM_T1);
         dp.n_row = dp.ntile * (uint32_t)DM_T1;
-        dp.ppw = 64;
+        dp.ppw = dm17 ? 128 : 64;   // (level 2 keeps <= 512 buckets per partition in LDS: sub_bits <= 9)
         while (n / dp.ppw > 4096 && dp.ppw < (uint32_t)DM_MAX_PPW) dp.ppw *= 2;   // ~4 K keys per level-2 partition (8 K at 2^22)
-        dp.sub_bits = 15;
+        dp.sub_bits = p.c - 1;
         for (uint32_t q = dp.ppw; q > 1; q >>= 1) --dp.sub_bits;
         dp.SB = 1u << dp.sub_bits;
         dp.idx_bits = 31 - dp.sub_bits;
     }
     TRY(ensure(c, c->item_idx, dm ? (size_t)dm_nwin * dp.n_row * 4 : nent * 4));
-    TRY(ensure(c, c->item_sub, dm ? (size_t)dm_nwin * dp.n_pad * 2 : nent * 2));
+    TRY(ensure(c, c->item_sub, dm ? (size_t)dm_nwin * dp.n_pad * 2 + (dm17 ? (size_t)2 * dm_nwin * (dp.n_pad / 8) : 0) : nent * 2));
     TRY(ensure(c, c->entries[sq], nent * 4));
     // buckets / segsum / wsum exist once per tail slot: in overlap mode the reduction of MSM k (tail stream)
     // runs while MSM k+1 fills the next slot's set.  (They were one allocation cut at par * this-plan's-size: two MSMs
@@ -484,7 +486,8 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     const int par = c->parity;
     TRY(ensure(c, c->buckets[par], (size_t)p.NBT * XYZZ_BYTES));
     {   // (the two-dimensional reduction keeps 4096 partial sums per window there)
-        const size_t r2d_records = p.NB == (uint32_t)(R2D_ROWS * R2D_COLS) ? (size_t)WT * (R2D_THREADS + 2) : 0;
+        const size_t r2d_records = p.NB == (uint32_t)(R2D_ROWS * R2D<7>::COLS) ? (size_t)WT * (R2D<7>::THREADS + 2)
+                                   : p.NB == (uint32_t)(R2D_ROWS * R2D<8>::COLS) ? (size_t)WT * (R2D<8>::THREADS + 2) : 0;
         TRY(ensure(c, c->segsum[par], (nseg_total > r2d_records ? nseg_total : r2d_records) * XYZZ_BYTES));
     }
     TRY(ensure(c, c->wsum[par], (size_t)WT * XYZZ_BYTES));
@@ -554,13 +557,19 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
             const unsigned dg = (unsigned)((n + BLOCK * DM_DIG_PER - 1) / (BLOCK * DM_DIG_PER));
             if (p.glv)   // d_scalars: the decomposed words (range-checked by k_glv_decompose)
                 hipLaunchKernelGGL(k_dm_digits_glv, dim3(dg), dim3(BLOCK), 0, st, d_scalars, (uint32_t)n, dp.n_pad, item_sub);
+            else if (dm17)
+                hipLaunchKernelGGL(k_dm_digits17, dim3(dg), dim3(BLOCK), 0, st, d_scalars, dp.n, dp.n_pad, item_sub, c->d_flags);
             else
                 hipLaunchKernelGGL(k_dm_digits, dim3(dg), dim3(BLOCK), 0, st, d_scalars, dp.n, dp.n_pad, item_sub, c->d_flags);
         }
         {
             StageTimer t(c, ST_PART_SCATTER);
-            hipLaunchKernelGGL(k_dm_partition, dim3(dp.ntile, dm_nwin), dim3(DM_TB1), 0, st, (const uint16_t*)item_sub, dp, pcount,
-                               tile_counts, item_idx);
+            if (dm17)
+                hipLaunchKernelGGL(k_dm_partition<true>, dim3(dp.ntile, dm_nwin), dim3(DM_TB1), 0, st, (const uint16_t*)item_sub, dp, pcount,
+                                   tile_counts, item_idx);
+            else
+                hipLaunchKernelGGL(k_dm_partition<false>, dim3(dp.ntile, dm_nwin), dim3(DM_TB1), 0, st, (const uint16_t*)item_sub, dp, pcount,
+                                   tile_counts, item_idx);
                 hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)pcount, PW, pstart);
             }
         {
@@ -708,7 +717,8 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
 #endif
     // two-dimensional bucket reduction for 16-bit windows (msm_kernels.hpp); H2AGG_REDUCE=segments keeps the segment kernels
     static const bool r2d_env_off = getenv("H2AGG_REDUCE") && !strcmp(getenv("H2AGG_REDUCE"), "segments");
-    const bool r2d = !r2d_env_off && !c->cfg_seg && !pre && p.NB == (uint32_t)(R2D_ROWS * R2D_COLS);
+    const int r2d_lc = p.NB == (uint32_t)(R2D_ROWS * R2D<7>::COLS) ? 7 : p.NB == (uint32_t)(R2D_ROWS * R2D<8>::COLS) ? 8 : 0;
+    const bool r2d = !r2d_env_off && !c->cfg_seg && !pre && r2d_lc != 0;
     uint32_t* ticket = nullptr;
     if (r2d) {
         DevBuf& tk = c->r2d_ticket[par];   // arrival counters of the two half-window workgroups: zero between MSMs
@@ -738,15 +748,23 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
             c->accdone_pending[sq] = true;
         }
         if (r2d) {
+            const uint32_t per_w = r2d_lc == 7 ? (uint32_t)R2D<7>::THREADS : (uint32_t)R2D<8>::THREADS;
             if (!(dbg_skip & 1)) {
                 StageTimer t(c, ST_REDUCE, ts);
-                const uint32_t total = WT * (uint32_t)R2D_THREADS;
-                hipLaunchKernelGGL(k_msm_reduce2d_parts, dim3(total / 64), dim3(64), 0, ts, (const uint8_t*)buckets, total, segsum);
+                const uint32_t total = WT * per_w;
+                if (r2d_lc == 7)
+                    hipLaunchKernelGGL(k_msm_reduce2d_parts<7>, dim3(total / 64), dim3(64), 0, ts, (const uint8_t*)buckets, total, segsum);
+                else
+                    hipLaunchKernelGGL(k_msm_reduce2d_parts<8>, dim3(total / 64), dim3(64), 0, ts, (const uint8_t*)buckets, total, segsum);
             }
             if (!(dbg_skip & 2)) {
                 StageTimer t(c, ST_WINDOW_SUM, ts);
-                hipLaunchKernelGGL(k_msm_reduce2d_window, dim3(WT, 2), dim3(R2D_TB), 0, ts, (const uint8_t*)segsum,
-                                   segsum + XYZZ_BYTES * (size_t)WT * R2D_THREADS, ticket, wsum);
+                if (r2d_lc == 7)
+                    hipLaunchKernelGGL(k_msm_reduce2d_window<7>, dim3(WT, 2), dim3(R2D_TB), 0, ts, (const uint8_t*)segsum,
+                                       segsum + XYZZ_BYTES * (size_t)WT * per_w, ticket, wsum);
+                else
+                    hipLaunchKernelGGL(k_msm_reduce2d_window<8>, dim3(WT, 2), dim3(R2D_TB), 0, ts, (const uint8_t*)segsum,
+                                       segsum + XYZZ_BYTES * (size_t)WT * per_w, ticket, wsum);
             }
         } else {
             if (!(dbg_skip & 1)) {

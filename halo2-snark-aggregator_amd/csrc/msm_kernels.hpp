@@ -310,10 +310,16 @@ __global__ void __launch_bounds__(BLOCK) k_msm_window_sum(const uint8_t* __restr
 //     sum_b (b + 1) B_b  =  128 * sum_h h R_h  +  sum_l (l + 1) C_l,      R_h = sum_l B[h][l],   C_l = sum_h B[h][l],
 // turns the bulk of the work into PLAIN sums — two additions per bucket as before, but independent ones: one lane each,
 // every lane busy, chains of 16 — and leaves two weighted sums over 256 and 128 points per window for one workgroup.
-constexpr int R2D_LCOLS = 7, R2D_COLS = 1 << R2D_LCOLS, R2D_ROWS = 256, R2D_L = 16;
-constexpr int R2D_RPARTS = R2D_COLS / R2D_L, R2D_CPARTS = R2D_ROWS / R2D_L;              // 8 row parts, 16 column parts
-constexpr int R2D_ROW_THREADS = R2D_ROWS * R2D_RPARTS, R2D_THREADS = 2 * R2D_ROW_THREADS;   // 2048 + 2048 per window
-static_assert(R2D_ROWS * R2D_RPARTS == R2D_COLS * R2D_CPARTS, "row and column parts are laid out back to back");
+// The grid is 256 rows x 2^LC columns: LC = 7 for 16-bit windows (2^15 buckets), LC = 8 for 17-bit windows (2^16 buckets).
+constexpr int R2D_ROWS = 256, R2D_L = 16;
+template <int LC>
+struct R2D {
+    static constexpr int LCOLS = LC, COLS = 1 << LC;
+    static constexpr int RPARTS = COLS / R2D_L, CPARTS = R2D_ROWS / R2D_L;               // LC = 7: 8 row parts, 16 column parts
+    static constexpr int ROW_THREADS = R2D_ROWS * RPARTS, COL_THREADS = COLS * CPARTS;   // LC = 7: 2048 + 2048 per window
+    static constexpr int THREADS = ROW_THREADS + COL_THREADS;
+};
+constexpr int R2D_COLS = R2D<7>::COLS, R2D_THREADS = R2D<7>::THREADS;   // (the 16-bit grid: what the host sizes by default)
 
 // 64 XYZZ records, one per lane, fetched by the wave as ONE 9216-byte block: slot g = 64 q + lane of the block is piece
 // g % 9 of lane g / 9's record, so consecutive lanes ask for consecutive 16-byte pieces (whole lines, each fetched once —
@@ -351,22 +357,27 @@ FP_INLINE G1XYZZ r2d_own(const uint32_t* lds_block, int lane) {
 // parts[w * 4096 + t]: t < 2048: row h = t >> 3, part j = t & 7: sum of B[h][j + 8 i], i < 16
 //                      t >= 2048: u = t - 2048, part j = u >> 7, column l = u & 127: sum of B[j + 16 i][l], i < 16
 // One-wave workgroups; a wave is all row parts or all column parts, so the step between a lane's records is wave-uniform.
+template <int LC>
 __global__ void __launch_bounds__(64) k_msm_reduce2d_parts(const uint8_t* __restrict__ buckets, uint32_t total,
                                                            uint8_t* __restrict__ parts) {
+    typedef R2D<LC> G;
     __shared__ __attribute__((aligned(16))) uint32_t blk[2][9 * 256];
     const int lane = threadIdx.x;
+    // (one chain per lane.  Two chains per lane — half the one-wave workgroups, to leave the next MSM's sort more LDS — was tried
+    // for the 256 x 256 grid and lost: the kernel then runs twice as long beside that sort, 1.22 -> 1.41 ms per step.)
     const uint32_t g = blockIdx.x * 64 + lane;
-    const uint32_t w = g / R2D_THREADS, t = g - w * R2D_THREADS;
+    {
+    const uint32_t w = g / G::THREADS, t = g - w * G::THREADS;
     uint32_t base, stride;
-    if (t < (uint32_t)R2D_ROW_THREADS) {
-        base = (t >> 3) * R2D_COLS + (t & 7);
-        stride = R2D_RPARTS;
-    } else {
-        const uint32_t u = t - R2D_ROW_THREADS;
-        base = (u >> R2D_LCOLS) * R2D_COLS + (u & (R2D_COLS - 1));
-        stride = R2D_CPARTS * R2D_COLS;
+    if (t < (uint32_t)G::ROW_THREADS) {            // row h = t / RPARTS, part j = t % RPARTS: B[h][j + RPARTS i], i < 16
+        base = (t / G::RPARTS) * G::COLS + (t % G::RPARTS);
+        stride = G::RPARTS;
+    } else {                                       // part j = u >> LC, column l: B[j + 16 i][l], i < 16
+        const uint32_t u = t - G::ROW_THREADS;
+        base = (u >> G::LCOLS) * G::COLS + (u & (G::COLS - 1));
+        stride = G::CPARTS * G::COLS;
     }
-    const uint8_t* B = buckets + XYZZ_BYTES * (size_t)w * (R2D_ROWS * R2D_COLS);
+    const uint8_t* B = buckets + XYZZ_BYTES * (size_t)w * (R2D_ROWS * G::COLS);
     uint32_t off[9];   // byte offset (from B) of the piece this lane fetches in round q
 #pragma unroll
     for (int q = 0; q < 9; ++q) {
@@ -387,6 +398,7 @@ __global__ void __launch_bounds__(64) k_msm_reduce2d_parts(const uint8_t* __rest
         acc = xyzz_add_chains(acc, cur);
     }
     if (g < total) xyzz_store(parts + XYZZ_BYTES * (size_t)g, acc);
+    }
 }
 
 constexpr int R2D_TB = 256;   // one wave per SIMD: every level of the scans below costs one addition's latency
@@ -416,39 +428,50 @@ FP_INLINE G1XYZZ r2d_get(const uint32_t* lds, int slot) {
 // weights l + 1, so S_0 counts too): a Hillis-Steele suffix scan and a tree, both log-depth, instead of a serial running
 // sum.  The second workgroup of a window to finish adds the two halves into wsum[w] (ticket[w] counts arrivals and is left
 // at zero again).
+template <int LC>
 __global__ void __launch_bounds__(R2D_TB) k_msm_reduce2d_window(const uint8_t* __restrict__ parts,
                                                                  uint8_t* __restrict__ halves /* [2 * windows] XYZZ */,
                                                                  uint32_t* __restrict__ ticket,
                                                                  uint8_t* __restrict__ wsum) {
+    typedef R2D<LC> G;
+    static_assert(LC == 7 || LC == 8, "128 columns (two threads each) or 256 (one thread each) for 256 threads");
     __shared__ uint32_t lds[XYZZ_WORDS * R2D_TB];
     __shared__ uint32_t last_flag;
     const int tid = threadIdx.x;
     const uint32_t w = blockIdx.x;
     const bool rows = blockIdx.y == 0;
-    const uint8_t* P = parts + XYZZ_BYTES * (size_t)w * R2D_THREADS;
-    // element `pos` of the group lives in LDS slot pos * sl; columns: slots 2l (the odd threads only feed the first level)
-    const int sl = rows ? 1 : 2;
-    const int pos = rows ? tid : (tid >> 1);
-    const int n = rows ? R2D_ROWS : R2D_COLS;
-    const bool owner = rows || (tid & 1) == 0;
-    const int lg = rows ? 8 : 7;   // log2(n)
+    const uint8_t* P = parts + XYZZ_BYTES * (size_t)w * G::THREADS;
+    // element `pos` of the group lives in LDS slot pos * sl; 128 columns: slots 2l (the odd threads only feed the first level)
+    constexpr bool two_per_col = LC == 7;
+    const int sl = (rows || !two_per_col) ? 1 : 2;
+    const int pos = (rows || !two_per_col) ? tid : (tid >> 1);
+    const int n = rows ? R2D_ROWS : G::COLS;
+    const bool owner = rows || !two_per_col || (tid & 1) == 0;
+    const int lg = rows ? 8 : LC;   // log2(n)
     G1XYZZ v;
     {
         const uint8_t* src;
         size_t step;
+        int cnt;
         if (rows) {
-            src = P + XYZZ_BYTES * (size_t)(tid * R2D_RPARTS);
+            src = P + XYZZ_BYTES * (size_t)(tid * G::RPARTS);
             step = XYZZ_BYTES;
+            cnt = G::RPARTS;
+        } else if (two_per_col) {
+            src = P + XYZZ_BYTES * (size_t)(G::ROW_THREADS + (8 * (tid & 1)) * G::COLS + (tid >> 1));
+            step = XYZZ_BYTES * (size_t)G::COLS;
+            cnt = 8;
         } else {
-            src = P + XYZZ_BYTES * (size_t)(R2D_ROW_THREADS + (8 * (tid & 1)) * R2D_COLS + (tid >> 1));
-            step = XYZZ_BYTES * (size_t)R2D_COLS;
+            src = P + XYZZ_BYTES * (size_t)(G::ROW_THREADS + tid);
+            step = XYZZ_BYTES * (size_t)G::COLS;
+            cnt = G::CPARTS;
         }
         v = xyzz_load(src);
         G1XYZZ nxt = xyzz_load(src + step);
 #pragma unroll 1
-        for (int j = 1; j < 8; ++j) {
+        for (int j = 1; j < cnt; ++j) {
             const G1XYZZ cur = nxt;
-            if (j + 1 < 8) nxt = xyzz_load(src + step * (j + 1));
+            if (j + 1 < cnt) nxt = xyzz_load(src + step * (j + 1));
             v = xyzz_add(v, cur);
         }
     }
@@ -456,7 +479,7 @@ __global__ void __launch_bounds__(R2D_TB) k_msm_reduce2d_window(const uint8_t* _
     __syncthreads();
     // levels: [columns only: the two halves] | suffix scan, d = 1, 2, .. n/2 | S_0 := 0 for rows | tree, s = n/2 .. 1
     // ONE inlined addition serves them all (the operand's slot and the "active" predicate change per level)
-    const int first = rows ? 1 : 0;
+    const int first = (rows || !two_per_col) ? 1 : 0;
 #pragma unroll 1
     for (int lv = first; lv <= 2 * lg; ++lv) {
         int partner;
@@ -486,7 +509,7 @@ __global__ void __launch_bounds__(R2D_TB) k_msm_reduce2d_window(const uint8_t* _
     if (tid == 0) {
         if (rows) {
 #pragma unroll 1
-            for (int k = 0; k < R2D_LCOLS; ++k) v = xyzz_double(v);
+            for (int k = 0; k < G::LCOLS; ++k) v = xyzz_double(v);
         }
         xyzz_store(halves + XYZZ_BYTES * (size_t)(2 * w + blockIdx.y), v);
         __threadfence();

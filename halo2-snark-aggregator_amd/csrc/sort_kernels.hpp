@@ -752,6 +752,53 @@ __global__ void __launch_bounds__(BLOCK) k_dm_digits(const uint8_t* __restrict__
     if (bad) atomicOr(flags, FLAG_NONCANONICAL);
 }
 
+// c = 17 (15 windows, 2^16 buckets each): the magnitudes m in [1, 2^16] take all 65 536 16-bit codes (m - 1), so sign and
+// "zero digit" travel beside them as BIT rows (one bit per key, written 64 at a time from a wave's ballot):
+//   codes[w * n_pad + i] = m - 1 (0 for a zero digit)      sign row w, zero row w: n_pad / 8 bytes each, behind the codes
+// — 2.25 bytes per key instead of 2, one window less everywhere else.  Window w covers bits [17 w, 17 w + 17); r < 2^254 leaves
+// the top window (w = 14, bits 238..253) 16 bits + the carry: no carry out.  n_pad is a multiple of 64 here.
+constexpr int DM17_W = 15;
+FP_INLINE const uint8_t* dm17_flags(const uint16_t* codes, uint32_t n_pad) {
+    return reinterpret_cast<const uint8_t*>(codes + (size_t)DM17_W * n_pad);
+}
+__global__ void __launch_bounds__(BLOCK) k_dm_digits17(const uint8_t* __restrict__ scalars, uint32_t n, uint32_t n_pad,
+                                                       uint16_t* __restrict__ codes, uint32_t* flags) {
+    SORT_PRIO();
+    const uint32_t i0 = blockIdx.x * (BLOCK * DM_DIG_PER) + threadIdx.x;
+    uint64_t* bits = reinterpret_cast<uint64_t*>(codes + (size_t)DM17_W * n_pad);   // [2 * DM17_W][n_pad / 64]
+    const uint32_t row64 = n_pad >> 6;
+    uint32_t bad = 0;
+#pragma unroll 1
+    for (int k = 0; k < DM_DIG_PER; ++k) {
+        const uint32_t i = i0 + k * BLOCK;
+        const bool act = i < n;
+        if (__ballot(i < n_pad) == 0) break;            // (wave-uniform: the wave's 64 keys start at a multiple of 64)
+        U256 s;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s.w[j] = 0;
+        if (act) s = u256_load(scalars + 32 * (size_t)i);
+        bad |= act && !u256_is_canonical_fr(s);
+        uint32_t carry = 0;
+#pragma unroll
+        for (int w = 0; w < DM17_W; ++w) {
+            const int pos = 17 * w, wd = pos >> 5, sh = pos & 31;
+            uint32_t v = s.w[wd] >> sh;
+            if (sh > 15 && wd + 1 < 8) v |= s.w[wd + 1] << (32 - sh);
+            const uint32_t raw = (v & 0x1ffffu) + carry;
+            const bool neg = raw > 0x10000u;
+            carry = neg ? 1u : 0u;
+            const uint32_t m = neg ? 0x20000u - raw : raw;   // 0 .. 2^16
+            const uint64_t sm = __ballot(act && neg), zm = __ballot(!act || m == 0);
+            if (i < n_pad) codes[(size_t)w * n_pad + i] = (uint16_t)(m ? m - 1u : 0u);
+            if ((threadIdx.x & 63) == 0 && i < n_pad) {
+                bits[(size_t)w * row64 + (i >> 6)] = sm;
+                bits[(size_t)(DM17_W + w) * row64 + (i >> 6)] = zm;
+            }
+        }
+    }
+    if (bad) atomicOr(flags, FLAG_NONCANONICAL);
+}
+
 // GLV: `words` are glv_decompose() outputs (two sign-magnitude 127-bit halves).  Both halves are recoded over the same 8
 // windows; row w holds the first halves' digits at [0, n) and the second halves' at [n, 2n).
 __global__ void __launch_bounds__(BLOCK) k_dm_digits_glv(const uint8_t* __restrict__ words, uint32_t n, uint32_t n_pad,
@@ -845,6 +892,7 @@ __global__ void __launch_bounds__(1024) k_dm_scan(const uint32_t* __restrict__ i
 
 // grid (ntile, W).  items[w * n_row + tile * DM_T1 + k], k < toff[..][ppw]: the tile's keys ordered by partition;
 // toff[(w * ntile + tile) * (ppw + 1) + p]: where partition p starts inside the tile; pcount[w * ppw + p] += its length
+template <bool WIDE>   // WIDE: 32-bit codes of k_dm_digits17 (`codes` then points at uint32_t), otherwise the 16-bit codes
 __global__ void __launch_bounds__(DM_TB1) k_dm_partition(const uint16_t* __restrict__ codes, DmPlan dp,
                                                          uint32_t* __restrict__ pcount, uint32_t* __restrict__ toff,
                                                          uint32_t* __restrict__ items) {
@@ -857,26 +905,54 @@ __global__ void __launch_bounds__(DM_TB1) k_dm_partition(const uint16_t* __restr
     __syncthreads();
     const size_t row = (size_t)w * dp.n_pad;
     const uint32_t t0 = tile * DM_T1;
-    uint4 v[DM_PER1 / 8];
+    // a thread's DM_PER1 keys sit in runs of G = 8 consecutive points: one 16-byte load of codes each (WIDE: + the run's sign
+    // and zero bytes of k_dm_digits17's bit rows)
+    constexpr int G = 8, NV = DM_PER1 / G;
+    uint4 v[NV];
+    uint32_t sg[NV], zr[NV];
 #pragma unroll
-    for (int k = 0; k < DM_PER1 / 8; ++k) {
-        const uint32_t i0 = t0 + (k * DM_TB1 + tid) * 8;
-        v[k] = (i0 < dp.n_pad) ? *reinterpret_cast<const uint4*>(codes + row + i0)
-                               : make_uint4(0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u);
+    for (int k = 0; k < NV; ++k) {
+        const uint32_t i0 = t0 + (k * DM_TB1 + tid) * G;
+        sg[k] = 0;
+        zr[k] = 0xffu;
+        if (WIDE) {
+            v[k] = make_uint4(0, 0, 0, 0);
+            if (i0 < dp.n_pad) {
+                const uint8_t* fl = dm17_flags(codes, dp.n_pad);
+                const size_t rb = dp.n_pad >> 3;
+                v[k] = *reinterpret_cast<const uint4*>(codes + row + i0);
+                sg[k] = fl[(size_t)w * rb + (i0 >> 3)];
+                zr[k] = fl[(size_t)(DM17_W + w) * rb + (i0 >> 3)];
+            }
+        } else {
+            v[k] = (i0 < dp.n_pad) ? *reinterpret_cast<const uint4*>(codes + row + i0)
+                                   : make_uint4(0x80008000u, 0x80008000u, 0x80008000u, 0x80008000u);
+        }
     }
+    // key e of load k: (valid, bucket inside the window, sign)
+    auto decode = [&](int k, int e, uint32_t& bkt, uint32_t& neg) -> bool {
+        const uint32_t wd[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+        const uint32_t code = (wd[e >> 1] >> (16 * (e & 1))) & 0xffffu;
+        if (WIDE) {
+            bkt = code;
+            neg = (sg[k] >> e) & 1u;
+            return !((zr[k] >> e) & 1u);
+        }
+        neg = code >> 15;
+        bkt = neg ? (code & 0x7fffu) - 1u : code;
+        return code != DM_ZERO;
+    };
     uint32_t pr[DM_PER1];   // partition << 16 | rank inside (tile, partition); 0xffffffff: no key
     const uint32_t submask = dp.SB - 1u;
 #pragma unroll
-    for (int k = 0; k < DM_PER1 / 8; ++k) {
-        const uint32_t wd[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+    for (int k = 0; k < NV; ++k) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const uint32_t code = (wd[e >> 1] >> (16 * (e & 1))) & 0xffffu;
-            const uint32_t i = t0 + (k * DM_TB1 + tid) * 8 + e;
-            const bool ok = code != DM_ZERO && i < dp.n;
-            const uint32_t bkt = (code & 0x8000u) ? (code & 0x7fffu) - 1u : code;
+        for (int e = 0; e < G; ++e) {
+            uint32_t bkt, neg;
+            const uint32_t i = t0 + (k * DM_TB1 + tid) * G + e;
+            const bool ok = decode(k, e, bkt, neg) && i < dp.n;
             const uint32_t p = bkt >> dp.sub_bits;
-            pr[k * 8 + e] = ok ? ((p << 16) | atomicAdd(&cnt[p], 1u)) : 0xffffffffu;
+            pr[k * G + e] = ok ? ((p << 16) | atomicAdd(&cnt[p], 1u)) : 0xffffffffu;
         }
     }
     __syncthreads();
@@ -888,16 +964,14 @@ __global__ void __launch_bounds__(DM_TB1) k_dm_partition(const uint16_t* __restr
     uint32_t* tt = toff + ((size_t)w * dp.ntile + tile) * (dp.ppw + 1);
     for (uint32_t p = tid; p <= dp.ppw; p += DM_TB1) tt[p] = cnt[p];
 #pragma unroll
-    for (int k = 0; k < DM_PER1 / 8; ++k) {
-        const uint32_t wd[4] = {v[k].x, v[k].y, v[k].z, v[k].w};
+    for (int k = 0; k < NV; ++k) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const uint32_t q = pr[k * 8 + e];
+        for (int e = 0; e < G; ++e) {
+            const uint32_t q = pr[k * G + e];
             if (q == 0xffffffffu) continue;
-            const uint32_t code = (wd[e >> 1] >> (16 * (e & 1))) & 0xffffu;
-            const uint32_t neg = code >> 15;
-            const uint32_t bkt = neg ? (code & 0x7fffu) - 1u : code;
-            const uint32_t i = t0 + (k * DM_TB1 + tid) * 8 + e;
+            uint32_t bkt, neg;
+            decode(k, e, bkt, neg);
+            const uint32_t i = t0 + (k * DM_TB1 + tid) * G + e;
             stage[cnt[q >> 16] + (q & 0xffffu)] = ((bkt & submask) << (dp.idx_bits + 1)) | (neg << dp.idx_bits) | i;
         }
     }

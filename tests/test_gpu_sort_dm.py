@@ -131,3 +131,50 @@ def test_reduction_paths_agree(eng):
         eng.msm_configure(0, 0, 0)
         eng.msm_configure_glv(0)
         eng.bases_free(table)
+
+
+# ---- 17-bit windows (15 windows of 2^16 buckets; 32-bit digit codes, 256 x 256 reduction grid) ---------------------------
+def _run17(eng, ks, ss):
+    n = len(ks)
+    dev = torch.device("cuda", 0)
+    d_k = torch.from_numpy(_bytes(ks).copy()).to(dev)
+    d_s = torch.from_numpy(_bytes(ss).copy()).to(dev)
+    table = eng.bases_generate(d_k.data_ptr(), n)
+    want = O.aff_to_bytes(O.scalar_mul(sum(k * s for k, s in zip(ks, ss)) % R, O.G1))
+    try:
+        eng.msm_configure_glv(-1)
+        got = {}
+        for c in (17, 16):
+            eng.msm_configure(c, 0, 0)
+            got[c] = eng.g1_batch_to_affine(eng.g1_msm_device(table, d_s.data_ptr(), n))
+        eng.msm_configure(17, 0, 0)
+        eng.msm_configure_sort(0, -3)       # the packed two-level sort + segment reduction: the same plan through other kernels
+        got["packed17"] = eng.g1_batch_to_affine(eng.g1_msm_device(table, d_s.data_ptr(), n))
+        assert got[17] == want
+        assert got[16] == want and got["packed17"] == want
+    finally:
+        eng.msm_configure_sort(0, 0)
+        eng.msm_configure(0, 0, 0)
+        eng.msm_configure_glv(0)
+        eng.bases_free(table)
+
+
+@pytest.mark.parametrize("n", [1 << 16, (1 << 16) + 5, 100003, (1 << 18) + 8191, 1 << 20, (1 << 21) + 12345])
+def test_c17_random_scalars(eng, n):
+    _run17(eng, _rand(n, 11 * n + 1), _rand(n, 11 * n + 2))
+
+
+def test_c17_structured_scalars(eng):
+    """17-bit digits at both ends of the signed range (+2^16, -(2^16 - 1)), carries rippling through all 15 windows, the top
+    window's 16 bits + carry, zero digits, one value in every lane (one bucket per window holds everything)"""
+    n = (1 << 16) + 77
+    ks = _rand(n, 6)
+    half = sum(0x10000 << (17 * w) for w in range(14))         # every digit exactly +2^16
+    ripple = sum(0x1ffff << (17 * w) for w in range(14))       # ... all ones: digit -1 then carries all the way up
+    over = sum(0x10001 << (17 * w) for w in range(14))         # first negative magnitude (2^16 - 1)
+    pats = [0, 1, R - 1, half, ripple, over, 1 << 238, (1 << 253) + 12345, 0x20000, 0x1ffff0001ffff, (1 << 254) - 1 - (1 << 200)]
+    pats = [v % R for v in pats]
+    _run17(eng, ks, [pats[i % len(pats)] for i in range(n)])
+    _run17(eng, ks, [R - 1] * n)
+    _run17(eng, ks, [0] * n)
+    _run17(eng, ks, [0x1234_5678_9abc_def0_1111_2222_3333_4444_5555_6666_7777_8888_9999_aaaa_bbbb % R] * n)

@@ -20,6 +20,8 @@ out = torch.zeros(96 * K, dtype=torch.uint8, device=dev)
 t = eng.bases_generate(dk.data_ptr(), n)
 import os
 eng.msm_set_tail_overlap(int(os.environ.get('LEVEL', '2')))
+if os.environ.get('WINDOW'):
+    eng.msm_configure(int(os.environ['WINDOW']), 0, 0)
 if PROF:
     eng.profile_enable(True, only_stage=4)
 for rep in range(3):
