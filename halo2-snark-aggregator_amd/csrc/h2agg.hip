@@ -109,6 +109,9 @@ struct h2agg_ctx {
 
     // host-buffer MSM: slices are copied on this stream while the previous slice is computed
     hipStream_t copy_stream = nullptr;
+    // verifier pipeline: point decompression of a circuit's proofs runs here, beside the instance-column MSMs
+    hipStream_t aux_stream = nullptr;
+    hipEvent_t ev_aux = nullptr, ev_aux_go = nullptr;
     hipEvent_t ev_copy[8] = {}, ev_ready = nullptr;
 
     std::map<uint64_t, Table> tables;
@@ -939,6 +942,12 @@ void h2agg_destroy(h2agg_ctx* c) {
             if (c->ev_copy[k]) hipEventDestroy(c->ev_copy[k]);
         if (c->ev_ready) hipEventDestroy(c->ev_ready);
         hipStreamDestroy(c->copy_stream);
+    }
+    if (c->aux_stream) {
+        hipStreamSynchronize(c->aux_stream);
+        if (c->ev_aux) hipEventDestroy(c->ev_aux);
+        if (c->ev_aux_go) hipEventDestroy(c->ev_aux_go);
+        hipStreamDestroy(c->aux_stream);
     }
     for (int r = 0; r < h2agg_ctx::PROF_RING; ++r)
         for (int s = 0; s < ST_N; ++s)

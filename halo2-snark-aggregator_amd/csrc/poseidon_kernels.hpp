@@ -248,11 +248,14 @@ __global__ void __launch_bounds__(BLOCK) k_transcript_elements(const uint8_t* __
                                                                uint32_t nproofs, uint32_t npoints,
                                                                uint8_t* __restrict__ points_out /* [proof][npoints][64] */,
                                                                uint8_t* __restrict__ elems, size_t elem_stride,
-                                                               uint32_t* flags) {
+                                                               uint32_t* flags, int which = 0) {
+    // which: 0 = every item; 1 = everything but the external points (what depends on the proof bytes only: runs beside the
+    // instance-column MSMs that produce the external points); 2 = the external points only
     const size_t total = (size_t)nproofs * nitems;
     for (size_t t = (size_t)blockIdx.x * BLOCK + threadIdx.x; t < total; t += (size_t)gridDim.x * BLOCK) {
         const uint32_t p = (uint32_t)(t / nitems);
         const TrItem it = items[t % nitems];
+        if ((which == 1 && it.kind == TR_POINT_EXT) || (which == 2 && it.kind != TR_POINT_EXT)) continue;
         uint8_t* e = elems + (size_t)p * elem_stride + 32 * (size_t)it.dst;
         if (it.kind == TR_CONST) {
             const Fr c = fp_load<FrParams>(consts + 32 * (size_t)it.src);

@@ -29,7 +29,10 @@
 namespace h2agg {
 
 // ------------------------------------------------------------------ device side: Fr tape
-enum : uint32_t { TAPE_MUL = 0, TAPE_ADD = 1, TAPE_SUB = 2, TAPE_INV = 3 };   // INV: dst = 1 / a (b unused); 1 / 0 raises FLAG_DIV_ZERO
+enum : uint32_t { TAPE_MUL = 0, TAPE_ADD = 1, TAPE_SUB = 2, TAPE_INV = 3,     // INV: dst = 1 / a (b unused); 1 / 0 raises FLAG_DIV_ZERO
+                  TAPE_SQRN = 4 };   // dst = a^(2^b), b an IMMEDIATE count (not a register): `pow_constant(x, n)` for n = 2^k
+                                     // (verify.rs:498) as ONE operation — k dependent squarings are k levels of the tape otherwise,
+                                     // each a round trip through the register file; recorded by the verifier pipeline only
 struct TapeOp {
     uint32_t dst, a, b, op;
 };
@@ -66,6 +69,12 @@ FP_INLINE Fr tape_exec(const TapeOp& op, const uint32_t* regs, uint32_t* flags) 
         if (fp_is_zero_mod<2, FrParams>(a)) atomicOr(flags, FLAG_DIV_ZERO);
         return fp_inv<FrParams>(a);
     }
+    if (op.op == TAPE_SQRN) {
+        Fr r = a;
+#pragma unroll 1
+        for (uint32_t i = 0; i < op.b; ++i) r = fp_sqr<FrParams>(r);
+        return r;
+    }
     const Fr b = reg_load(regs, op.b);
     if (op.op == TAPE_MUL) return fp_mul<FrParams>(a, b);                   // 4/169 + 1 -> < 2r
     if (op.op == TAPE_ADD) return fr_fold_2r(fp_add<FrParams>(a, b));      // < 4r -> < 2r
@@ -97,15 +106,26 @@ constexpr int TAPE_THREADS = 1024;
 __global__ void __launch_bounds__(TAPE_THREADS) k_tape_run(const TapeOp* __restrict__ ops,
                                                            const uint32_t* __restrict__ level_start,
                                                            uint32_t nlevels, uint32_t* __restrict__ regs, uint32_t* flags) {
+    // A level is a dependent round trip: operation -> operands -> result -> barrier.  The operation descriptors do not depend
+    // on any result, so a lane fetches the one it will run in the NEXT level before it waits at this level's barrier
+    // (one memory latency less per level: ~60 levels per aggregation).
+    uint32_t lo = nlevels ? level_start[0] : 0, hi = nlevels ? level_start[1] : 0;
+    TapeOp nxt = {0, 0, 0, 0};
+    if (lo + threadIdx.x < hi) nxt = ops[lo + threadIdx.x];
 #pragma unroll 1
     for (uint32_t l = 0; l < nlevels; ++l) {
-        const uint32_t lo = level_start[l], hi = level_start[l + 1];
+        const TapeOp first = nxt;
+        const uint32_t lo_n = hi, hi_n = l + 1 < nlevels ? level_start[l + 2] : hi;
+        if (l + 1 < nlevels && lo_n + threadIdx.x < hi_n) nxt = ops[lo_n + threadIdx.x];
+        if (lo + threadIdx.x < hi) reg_store(regs, first.dst, tape_exec(first, regs, flags));
 #pragma unroll 1
-        for (uint32_t i = lo + threadIdx.x; i < hi; i += TAPE_THREADS) {
+        for (uint32_t i = lo + threadIdx.x + TAPE_THREADS; i < hi; i += TAPE_THREADS) {
             const TapeOp op = ops[i];
             reg_store(regs, op.dst, tape_exec(op, regs, flags));
         }
         __syncthreads();  // workgroup-scope release/acquire: the next level reads these registers
+        lo = lo_n;
+        hi = hi_n;
     }
 }
 

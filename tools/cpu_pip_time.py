@@ -1,6 +1,6 @@
 """per-thread speed of the oracle's CPU Pippenger on this host: n points, c, threads"""
 import sys, time
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import cref, bn254 as O
 import numpy as np
 n = 1 << int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 16

@@ -3,7 +3,7 @@
 Same synthetic P = 347 key as bench.py's `aggregate.full_pipeline` leg; prints ms per aggregation and proofs/s, and checks
 that the two backends return the same pair and lambda."""
 import importlib, sys, time, types
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import __graft_entry__ as entry
 pkg = entry.load_package()
