@@ -68,7 +68,8 @@ struct PreTable {   // what msm_run needs of it
 
 }  // namespace
 
-constexpr int MSM_MAX_SLICES = 8;
+constexpr int MSM_MAX_SLICES = 16;
+enum { CHAIN_OFF = 0, CHAIN_FIRST = 1, CHAIN_MID = 2, CHAIN_LAST = 3 };
 
 struct h2agg_ctx {
     int device = 0;
@@ -112,7 +113,7 @@ struct h2agg_ctx {
     // verifier pipeline: point decompression of a circuit's proofs runs here, beside the instance-column MSMs
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_aux = nullptr, ev_aux_go = nullptr;
-    hipEvent_t ev_copy[8] = {}, ev_ready = nullptr;
+    hipEvent_t ev_copy[MSM_MAX_SLICES] = {}, ev_copy_s[MSM_MAX_SLICES] = {}, ev_ready = nullptr;
 
     std::map<uint64_t, Table> tables;
     uint64_t next_handle = 1;
@@ -142,6 +143,17 @@ struct h2agg_ctx {
     hipEvent_t ev_bulk[TAIL_SLOTS] = {}, ev_tail[TAIL_SLOTS] = {};
     bool tail_pending[TAIL_SLOTS] = {};
     int parity = 0;   // slot of the next MSM
+    // Slices of ONE MSM that share a bucket set (an MSM is a sum over points: the slices' bucket sums just add up, so only
+    // the last slice needs the bucket reduction / window sums / Horner tail — one latency chain per MSM instead of one per
+    // slice).  0 = off; CHAIN_FIRST / CHAIN_MID: sort + accumulation only, the slot does not rotate; CHAIN_LAST: accumulation
+    // on top of what the slot holds, then the tail.  chain_n: the point count the plan is made for (every slice the same
+    // plan); chain_glv: the plan's endomorphism split.
+    int chain = 0;
+    size_t chain_n = 0;
+    bool chain_glv = false;
+    // called by msm_run on the stream of the accumulation, behind the sort and in front of the first kernel that reads the
+    // bases: the host-buffer MSM waits there for the slice's bases (the sort only needs the scalars, which cross PCIe first)
+    std::function<int(hipStream_t)> bases_hook;
     // overlap level 3: the bucket accumulation of MSM k runs on its own stream, under the sort of MSM k+1 (which stays on the
     // context's stream, ordered after whatever the caller queued there).  The sort's outputs exist twice.
     // Deferred tail (overlap level >= 2): the tail of MSM k is launched from the NEXT MSM's call, behind that MSM's sort —
@@ -377,7 +389,14 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
             uint32_t batch = 1, const uint8_t* d_endo_x = nullptr, const PreTable* pre = nullptr) {
     const size_t n = n_base * batch;   // scalars
     if (n >= ((size_t)1 << 30)) return fail(c, H2AGG_ERR_INVALID, "n must be < 2^30");
-    MsmPlan p = make_plan(c, n_base, batch);
+    const int chain = (pre || batch != 1) ? CHAIN_OFF : c->chain;
+    MsmPlan p = make_plan(c, chain ? c->chain_n : n_base, batch);
+    if (chain && p.glv != c->chain_glv) {   // (the caller fixed the split for the whole chain)
+        const int was = c->cfg_glv;
+        c->cfg_glv = c->chain_glv ? 1 : -1;
+        p = make_plan(c, c->chain_n, batch);
+        c->cfg_glv = was;
+    }
     int Wd = p.W;                             // digit positions per scalar (what the recoding loops over)
     if (pre) {
         p.glv = false;
@@ -539,10 +558,13 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         }
     }
 
+    bool endo_late = false;   // (with a bases hook the beta*x column is computed behind it, in front of the accumulation)
     if (p.glv && !d_endo_x) {
         TRY(ensure(c, c->endo_buf, n_base * 32));
-        hipLaunchKernelGGL(k_bases_endo_x, dim3(grid_for(c, n_base)), dim3(BLOCK), 0, st, d_bases, n_base,
-                           (uint8_t*)c->endo_buf.p);
+        if (c->bases_hook) endo_late = true;
+        else
+            hipLaunchKernelGGL(k_bases_endo_x, dim3(grid_for(c, n_base)), dim3(BLOCK), 0, st, d_bases, n_base,
+                               (uint8_t*)c->endo_buf.p);
         d_endo_x = (const uint8_t*)c->endo_buf.p;
     }
     if (p.glv) {  // k = k1 + lambda*k2: the sort below reads the decomposed words instead of the scalars
@@ -663,26 +685,38 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     if (c->cfg_lpb) lpb = (uint32_t)c->cfg_lpb;
     else   // ... but only while the mean run still covers the slices (measured, profiles/r01_sweeps.txt): sparse buckets
            // (small MSMs with wide windows) gain nothing from slices and pay lpb - 1 additions per bucket in the combine
-        while (lpb < 8 && (size_t)p.NBT * lpb < (size_t)8192 * 64 && nent >= (size_t)lpb * p.NBT) lpb *= 2;
+        while (lpb < 8 && (size_t)p.NBT * lpb < (size_t)8192 * 64 &&
+               (chain ? c->chain_n * (size_t)Wd * (p.glv ? 2 : 1) : nent) >= (size_t)lpb * p.NBT)
+            lpb *= 2;   // (a chain's slices all cut their buckets alike: the slots are resumed)
+    if (c->bases_hook) {
+        TRY(c->bases_hook(st));
+        if (endo_late)
+            hipLaunchKernelGGL(k_bases_endo_x, dim3(grid_for(c, n_base)), dim3(BLOCK), 0, st, d_bases, n_base, (uint8_t*)c->endo_buf.p);
+    }
     uint8_t* acc_out = buckets;
     if (lpb > 1) {
         TRY(ensure(c, c->parts, (size_t)p.NBT * lpb * XYZZ_BYTES));
         acc_out = (uint8_t*)c->parts.p;
     }
-    constexpr int acc_block = 64;
+    // (experiment knob: 256-thread workgroups + H2AGG_ACC_LDS pin the accumulation at exactly N waves per SIMD and leave the rest
+    // of the CU — registers and LDS — to whatever else is in flight; see profiles/r03_sweeps.txt section 10)
+    static const int acc_block = getenv("H2AGG_ACC_BLOCK") ? atoi(getenv("H2AGG_ACC_BLOCK")) : 64;
     {
         StageTimer t(c, ST_ACCUM, st);
         // one-wave workgroups: a 4-wave workgroup needs a free slot on all four SIMDs of a CU at once and its waves retire
         // at different times; single waves fill any slot as it frees up (2^20 points: 1.74 -> 1.67 ms/step)
         static const int acc_lds = getenv("H2AGG_ACC_LDS") ? atoi(getenv("H2AGG_ACC_LDS")) : 0;   // experiment: unused LDS per wave caps the occupancy
-        hipLaunchKernelGGL(k_msm_accumulate, dim3((unsigned)(((size_t)p.NBT * lpb + acc_block - 1) / acc_block)), dim3(acc_block), (size_t)acc_lds,
+        auto kacc = chain == CHAIN_FIRST ? k_msm_accumulate<1> : (chain == CHAIN_MID || chain == CHAIN_LAST) ? k_msm_accumulate<2> : k_msm_accumulate<0>;
+        hipLaunchKernelGGL(kacc, dim3((unsigned)(((size_t)p.NBT * lpb + acc_block - 1) / acc_block)), dim3(acc_block), (size_t)acc_lds,
                            st, d_bases, d_endo_x, entries, offs, hist, ordered ? order : (uint32_t*)nullptr, p.NBT, p.big, lpb, acc_out,
                            big_list, big_keys, big_count);
     }
     // Buckets longer than `big` (skewed scalars; none for uniform ones, where the two launches below only find empty lists):
     // with alternating sort outputs they leave the bulk stream and go in front of the bucket reduction on the tail stream,
     // followed by the zeroing of this slot's counters for the MSM after next.
-    const bool tail_big = altbuf && c->overlap_level >= 2 && lpb == 1;
+    const bool tail_big = altbuf && c->overlap_level >= 2 && lpb == 1 && (chain == CHAIN_OFF || chain == CHAIN_LAST);
+    const uint32_t resume = (chain == CHAIN_MID || chain == CHAIN_LAST) ? 1u : 0u;
+    const bool chain_open = chain == CHAIN_FIRST || chain == CHAIN_MID;   // no tail yet
     // (no bucket can hold more keys than its bucket set receives: a multi_exp of a dozen points skips the two launches,
     // ~35 us at the head of its tail)
     const bool big_possible = nent / WT > p.big;
@@ -693,13 +727,15 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         const size_t cap = (size_t)c->cu_count * 8;   // one-wave workgroups, grid-stride over the (usually empty) lists
         if (grid > cap) grid = cap;
         hipLaunchKernelGGL(k_msm_accumulate_big, dim3((unsigned)grid), dim3(64), 0, bs, d_bases, d_endo_x, entries, offs, hist,
-                           acc_out, lpb, big_part, big_list, big_count);
+                           acc_out, lpb, big_part, big_list, big_count, resume);
         size_t gk = max_keys < cap ? max_keys : cap;
         hipLaunchKernelGGL(k_msm_big_combine, dim3((unsigned)gk), dim3(64), 0, bs, big_part, big_keys, big_count,
-                           acc_out, lpb);
-        if (lpb > 1)
+                           acc_out, lpb, resume);
+        // (in a chain only the last slice folds the slice slots, and it folds ALL of them: a bucket that is over-long in this
+        // slice may hold ordinary partial sums from earlier ones)
+        if (lpb > 1 && !chain_open)
             hipLaunchKernelGGL(k_msm_bucket_combine, dim3((p.NBT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, bs,
-                               (const uint8_t*)acc_out, hist, p.NBT, p.big, lpb, buckets);
+                               (const uint8_t*)acc_out, hist, p.NBT, chain ? 0xffffffffu : p.big, lpb, buckets);
     };
     if (!tail_big) {
         big_kernels(st);
@@ -709,6 +745,11 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         }
     }
     if (altbuf) c->sort_par ^= 1;
+    if (chain_open) {   // the bucket set stays open for the next slice: no tail, the slot does not rotate
+        HIP_TRY(c, hipGetLastError());
+        profile_end_call(c);
+        return H2AGG_OK;
+    }
     // Everything after the bucket accumulation is latency-shaped (one wave per SIMD or less): bucket
     // reduction, per-window sums, Horner tail.  In overlap mode it runs on one of the context's tail streams, under the
     // accumulation of the next MSM (launched from that MSM's call, behind its sort: `deferred_tail`); results are picked
@@ -938,8 +979,10 @@ void h2agg_destroy(h2agg_ctx* c) {
     if (c->h_stage) hipHostFree(c->h_stage);
     if (c->copy_stream) {
         hipStreamSynchronize(c->copy_stream);
-        for (int k = 0; k < MSM_MAX_SLICES; ++k)
+        for (int k = 0; k < MSM_MAX_SLICES; ++k) {
             if (c->ev_copy[k]) hipEventDestroy(c->ev_copy[k]);
+            if (c->ev_copy_s[k]) hipEventDestroy(c->ev_copy_s[k]);
+        }
         if (c->ev_ready) hipEventDestroy(c->ev_ready);
         hipStreamDestroy(c->copy_stream);
     }
@@ -1417,24 +1460,26 @@ int h2agg_g1_msm_device_async(h2agg_ctx* c, uint64_t handle, const void* d_scala
     }
     const size_t SLICE = (size_t)1 << 22;
     if (n <= SLICE) return msm_run(c, it->second.d, (const uint8_t*)d_scalars, n, (uint8_t*)d_out_jac, 1, endo);
+    // The slices share ONE bucket set (chain modes of msm_run): every slice adds its points to the sums the buckets already
+    // hold, and only the last one is followed by the bucket reduction / window sums / Horner tail.
     const size_t nsl = (n + SLICE - 1) / SLICE;
-    TRY(ensure(c, c->out, 96 * nsl));
     const bool was_overlap = c->tail_overlap;
     const int was_level = c->overlap_level;
     c->tail_overlap = true;
     c->overlap_level = 2;
+    c->chain_n = n;
+    c->chain_glv = false;
     int rc = H2AGG_OK;
     for (size_t k = 0; k < nsl && rc == H2AGG_OK; ++k) {
         const size_t off = k * SLICE, m = n - off < SLICE ? n - off : SLICE;
-        rc = msm_run(c, it->second.d + 64 * off, (const uint8_t*)d_scalars + 32 * off, m, (uint8_t*)c->out.p + 96 * k, 1,
-                     endo + 32 * off);
+        c->chain = k == 0 ? CHAIN_FIRST : (k + 1 == nsl ? CHAIN_LAST : CHAIN_MID);
+        rc = msm_run(c, it->second.d + 64 * off, (const uint8_t*)d_scalars + 32 * off, m, (uint8_t*)d_out_jac, 1, endo + 32 * off);
     }
+    c->chain = CHAIN_OFF;
     c->tail_overlap = was_overlap;
     c->overlap_level = was_level;
     TRY(rc);
-    TRY(join_tails(c));
-    hipLaunchKernelGGL(k_g1_sum, dim3(1), dim3(BLOCK), 0, c->stream, (const uint8_t*)c->out.p, nsl, (uint8_t*)d_out_jac,
-                       c->d_flags);
+    if (!was_overlap) TRY(join_tails(c));   // without overlap mode the caller's stream orders the result
     return H2AGG_OK;
 } catch (const std::bad_alloc&) {
     return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
@@ -1595,11 +1640,16 @@ int msm_host(h2agg_ctx* c, const uint8_t* bases, size_t stride, const uint8_t* s
     // Large inputs are cut into slices that cross PCIe on a copy stream while the previous slice is being computed
     // (an MSM is a sum over points, so the slices' results just add up): 96 B/point of transfer hide under ~1.7 ns/point
     // of arithmetic, instead of preceding it.  Slices of >= 2^19 points keep the per-MSM efficiency (2^18-point slices lose more than the overlap gains).
-    const size_t MIN_SLICE = (size_t)1 << 19;
-    size_t nslices = n / MIN_SLICE;
+    const bool chain_env_off = getenv("H2AGG_PCIE_CHAIN") && !strcmp(getenv("H2AGG_PCIE_CHAIN"), "0");
+    const bool chained = !chain_env_off;
+    // chained slices (below) of ~200 K points: the transfer (1.73 ns/point) and the slice's sort + accumulation (~90 us +
+    // 1.3 ns/point) then take turns of equal length — measured, profiles/r03_sweeps.txt section 10: 2^20 points 3.03 / 2.97 /
+    // 2.92 / 2.96 / 3.15 ms with 3 / 4 / 5 / 6 / 8 slices
+    const size_t MIN_SLICE = chained ? (size_t)200 << 10 : (size_t)1 << 19;
+    size_t nslices = chained ? (n + MIN_SLICE / 2) / MIN_SLICE : n / MIN_SLICE;
     if (nslices > MSM_MAX_SLICES) nslices = MSM_MAX_SLICES;
-    static const int env_slices = getenv("H2AGG_PCIE_SLICES") ? atoi(getenv("H2AGG_PCIE_SLICES")) : 0;   // measurement knob
-    if (env_slices >= 1 && env_slices <= MSM_MAX_SLICES && n >= ((size_t)1 << 16) * (size_t)env_slices) nslices = (size_t)env_slices;
+    const int env_slices = getenv("H2AGG_PCIE_SLICES") ? atoi(getenv("H2AGG_PCIE_SLICES")) : 0;   // measurement knob (read per call: tests vary it)
+    if (env_slices >= 1 && env_slices <= MSM_MAX_SLICES && n >= ((size_t)1 << 10) * (size_t)env_slices) nslices = (size_t)env_slices;
     if (nslices < 2) {
         HIP_TRY(c, hipMemcpyAsync(c->in_a.p, bases, stride * n, hipMemcpyHostToDevice, c->stream));
         HIP_TRY(c, hipMemcpyAsync(c->in_b.p, scalars, 32 * n, hipMemcpyHostToDevice, c->stream));
@@ -1614,7 +1664,10 @@ int msm_host(h2agg_ctx* c, const uint8_t* bases, size_t stride, const uint8_t* s
     }
     if (!c->copy_stream) {
         HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        for (int k = 0; k < MSM_MAX_SLICES; ++k) HIP_TRY(c, hipEventCreateWithFlags(&c->ev_copy[k], hipEventDisableTiming));
+        for (int k = 0; k < MSM_MAX_SLICES; ++k) {
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_copy[k], hipEventDisableTiming));
+            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_copy_s[k], hipEventDisableTiming));
+        }
         HIP_TRY(c, hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
     }
     TRY(ensure(c, c->out, 96 * MSM_MAX_SLICES));
@@ -1624,37 +1677,65 @@ int msm_host(h2agg_ctx* c, const uint8_t* bases, size_t stride, const uint8_t* s
     const size_t per = (n + nslices - 1) / nslices;
     const bool was_overlap = c->tail_overlap;
     const int was_level = c->overlap_level;
-    c->tail_overlap = true;   // slice k's reduction / Horner tail under slice k+1's sort + accumulation
+    c->tail_overlap = true;
     c->overlap_level = 2;
+    // The slices share one bucket set (chain modes of msm_run): slice k only sorts its keys and adds its points to the bucket
+    // sums; ONE reduction / window-sum / Horner chain follows the last slice — that chain (0.6-0.9 ms of pure latency) is what
+    // is left exposed behind the last byte of the transfer, so the slices can be small.  H2AGG_PCIE_CHAIN=0: the earlier
+    // scheme (every slice a whole MSM, results added) for A/B runs.
+    const int chain_glv_env = getenv("H2AGG_PCIE_GLV") ? atoi(getenv("H2AGG_PCIE_GLV")) : 0;
+    if (chained) {
+        c->chain_n = n;
+        c->chain_glv = chain_glv_env ? chain_glv_env > 0 : (c->cfg_glv >= 0 && n < ((size_t)1 << 22));
+    }
     int rc = H2AGG_OK;
     size_t done = 0, k = 0;
     for (; done < n && rc == H2AGG_OK; done += per, ++k) {
         const size_t m = n - done < per ? n - done : per;
         hipError_t e = hipMemcpyAsync((uint8_t*)c->in_b.p + 32 * done, scalars + 32 * done, 32 * m, hipMemcpyHostToDevice,
                                       c->copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(c->ev_copy_s[k], c->copy_stream);
         if (e == hipSuccess)
             e = hipMemcpyAsync((uint8_t*)c->in_a.p + stride * done, bases + stride * done, stride * m, hipMemcpyHostToDevice,
                                c->copy_stream);
         if (e == hipSuccess) e = hipEventRecord(c->ev_copy[k], c->copy_stream);
-        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, c->ev_copy[k], 0);
+        // the sort of a slice only reads its scalars: it runs while the slice's bases are still on their way (chained
+        // slices; the earlier scheme waits for both, as it always did)
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, chained ? c->ev_copy_s[k] : c->ev_copy[k], 0);
         if (e != hipSuccess) {
             rc = fail(c, H2AGG_ERR_HIP, hipGetErrorString(e));
             break;
         }
-        if (stride == 96)
-            hipLaunchKernelGGL(k_jac_to_mont_affine, dim3(grid_for(c, (m + TA_K - 1) / TA_K)), dim3(BLOCK), 0, c->stream,
-                               (const uint8_t*)c->in_a.p + 96 * done, m, (uint8_t*)c->tmp_bases.p + 64 * done, c->d_flags);
-        else
-            hipLaunchKernelGGL(k_bases_to_mont, dim3(grid_for(c, m)), dim3(BLOCK), 0, c->stream,
-                               (const uint8_t*)c->in_a.p + 64 * done, m, (uint8_t*)c->tmp_bases.p + 64 * done, c->d_flags);
+        auto convert = [=](hipStream_t st) {
+            if (stride == 96)
+                hipLaunchKernelGGL(k_jac_to_mont_affine, dim3(grid_for(c, (m + TA_K - 1) / TA_K)), dim3(BLOCK), 0, st,
+                                   (const uint8_t*)c->in_a.p + 96 * done, m, (uint8_t*)c->tmp_bases.p + 64 * done, c->d_flags);
+            else
+                hipLaunchKernelGGL(k_bases_to_mont, dim3(grid_for(c, m)), dim3(BLOCK), 0, st,
+                                   (const uint8_t*)c->in_a.p + 64 * done, m, (uint8_t*)c->tmp_bases.p + 64 * done, c->d_flags);
+        };
+        if (chained) {
+            c->chain = done == 0 ? CHAIN_FIRST : (done + per >= n ? CHAIN_LAST : CHAIN_MID);
+            hipEvent_t ev_bases = c->ev_copy[k];
+            c->bases_hook = [=](hipStream_t st) -> int {
+                HIP_TRY(c, hipStreamWaitEvent(st, ev_bases, 0));
+                convert(st);
+                return H2AGG_OK;
+            };
+        } else {
+            convert(c->stream);
+        }
         rc = msm_run(c, (const uint8_t*)c->tmp_bases.p + 64 * done, (const uint8_t*)c->in_b.p + 32 * done, m,
-                     (uint8_t*)c->out.p + 96 * k);
+                     chained ? c->d_res_jac : (uint8_t*)c->out.p + 96 * k);
+        c->bases_hook = nullptr;
     }
+    c->chain = CHAIN_OFF;
     c->tail_overlap = was_overlap;
     c->overlap_level = was_level;
     TRY(rc);
     TRY(join_tails(c));
-    hipLaunchKernelGGL(k_g1_sum, dim3(1), dim3(BLOCK), 0, c->stream, (const uint8_t*)c->out.p, k, c->d_res_jac, c->d_flags);
+    if (!chained)
+        hipLaunchKernelGGL(k_g1_sum, dim3(1), dim3(BLOCK), 0, c->stream, (const uint8_t*)c->out.p, k, c->d_res_jac, c->d_flags);
     return fetch_result_jac(c, out);
 }
 }   // namespace

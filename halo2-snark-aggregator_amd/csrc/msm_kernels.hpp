@@ -82,6 +82,10 @@ FP_INLINE uint32_t big_chunk_size(uint32_t len) {
     return cs;
 }
 
+// CHAIN (slices of one MSM sharing one bucket set, h2agg.hip `msm_run` chain modes): 0 = a whole MSM; 1 = first slice (like 0,
+// but an over-long bucket's unused slice slots are set to the identity so that later slices can resume from them); 2 = later
+// slice: every lane starts from the sum its slot already holds and leaves it alone when the slice has nothing for it.
+template <int CHAIN>
 __global__ void __launch_bounds__(BLOCK) k_msm_accumulate(const uint8_t* __restrict__ bases,
                                                           const uint8_t* __restrict__ endo_x,
                                                           const uint32_t* __restrict__ entries,
@@ -102,7 +106,10 @@ __global__ void __launch_bounds__(BLOCK) k_msm_accumulate(const uint8_t* __restr
     const uint32_t key = order ? order[t / lpb] : t / lpb;   // (small MSMs skip the ordering pass)
     const uint32_t len = hist[key];
     if (len > big) {
-        if (part != 0) return;
+        if (part != 0) {
+            if (CHAIN == 1) xyzz_store(buckets + XYZZ_BYTES * ((size_t)key * lpb + part), G1XYZZ::identity());
+            return;
+        }
         const uint32_t cs = big_chunk_size(len);
         const uint32_t nch = (len + cs - 1) / cs;
         const uint32_t base = atomicAdd(&counters[0], nch);
@@ -123,12 +130,18 @@ __global__ void __launch_bounds__(BLOCK) k_msm_accumulate(const uint8_t* __restr
     const uint32_t* run = entries + offs[key];
     G1XYZZ acc = G1XYZZ::identity();
     uint32_t k0 = lo;
+    bool fresh = true;
+    if (CHAIN == 2) {
+        if (hi == lo) return;
+        acc = xyzz_load(buckets + XYZZ_BYTES * ((size_t)key * lpb + part));
+        fresh = acc.is_identity();
+    }
     // The first point of a bucket is a copy and the second an affine + affine addition (4M + 2S): both outside the loop,
     // which then only ever sees the 8M + 2S mixed addition.  (Identity bases are skipped; a lane that meets some simply
     // enters the loop at its own k0.)
     G1Affine first;
     bool have_first = false;
-    while (k0 < hi && !have_first) {
+    while (fresh && k0 < hi && !have_first) {
         first = msm_gather(bases, endo_x, run[k0++]);
         have_first = !first.is_identity();
     }
@@ -220,7 +233,8 @@ __global__ void __launch_bounds__(64) k_msm_accumulate_big(const uint8_t* __rest
                                                            uint8_t* __restrict__ buckets, uint32_t stride /* lpb */,
                                                            uint8_t* __restrict__ big_part,
                                                            const uint32_t* __restrict__ big_list,
-                                                           const uint32_t* __restrict__ counters) {
+                                                           const uint32_t* __restrict__ counters,
+                                                           uint32_t resume /* later slice of a chain: add to what the slot holds */) {
     __shared__ uint32_t lds[XYZZ_WORDS * 64];
     const uint32_t nslots = counters[0];
     for (uint32_t b = blockIdx.x; b < nslots; b += gridDim.x) {
@@ -233,8 +247,10 @@ __global__ void __launch_bounds__(64) k_msm_accumulate_big(const uint8_t* __rest
 #pragma unroll 1
         for (uint32_t k = lo + threadIdx.x; k < hi; k += 64) xyzz_add_affine(acc, msm_gather(bases, endo_x, run[k]));
         G1XYZZ tot = wave_sum_xyzz(acc, lds);
-        if (threadIdx.x == 0)
+        if (threadIdx.x == 0) {
+            if (nch == 1 && resume) tot = xyzz_add(tot, xyzz_load(buckets + XYZZ_BYTES * (size_t)key * stride));
             xyzz_store(nch == 1 ? buckets + XYZZ_BYTES * (size_t)key * stride : big_part + XYZZ_BYTES * (size_t)b, tot);
+        }
         __syncthreads();
     }
 }
@@ -242,7 +258,7 @@ __global__ void __launch_bounds__(64) k_msm_accumulate_big(const uint8_t* __rest
 __global__ void __launch_bounds__(64) k_msm_big_combine(const uint8_t* __restrict__ big_part,
                                                         const uint32_t* __restrict__ big_keys,
                                                         const uint32_t* __restrict__ counters,
-                                                        uint8_t* __restrict__ buckets, uint32_t stride /* lpb */) {
+                                                        uint8_t* __restrict__ buckets, uint32_t stride /* lpb */, uint32_t resume) {
     __shared__ uint32_t lds[XYZZ_WORDS * 64];
     const uint32_t nkeys = counters[1];
     for (uint32_t k = blockIdx.x; k < nkeys; k += gridDim.x) {
@@ -252,7 +268,10 @@ __global__ void __launch_bounds__(64) k_msm_big_combine(const uint8_t* __restric
         for (uint32_t j = threadIdx.x; j < nch; j += 64)
             acc = xyzz_add(acc, xyzz_load(big_part + XYZZ_BYTES * (size_t)(base + j)));
         G1XYZZ tot = wave_sum_xyzz(acc, lds);
-        if (threadIdx.x == 0) xyzz_store(buckets + XYZZ_BYTES * (size_t)key * stride, tot);
+        if (threadIdx.x == 0) {
+            if (resume) tot = xyzz_add(tot, xyzz_load(buckets + XYZZ_BYTES * (size_t)key * stride));
+            xyzz_store(buckets + XYZZ_BYTES * (size_t)key * stride, tot);
+        }
         __syncthreads();
     }
 }

@@ -1,0 +1,134 @@
+"""GPU: slices of ONE multi_exp that share a bucket set (`msm_run`'s chain modes in csrc/h2agg.hip): the host-buffer MSM
+(`h2agg_g1_msm`, the call behind ArithEccChip::multi_exp in the drop-in, mock/arith/ecc.rs:106-129) cuts its input into slices
+that cross PCIe while the previous one is accumulated; only the last slice is followed by the bucket reduction / Horner tail.
+Every slice resumes the bucket sums the earlier ones left — including buckets that are over-long (chunked path) in some slices
+and ordinary in others, and the lanes-per-bucket slice slots of small plans.
+
+Expected values: (sum k_i s_i) G from the Python oracle; the unchained scheme (H2AGG_PCIE_CHAIN=0) must agree bit for bit."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import bn254 as O
+from tests.util import fr_bytes
+
+pytestmark = pytest.mark.gpu
+
+
+def _vals(n, seed):
+    rng = np.random.Generator(np.random.PCG64(seed))
+    raw = rng.bytes(64 * n)
+    return [int.from_bytes(raw[64 * i:64 * i + 64], "little") % O.R for i in range(n)]
+
+
+def _bases(eng, ks):
+    """k_i * G computed on the device, returned as host bytes (affine, 64 B each)"""
+    n = len(ks)
+    arr = np.frombuffer(fr_bytes(ks), dtype=np.uint8).reshape(n, 32)
+    d_k = torch.from_numpy(arr.copy()).to(torch.device("cuda", 0))
+    t = eng.bases_generate(d_k.data_ptr(), n)
+    try:
+        return eng.bases_download(t, 0, n)
+    finally:
+        eng.bases_free(t)
+
+
+def _want(ks, ss):
+    return O.aff_to_bytes(O.scalar_mul(sum(k * s for k, s in zip(ks, ss)) % O.R, O.G1))
+
+
+class _Env:
+    def __init__(self, **kv):
+        self.kv = {k: str(v) for k, v in kv.items()}
+
+    def __enter__(self):
+        self.old = {k: os.environ.get(k) for k in self.kv}
+        os.environ.update(self.kv)
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _scalars(kind, n, seed):
+    ss = _vals(n, seed)
+    q = n // 4
+    if kind == "equal":
+        ss = [ss[0]] * n                         # one bucket per window, over-long in every slice
+    elif kind == "first_quarter_equal":
+        ss[:q] = [ss[0]] * q                     # over-long in slice 0 only: later slices resume it as an ordinary bucket
+    elif kind == "last_quarter_equal":
+        ss[n - q:] = [ss[-1]] * q                # ordinary partial sums first, the chunked path on top in the last slice
+    elif kind == "small":
+        ss = [s % 1000 for s in ss]              # upper windows stay empty in every slice
+    elif kind == "sparse":
+        ss = [s if i % 7 == 0 else 0 for i, s in enumerate(ss)]   # most keys dropped; some slices leave most buckets untouched
+    return ss
+
+
+@pytest.mark.parametrize("glv", [1, -1])
+@pytest.mark.parametrize("kind", ["random", "equal", "first_quarter_equal", "last_quarter_equal", "small", "sparse"])
+def test_chained_slices_resume_bucket_sums(eng, kind, glv):
+    n = (1 << 14) + 37                           # ragged last slice
+    ks = _vals(n, 7001)
+    ss = _scalars(kind, n, 7002)
+    if kind == "random":
+        ks[5] = ks[5000]                     # the same base with the same scalar in two different slices: P + P on resume
+        ss[5] = ss[5000]
+        ks[9] = (-ks[8200]) % O.R                # a base in one slice, its negation in another, same scalar: the bucket returns to the identity
+        ss[9] = ss[8200]
+    bases, sb, want = _bases(eng, ks), fr_bytes(ss), _want(ks, ss)
+    with _Env(H2AGG_PCIE_SLICES=4, H2AGG_PCIE_GLV=glv):
+        got = eng.g1_batch_to_affine(eng.g1_msm(bases, sb))
+        assert got == want
+        with _Env(H2AGG_PCIE_CHAIN=0):
+            assert eng.g1_batch_to_affine(eng.g1_msm(bases, sb)) == want
+
+
+@pytest.mark.parametrize("glv", [1, -1])
+@pytest.mark.parametrize("c,big", [(8, 64), (5, 0), (13, 0)])
+def test_chained_slices_small_plans_with_slice_slots(eng, c, big, glv):
+    """narrow windows: few buckets, several lanes per bucket (slice slots resumed one by one, folded once at the end),
+    and a low over-long threshold so that the chunked path and the slots meet"""
+    n = 6000
+    ks = _vals(n, 7101 + c)
+    ss = _scalars("first_quarter_equal", n, 7102 + c)
+    bases, sb, want = _bases(eng, ks), fr_bytes(ss), _want(ks, ss)
+    eng.msm_configure(window_bits=c, big_bucket_threshold=big)
+    eng.msm_configure_glv(glv)
+    try:
+        for slices in (2, 3, 5):
+            with _Env(H2AGG_PCIE_SLICES=slices):
+                assert eng.g1_batch_to_affine(eng.g1_msm(bases, sb)) == want, slices
+    finally:
+        eng.msm_configure()
+        eng.msm_configure_glv(0)
+
+
+@pytest.mark.parametrize("slices,glv", [(2, 1), (4, -1), (8, 1), (16, -1)])
+def test_chained_slices_digit_major_sizes(eng, slices, glv):
+    """2^20 + 5 points: 16-bit windows, digit-major sort and two-dimensional reduction in every slice"""
+    n = (1 << 20) + 5
+    ks = _vals(n, 7201)
+    ss = _vals(n, 7202)
+    bases, sb, want = _bases(eng, ks), fr_bytes(ss), _want(ks, ss)
+    with _Env(H2AGG_PCIE_SLICES=slices, H2AGG_PCIE_GLV=glv):
+        assert eng.g1_batch_to_affine(eng.g1_msm(bases, sb)) == want
+    # the default cut (no knobs) as well
+    assert eng.g1_batch_to_affine(eng.g1_msm(bases, sb)) == want
+
+
+def test_chain_leaves_the_context_clean(eng):
+    """an ordinary MSM right after a chained one (the slot rotation and the slice slots must not leak)"""
+    n = 1 << 13
+    ks, ss = _vals(n, 7301), _vals(n, 7302)
+    bases, sb, want = _bases(eng, ks), fr_bytes(ss), _want(ks, ss)
+    with _Env(H2AGG_PCIE_SLICES=4):
+        assert eng.g1_batch_to_affine(eng.g1_msm(bases, sb)) == want
+    m = 3000
+    assert eng.g1_batch_to_affine(eng.g1_msm(bases[:64 * m], sb[:32 * m])) == _want(ks[:m], ss[:m])
