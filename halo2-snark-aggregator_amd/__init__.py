@@ -124,6 +124,7 @@ def load_library():
         "h2agg_vk_destroy": (None, [C.c_void_p]),
         "h2agg_verify_aggregation": (i32, [ctxp, vp, sz, u8p, u8p, vp, vp, vp, C.POINTER(i32)]),   # see verifier.py
         "h2agg_verify_aggregation_ex": (i32, [ctxp, vp, sz, u8p, u8p, vp, vp, vp, C.POINTER(i32), vp, sz]),
+        "h2agg_verify_plan_stats": (i32, [ctxp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "h2agg_transcript_configure": (i32, [ctxp, i32]),
         "h2agg_poseidon_squeeze_batch_host": (i32, [u8p, sz, sz, C.POINTER(C.c_uint32), sz, vp, i32]),
         "h2agg_host_threads": (i32, []),
@@ -415,6 +416,12 @@ class H2Agg:
         out = C.create_string_buffer(max(32 * nproofs * nsq, 1))
         self._check(self._lib.h2agg_poseidon_squeeze_batch(self._ctx, elems, nproofs, nelem, arr, nsq, out))
         return out.raw[:32 * nproofs * nsq]
+
+    def verify_plan_stats(self):
+        """(hits, misses, plans kept) of the context's recorded-aggregation cache (h2agg_verify_plan_stats)"""
+        h, m, k = C.c_uint64(), C.c_uint64(), C.c_uint64()
+        self._check(self._lib.h2agg_verify_plan_stats(self._ctx, C.byref(h), C.byref(m), C.byref(k)))
+        return h.value, m.value, k.value
 
     def transcript_configure(self, backend: str = "auto"):
         """which backend runs the Poseidon sponges of this context: "auto" (by batch size), "device", "host" (worker threads)"""

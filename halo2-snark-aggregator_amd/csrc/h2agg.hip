@@ -107,6 +107,7 @@ struct h2agg_ctx {
     uint8_t* h_stage = nullptr;
     size_t h_stage_cap = 0;
     const void* sch_owner = nullptr;  // the schema whose tape sch_regs reflects
+    struct AggPlanCache* agg_plans = nullptr;   // recorded aggregations kept for the next call of the same shape (csrc/verifier.inc)
 
     // host-buffer MSM: slices are copied on this stream while the previous slice is computed
     hipStream_t copy_stream = nullptr;
@@ -951,12 +952,14 @@ int h2agg_create(int device_ordinal, h2agg_ctx** out) try {
 }  // extern "C"
 namespace {
 void comm_release(h2agg_ctx* c);   // csrc/comm.inc
+void agg_plans_release(h2agg_ctx* c);   // csrc/verifier.inc
 }
 extern "C" {
 void h2agg_destroy(h2agg_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
     comm_release(c);
+    agg_plans_release(c);
     flush_deferred_tail(c, false);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->acc_stream) hipStreamSynchronize(c->acc_stream);

@@ -367,6 +367,10 @@ struct Prepared {
 struct Schema {
     std::vector<SchemaNode> nodes;
     std::vector<uint8_t> points;  // 64 B canonical affine each
+    // where every point was copied from (verifier pipeline, while it records an aggregation it will want to run again with
+    // other proofs of the same shape: csrc/verifier.inc `AggPlan`)
+    bool track_src = false;
+    std::vector<const uint8_t*> point_src;
     Tape tape;
     uint32_t one_reg = 0;
     bool has_one = false;
@@ -405,6 +409,7 @@ struct Schema {
         n.key = key;
         n.point = (int32_t)(points.size() / 64);
         points.insert(points.end(), p, p + 64);
+        if (track_src) point_src.push_back(p);
         nodes.push_back(n);
         return (uint32_t)nodes.size() - 1;
     }

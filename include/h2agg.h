@@ -332,6 +332,13 @@ int h2agg_verify_aggregation(h2agg_ctx* ctx, const h2agg_circuit_proofs* circuit
 int h2agg_verify_aggregation_ex(h2agg_ctx* ctx, const h2agg_circuit_proofs* circuits, size_t ncircuits, const uint8_t* s_g2,
                                 const uint8_t* g2, uint8_t left_aff[64], uint8_t right_aff[64], uint8_t lambda_out[32],
                                 int* pairing_ok, uint8_t* advice_out, size_t advice_cap);
+/* The host-side recording of an aggregation (every proof's queries of params.rs:74-224, the multiopen fold, both eval_prepare
+ * walks of evaluation.rs:205-293) depends on the SHAPE of the call only — which keys, how many proofs of each, their length —
+ * so a context keeps the last few recordings and a later call of the same shape only refills the proof scalars, challenges and
+ * commitments before running the same tape and multi_exps on them (every value is still computed from that call's inputs).
+ * This reports how often that happened; any pointer may be NULL.  H2AGG_PLAN_CACHE=0 in the environment records every call
+ * afresh. */
+int h2agg_verify_plan_stats(h2agg_ctx* ctx, uint64_t* hits, uint64_t* misses, uint64_t* plans_kept);
 
 /* ---- multi-GPU exchange -----------------------------------------------------------
  * The one collective of a sharded aggregation: every rank holds partial accumulators (the sharded form of the fold

@@ -193,3 +193,88 @@ def test_verify_run_from_the_reference_files(eng, pkg, tmp_path):
                                                                   for i in range(nproofs)])]
     wl, wr, plain, _c, _lam = V.verify_aggregation_proofs_in_chip(S.OracleEccChip(), circuits)
     assert (tmp_path / "verify_circuit_final_pair.data").read_bytes() == S.final_pair_bytes(wl, wr, plain)
+
+
+def test_recorded_aggregation_is_reused_for_new_proofs_of_the_same_shape(eng, pkg, backend):
+    """h2agg_verify_aggregation keeps the host-side recording of a call (csrc/verifier.inc `AggPlan`); a later call with the same
+    keys, proof counts and proof length only refills the proof scalars, challenges and commitments.  Same keys, different
+    proofs every time: every result must still be the oracle's, bit for bit, and accepted by the pairing; a tampered proof on
+    a reused recording must give the reference's (rejected) pair; a refused call must not poison the recording."""
+    import copy
+    import os
+    setup, circuits = make_batch(0x91, [SHAPES[0], SHAPES[2]], 4)
+    ver = importlib.import_module(entry.PKG_NAME + ".verifier")
+    table = eng.bases_upload(b"".join(O.aff_to_bytes(p) for p in setup.g_lagrange))
+    vks = [ver.VerifyingKey(eng, ver.encode_vk(c.cs, O.aff_to_bytes)) for c in circuits]
+
+    def subset(sel, patch=None):
+        out = []
+        for c in circuits:
+            c2 = copy.copy(c)
+            c2.proofs = [c.proofs[j] for j in sel]
+            out.append(c2)
+        if patch:
+            patch(out)
+        return out
+
+    def product(cs):
+        arg = []
+        for vk, c in zip(vks, cs):
+            proofs = [([b"".join(O.fe_to_bytes(v) for v in col) for col in inst[0]], data) for inst, data in c.proofs]
+            arg.append((vk, c.name, table, proofs))
+        return ver.verify_aggregation(eng, arg, g2b(setup.s_g2), g2b(setup.g2), with_commits=True)
+
+    def check(cs, accept=True):
+        want_l, want_r, _plain, want_commits, want_lam = V.verify_aggregation_proofs_in_chip(S.OracleEccChip(), cs)
+        left, right, lam, ok, commits = product(cs)
+        assert lam == O.fe_to_bytes(want_lam)
+        assert left + right == S.final_pair_bytes(want_l, want_r)
+        assert ok is accept
+        assert commits == [[O.aff_to_bytes(p) for p in per_proof] for per_proof in want_commits]
+        return left, right, lam
+
+    try:
+        h0, m0, _ = eng.verify_plan_stats()
+        check(subset([0, 1]))                        # recorded
+        check(subset([2, 3]))                        # reused with two other proofs per circuit
+        check(subset([1, 2]))
+        h1, m1, _ = eng.verify_plan_stats()
+        assert (h1 - h0, m1 - m0) == (2, 1)
+        check(subset([0, 1, 2]))                     # another shape: its own recording
+        r_a = check(subset([3, 0]))                  # the first shape again
+        h2, m2, kept = eng.verify_plan_stats()
+        assert (h2 - h0, m2 - m0) == (3, 2) and kept >= 2
+        os.environ["H2AGG_PLAN_CACHE"] = "0"
+        try:
+            assert check(subset([3, 0])) == r_a      # recorded afresh: the same bytes
+            assert eng.verify_plan_stats()[:2] == (h2, m2)
+        finally:
+            del os.environ["H2AGG_PLAN_CACHE"]
+
+        def flip_eval(cs):
+            inst, data = cs[0].proofs[1]
+            bad = bytearray(data)
+            bad[len(bad) - 32 * 6 + 3] ^= 0x10
+            cs[0].proofs[1] = (inst, bytes(bad))
+        check(subset([0, 1], flip_eval), accept=False)   # on the reused recording: the reference's rejected pair
+
+        def big_scalar(cs):
+            inst, data = cs[0].proofs[0]
+            bad = bytearray(data)
+            off = len(bad) - 32 * 6
+            bad[off:off + 32] = O.R.to_bytes(32, "little")
+            cs[0].proofs[0] = (inst, bytes(bad))
+        with pytest.raises(pkg.H2AggError) as ei:
+            product(subset([2, 3], big_scalar))
+        assert ei.value.code == pkg.ERR_NONCANONICAL
+        check(subset([2, 3]))                        # and the recording still serves good proofs
+        # a key made again from the same description is a different key: no reuse across keys
+        vks[0].close()
+        vks[0] = ver.VerifyingKey(eng, ver.encode_vk(circuits[0].cs, O.aff_to_bytes))
+        h3, m3, _ = eng.verify_plan_stats()
+        check(subset([0, 1]))
+        assert eng.verify_plan_stats()[1] == m3 + 1
+    finally:
+        for vk in vks:
+            vk.close()
+        eng.bases_free(table)
