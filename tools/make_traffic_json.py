@@ -20,6 +20,8 @@ def counters(path, kernel):
     with open(path) as f:
         for line in f:
             p = line.split()
+            if p and p[0] == "void":        # (template instantiations are printed with their return type)
+                p = p[1:]
             if len(p) == 5 and p[0] == kernel:
                 out[p[1]] = (float(p[3]), float(p[4]))
     return out
@@ -27,7 +29,7 @@ def counters(path, kernel):
 
 def main(prefix):
     import bench
-    k = "h2agg::k_msm_accumulate"
+    k = "h2agg::k_msm_accumulate<0>"   # (the whole-MSM instantiation; <1> / <2> are the chained slices of the host-buffer path)
     fetch = counters(prefix + "_pmc_fetch.txt", k)["FETCH_SIZE"]
     write = counters(prefix + "_pmc_write.txt", k)["WRITE_SIZE"]
     sq = counters(prefix + "_pmc_sq.txt", k)
