@@ -278,7 +278,10 @@ int choose_window(size_t n, bool glv) {
     // (GLV 8/13/16, plain 8/15/16: top window as sparse as the others) avoid a dense top window that costs as much as all the
     // other windows together.
     if (glv) return n <= ((size_t)1 << 10) ? 8 : n <= ((size_t)1 << 14) ? 13 : 16;
-    return n <= ((size_t)1 << 12) ? 8 : n < ((size_t)1 << 19) ? 15 : 16;
+    // 17 bits from 1.5 * 2^20 points on: a bucket costs 2 general additions (~2.8 insertions) whatever the point count, a
+    // window's insertions grow with it — 15 windows of 2^16 buckets overtake 16 of 2^15 between 2^20 points (+0.7 %) and
+    // 2^21 (+5.7 %; 2^22: +8.8 %, profiles/r03_sweeps.txt section 11)
+    return n <= ((size_t)1 << 12) ? 8 : n < ((size_t)1 << 19) ? 15 : n < ((size_t)3 << 19) ? 16 : 17;
 }
 
 MsmPlan make_plan(const h2agg_ctx* c, size_t n, uint32_t batch = 1) {

@@ -132,3 +132,31 @@ def test_chain_leaves_the_context_clean(eng):
         assert eng.g1_batch_to_affine(eng.g1_msm(bases, sb)) == want
     m = 3000
     assert eng.g1_batch_to_affine(eng.g1_msm(bases[:64 * m], sb[:32 * m])) == _want(ks[:m], ss[:m])
+
+
+def test_chained_slices_random_shapes_agree_with_the_resident_msm(eng):
+    """random sizes / slice counts / plans / scalar patterns: the chained host-buffer MSM against the resident one over the same
+    table (whose own parity with the oracle is tests/test_gpu_parity.py's and tests/test_gpu_scale.py's business)"""
+    rng = np.random.Generator(np.random.PCG64(7401))
+    n_max = 300_000
+    ks = _vals(n_max, 7402)
+    arr = np.frombuffer(fr_bytes(ks), dtype=np.uint8).reshape(n_max, 32)
+    dev = torch.device("cuda", 0)
+    d_k = torch.from_numpy(arr.copy()).to(dev)
+    table = eng.bases_generate(d_k.data_ptr(), n_max)
+    bases = eng.bases_download(table, 0, n_max)
+    try:
+        for case in range(10):
+            n = int(rng.integers(3000, n_max))
+            slices = int(rng.integers(2, 10))
+            glv = int(rng.choice([1, -1]))
+            kind = str(rng.choice(["random", "first_quarter_equal", "last_quarter_equal", "sparse", "small"]))
+            ss = _scalars(kind, n, 7500 + case)
+            sb = fr_bytes(ss)
+            d_s = torch.from_numpy(np.frombuffer(sb, dtype=np.uint8).copy()).to(dev)
+            want = eng.g1_batch_to_affine(eng.g1_msm_device(table, d_s.data_ptr(), n))
+            with _Env(H2AGG_PCIE_SLICES=slices, H2AGG_PCIE_GLV=glv):
+                got = eng.g1_batch_to_affine(eng.g1_msm(bases[:64 * n], sb))
+            assert got == want, (case, n, slices, glv, kind)
+    finally:
+        eng.bases_free(table)

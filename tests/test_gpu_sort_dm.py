@@ -178,3 +178,32 @@ def test_c17_structured_scalars(eng):
     _run17(eng, ks, [R - 1] * n)
     _run17(eng, ks, [0] * n)
     _run17(eng, ks, [0x1234_5678_9abc_def0_1111_2222_3333_4444_5555_6666_7777_8888_9999_aaaa_bbbb % R] * n)
+
+
+def test_large_plain_msms_take_17_bit_windows_by_themselves(eng):
+    """choose_window: from 1.5 * 2^20 points on a plain (non-GLV) MSM runs on 15 windows of 17 bits without being told to — the
+    plan of back-to-back MSMs in overlap mode; the explicit 16-bit plan must give the same point"""
+    n = (3 << 19) + 11
+    ks, ss = _rand(n, 9101), _rand(n, 9102)
+    dev = torch.device("cuda", 0)
+    d_k = torch.from_numpy(_bytes(ks).copy()).to(dev)
+    d_s = torch.from_numpy(_bytes(ss).copy()).to(dev)
+    table = eng.bases_generate(d_k.data_ptr(), n)
+    want = O.aff_to_bytes(O.scalar_mul(sum(k * s for k, s in zip(ks, ss)) % R, O.G1))
+    out = torch.zeros(96 * 3, dtype=torch.uint8, device=dev)
+    try:
+        eng.msm_set_tail_overlap(2)
+        for i in range(3):
+            eng.g1_msm_device_async(table, d_s.data_ptr(), n, out.data_ptr() + 96 * i)
+        eng.synchronize()
+        res = bytes(out.cpu().numpy().tobytes())
+        for i in range(3):
+            assert eng.g1_batch_to_affine(res[96 * i:96 * i + 96]) == want
+        eng.msm_configure(16, 0, 0)
+        eng.g1_msm_device_async(table, d_s.data_ptr(), n, out.data_ptr())
+        eng.synchronize()
+        assert eng.g1_batch_to_affine(bytes(out[:96].cpu().numpy().tobytes())) == want
+    finally:
+        eng.msm_configure(0, 0, 0)
+        eng.msm_set_tail_overlap(0)
+        eng.bases_free(table)
