@@ -23,8 +23,25 @@ backend = agg.GpuBackend(pkg, eng)
 pool = syn.point_pool(eng, 0xA66)
 specs, lam = syn.make_proofs(pool, 4, 300)
 
+# the from-bytes pipeline over SIX call shapes (the context keeps four recordings: least-recently-used ones are evicted and
+# recorded again) and the chained host-buffer MSM
+ver = importlib.import_module(entry.PKG_NAME + ".verifier")
+comp = eng.g1_batch_compress(b"".join(pool))
+pool_c = [comp[32 * i:32 * i + 32] for i in range(len(pool))]
+_, gk = gen_scalars(7, 1 << 12)
+g_table = eng.bases_generate(torch.from_numpy(gk.copy()).to(dev).data_ptr(), 1 << 12)
+shape = syn.CircuitShape(12, 60, pool)
+vk = ver.VerifyingKey(eng, ver.encode_vk(shape, lambda p: p))
+fr = syn.fr_stream(0xF00D)
+vproofs = [([b"".join(fr() for _ in range(16))], shape.random_transcript(pool_c, 500 + i)) for i in range(6)]
+h_bases = eng.bases_download(table, 0, 1 << 18)
+h_scal = bytes(s[:1 << 18].tobytes())
+
 def one_round():
     res = []
+    for k in range(1, 7):
+        res.append(ver.verify_aggregation(eng, [(vk, "soak", g_table, vproofs[:k])])[:3])
+    res.append(eng.g1_batch_to_affine(eng.g1_msm(h_bases, h_scal)))
     for i in range(8):
         eng.g1_msm_device_async(table, ds.data_ptr(), n, out.data_ptr() + 96 * i)
     eng.synchronize()
@@ -51,5 +68,6 @@ while time.time() < t_end:
     rounds += 1
 torch.cuda.synchronize()
 free1 = torch.cuda.mem_get_info(dev)[0]; rss1 = rss_mb()
-print("soak ok: %d rounds (8 async 2^20-point MSMs + 4 MSMs of other sizes + one 4-proof aggregation each); device memory %+.1f MiB, "
-      "host max RSS %+.1f MiB" % (rounds, (free0 - free1) / 2**20, rss1 - rss0))
+print("soak ok: %d rounds (8 async 2^20-point MSMs + 4 MSMs of other sizes + one 4-proof aggregation + six from-bytes aggregations of "
+      "different shapes + one chained host-buffer MSM each); device memory %+.1f MiB, host max RSS %+.1f MiB; recorded aggregations "
+      "(hits, misses, kept) %s" % (rounds, (free0 - free1) / 2**20, rss1 - rss0, eng.verify_plan_stats()))
