@@ -59,6 +59,10 @@ struct Table {
     // fixed-base levels (h2agg_bases_precompute): pre[(w * n + i) * 64] = 2^(pre_c * w) * P_i, w < pre_W
     uint8_t* pre = nullptr;
     int pre_c = 0, pre_W = 0;
+    // comb of the first comb_n bases (k_comb_table_build with bases; made on the first small MSM over a table that has
+    // fixed-base levels, i.e. one its owner declared constant): comb[((b * 32 + w) * 255 + d - 1) * 64] = d * 2^(8w) * P_b
+    uint8_t* comb = nullptr;
+    size_t comb_n = 0;
 };
 struct PreTable {   // what msm_run needs of it
     const uint8_t* d;
@@ -979,6 +983,7 @@ void h2agg_destroy(h2agg_ctx* c) {
     for (auto& kv : c->tables) {
         if (kv.second.d) hipFree(kv.second.d);
         if (kv.second.endo_x) hipFree(kv.second.endo_x);
+        if (kv.second.comb) hipFree(kv.second.comb);
         if (kv.second.pre) hipFree(kv.second.pre);
     }
     if (c->h_pinned) hipHostFree(c->h_pinned);
@@ -1374,6 +1379,7 @@ int h2agg_bases_free(h2agg_ctx* c, uint64_t handle) try {
     hipFree(it->second.d);
     if (it->second.endo_x) hipFree(it->second.endo_x);
     if (it->second.pre) hipFree(it->second.pre);
+    if (it->second.comb) hipFree(it->second.comb);
     c->tables.erase(it);
     return H2AGG_OK;
 } catch (const std::bad_alloc&) {
@@ -1431,6 +1437,11 @@ int h2agg_bases_precompute(h2agg_ctx* c, uint64_t handle, int window_bits) try {
         hipFree(t.pre);
         t.pre = nullptr;
     }
+    if (t.comb) {
+        hipFree(t.comb);
+        t.comb = nullptr;
+        t.comb_n = 0;
+    }
     if (hipMalloc((void**)&t.pre, (size_t)W * t.n * 64) != hipSuccess)
         return fail(c, H2AGG_ERR_NOMEM, "hipMalloc(fixed-base levels)");
     HIP_TRY(c, hipMemcpyAsync(t.pre, t.d, t.n * 64, hipMemcpyDeviceToDevice, c->stream));
@@ -1447,6 +1458,38 @@ int h2agg_bases_precompute(h2agg_ctx* c, uint64_t handle, int window_bits) try {
     return H2AGG_ERR_INVALID;
 }
 
+}   // extern "C"
+namespace {
+// `batch` MSMs of n <= COMB_MSM_MAX scalars each over the leading bases of a table with fixed-base levels: through the table's
+// comb (made here on first use).  Returns false when the comb route does not apply.
+bool comb_msm_applies(const h2agg_ctx* c, const Table& t, size_t n) {
+    const bool off = getenv("H2AGG_COMB_MSM") && !strcmp(getenv("H2AGG_COMB_MSM"), "0");
+    return !off && t.pre && !c->cfg_c && n >= 1 && n <= (size_t)COMB_MSM_MAX;
+}
+int comb_msm_run(h2agg_ctx* c, Table& t, const uint8_t* d_scalars, size_t n, size_t batch, uint8_t* d_out_jac) {
+    if (!t.comb || t.comb_n < n) {
+        const size_t nb = t.n < (size_t)COMB_MSM_MAX ? t.n : (size_t)COMB_MSM_MAX;
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (t.comb) hipFree(t.comb);
+        t.comb = nullptr;
+        t.comb_n = 0;
+        const size_t entries = nb * (size_t)COMB_WINDOWS * COMB_ROW;
+        if (hipMalloc((void**)&t.comb, entries * 64) != hipSuccess) return fail(c, H2AGG_ERR_NOMEM, "hipMalloc(table comb)");
+        size_t grid = (entries + SM_GROUPS - 1) / SM_GROUPS;
+        const size_t cap = (size_t)c->cu_count * 16;
+        if (grid > cap) grid = cap;
+        hipLaunchKernelGGL(k_comb_table_build, dim3((unsigned)grid), dim3(SM_THREADS), 0, c->stream, t.comb, c->d_flags,
+                           (const uint8_t*)t.d, (uint32_t)nb);
+        t.comb_n = nb;
+    }
+    hipLaunchKernelGGL(k_comb_msm, dim3((unsigned)batch), dim3(BLOCK), 0, c->stream, (const uint8_t*)t.comb, d_scalars, (uint32_t)n,
+                       d_out_jac, c->d_flags);
+    HIP_TRY(c, hipGetLastError());
+    return H2AGG_OK;
+}
+}   // namespace
+extern "C" {
+
 int h2agg_g1_msm_device_async(h2agg_ctx* c, uint64_t handle, const void* d_scalars, size_t n, void* d_out_jac) try {
     TRY(bind(c));
     auto it = c->tables.find(handle);
@@ -1454,6 +1497,7 @@ int h2agg_g1_msm_device_async(h2agg_ctx* c, uint64_t handle, const void* d_scala
     if (!d_scalars || !d_out_jac) return fail(c, H2AGG_ERR_INVALID, "null buffer");
     if (n == 0) return fail(c, H2AGG_ERR_EMPTY, "multi_exp of zero pairs (reference panics: mock/arith/ecc.rs:128)");
     if (n > it->second.n) return fail(c, H2AGG_ERR_INVALID, "more scalars than bases in the table");
+    if (comb_msm_applies(c, it->second, n)) return comb_msm_run(c, it->second, (const uint8_t*)d_scalars, n, 1, (uint8_t*)d_out_jac);
     const uint8_t* endo = nullptr;
     TRY(table_endo(c, it->second, &endo));
     // Beyond 2^22 points the packed (index | sub-bucket) sort item no longer fits 32 bits and the sort would fall back to
@@ -1502,6 +1546,8 @@ int h2agg_g1_msm_device_batch_async(h2agg_ctx* c, uint64_t handle, const void* d
     if (n == 0 || batch == 0)
         return fail(c, H2AGG_ERR_EMPTY, "multi_exp of zero pairs (reference panics: mock/arith/ecc.rs:128)");
     if (n > it->second.n) return fail(c, H2AGG_ERR_INVALID, "more scalars than bases in the table");
+    if (comb_msm_applies(c, it->second, n))
+        return comb_msm_run(c, it->second, (const uint8_t*)d_scalars, n, batch, (uint8_t*)d_out_jac);
     // MSMs per set of launches: the level-1 sort partitions (batch * W * NB >> sub_bits, sub_bits <= 11) must fit its
     // LDS counters, and the entry count its 32-bit offsets
     const bool use_pre = it->second.pre && !c->cfg_c;   // fixed-base levels (h2agg_bases_precompute)

@@ -153,16 +153,21 @@ __global__ void __launch_bounds__(SM_THREADS) k_g1_batch_scalar_mul_w4(const uin
 // ---- fixed-base comb for the generator ----------------------------------------------------------------------------
 constexpr int COMB_BITS = 8, COMB_WINDOWS = 32, COMB_ROW = (1 << COMB_BITS) - 1;   // 32 x 255 affine points
 
-// table[w * 255 + (d - 1)] = d * 2^(8w) * G (Montgomery affine, 64 B); one group of four lanes per entry
-__global__ void __launch_bounds__(SM_THREADS) k_comb_table_build(uint8_t* __restrict__ table, uint32_t* flags) {
+// table[w * 255 + (d - 1)] = d * 2^(8w) * G (Montgomery affine, 64 B); one group of four lanes per entry.
+// bases != nullptr: the same rows for each of nb resident bases instead of the generator, table[(b * 32 + w) * 255 + (d - 1)] =
+// d * 2^(8w) * B_b — the comb of a FIXED table's leading bases (k_comb_msm below).
+__global__ void __launch_bounds__(SM_THREADS) k_comb_table_build(uint8_t* __restrict__ table, uint32_t* flags,
+                                                                 const uint8_t* __restrict__ bases = nullptr, uint32_t nb = 1) {
     __shared__ uint32_t tab[SM_TABLE * XYZZ_WORDS * SM_GROUPS];
-    const size_t total = (size_t)COMB_WINDOWS * COMB_ROW;
+    const size_t per_base = (size_t)COMB_WINDOWS * COMB_ROW;
+    const size_t total = per_base * nb;
     const size_t ngroups_total = (size_t)gridDim.x * SM_GROUPS;
     for (size_t e0 = (size_t)blockIdx.x * SM_GROUPS; e0 < total; e0 += ngroups_total) {
         const size_t e = e0 + (threadIdx.x >> 2);
         const bool live = e < total;
         const size_t ee = live ? e : total - 1;
-        const uint32_t w = (uint32_t)(ee / COMB_ROW), dgt = (uint32_t)(ee % COMB_ROW) + 1u;
+        const size_t bi = ee / per_base, er = ee - bi * per_base;
+        const uint32_t w = (uint32_t)(er / COMB_ROW), dgt = (uint32_t)(er % COMB_ROW) + 1u;
         U256 s;
 #pragma unroll
         for (int k = 0; k < 8; ++k) s.w[k] = 0;
@@ -181,9 +186,14 @@ __global__ void __launch_bounds__(SM_THREADS) k_comb_table_build(uint8_t* __rest
             }
         }
         G1Affine gen;
-        gen.x = Fq::one();
-        gen.y = FQ_DBL(Fq::one());
-        const G1XYZZ r = g1_scalar_mul_w4_par4(gen, s, tab, flags);
+        if (bases) {
+            gen = affine_load(bases + 64 * bi);
+        } else {
+            gen.x = Fq::one();
+            gen.y = FQ_DBL(Fq::one());
+        }
+        G1XYZZ r = G1XYZZ::identity();
+        if (!gen.is_identity()) r = g1_scalar_mul_w4_par4(gen, s, tab, flags);
         if (live && (threadIdx.x & 3) == 0) affine_store(table + 64 * e, affine_from_xyzz(r));
         __syncthreads();
     }
@@ -204,6 +214,29 @@ __global__ void __launch_bounds__(BLOCK) k_bases_generate_comb(const uint8_t* __
         }
         affine_store(out + 64 * i, affine_from_xyzz(acc));
     }
+}
+
+// Small multi_exps over the LEADING bases of a fixed table (an instance column of a few dozen public inputs against
+// params.g_lagrange: assign_instance_commitment, verify.rs:574-649): sum_i v_i B_i = sum over (i, byte position w) of
+// table[i][w][byte_w(v_i)] — no doublings, no buckets, no serial tail: every thread adds its share of the n x 32 table entries
+// with mixed additions, one tree per workgroup.  One workgroup per MSM of the batch (scalars [batch][n]); canonical Jacobian out.
+constexpr int COMB_MSM_MAX = 256;   // bases per table that get a comb (133 MB); longer MSMs take the bucket path
+__global__ void __launch_bounds__(BLOCK) k_comb_msm(const uint8_t* __restrict__ table, const uint8_t* __restrict__ scalars,
+                                                    uint32_t n, uint8_t* __restrict__ out_jac, uint32_t* flags) {
+    __shared__ uint32_t lds[XYZZ_WORDS * BLOCK];
+    const uint8_t* sc = scalars + 32 * (size_t)n * blockIdx.x;
+    G1XYZZ acc = G1XYZZ::identity();
+    bool bad = false;
+#pragma unroll 1
+    for (uint32_t e = threadIdx.x; e < n * (uint32_t)COMB_WINDOWS; e += BLOCK) {
+        const uint32_t i = e / COMB_WINDOWS, w = e % COMB_WINDOWS;
+        if (w == 0) bad |= !u256_is_canonical_fr(u256_load(sc + 32 * (size_t)i));
+        const uint32_t d = sc[32 * (size_t)i + w];
+        if (d) xyzz_add_affine(acc, affine_load(table + 64 * (((size_t)i * COMB_WINDOWS + w) * COMB_ROW + d - 1)));
+    }
+    if (bad) atomicOr(flags, FLAG_NONCANONICAL);
+    const G1XYZZ tot = block_sum_xyzz(acc, lds);
+    if (threadIdx.x == 0) jac_store_canonical(out_jac + 96 * (size_t)blockIdx.x, jac_from_xyzz(tot));
 }
 
 }  // namespace h2agg

@@ -160,3 +160,52 @@ def test_chained_slices_random_shapes_agree_with_the_resident_msm(eng):
             assert got == want, (case, n, slices, glv, kind)
     finally:
         eng.bases_free(table)
+
+
+# ---- small multi_exps over the leading bases of a fixed table: the table's comb (csrc/scalar_mul_kernels.hpp k_comb_msm) -----
+def test_small_msms_over_a_fixed_table_take_its_comb(eng, pkg):
+    """assign_instance_commitment with a handful of public inputs (verify.rs:574-649): sum_i v_i * g_lagrange[i].  A table with
+    fixed-base levels (h2agg_bases_precompute) answers MSMs of <= 256 scalars from a comb of its leading bases — no buckets, no
+    doubling chain.  Against the reference loop (scalar multiplication + addition per term), for every length class, with
+    zero / all-ones / maximal scalars and identity bases; the bucket path (H2AGG_COMB_MSM=0, and n = 257) must agree."""
+    n_table = 300
+    ks = _vals(n_table, 7601)
+    ks[3] = 0                                    # an identity base inside the comb's range
+    ks[255] = ks[254]                            # equal bases
+    bases = _bases(eng, ks)
+    h = eng.bases_upload(bases)
+    dev = torch.device("cuda", 0)
+    try:
+        eng.bases_precompute(h)
+        pats = [0, 1, O.R - 1, (1 << 248) - 1, 0xff, 0x0100, int.from_bytes(b"\x01" * 31 + b"\x00", "little"), 1 << 253]
+        for n in (1, 2, 7, 64, 255, 256, 257):
+            batch = 5
+            cols = []
+            for q in range(batch):
+                ss = _vals(n, 7700 + 10 * n + q)
+                for j, p in enumerate(pats):
+                    if q == 0 and j < n:
+                        ss[j] = p
+                if q == 1:
+                    ss = [0] * n                 # an all-zero column: the identity
+                cols.append(ss)
+            flat = b"".join(fr_bytes(ss) for ss in cols)
+            d_s = torch.from_numpy(np.frombuffer(flat, dtype=np.uint8).copy()).to(dev)
+            out = torch.zeros(96 * batch, dtype=torch.uint8, device=dev)
+            want = [O.aff_to_bytes(O.scalar_mul(sum(k * s for k, s in zip(ks, ss)) % O.R, O.G1)) for ss in cols]
+            for env in ({}, {"H2AGG_COMB_MSM": "0"}):
+                with _Env(**env):
+                    eng.g1_msm_device_batch_async(h, d_s.data_ptr(), n, batch, out.data_ptr())
+                    eng.synchronize()
+                    got = bytes(out.cpu().numpy().tobytes())
+                    for q in range(batch):
+                        assert eng.g1_batch_to_affine(got[96 * q:96 * q + 96]) == want[q], (n, q, env)
+                    assert eng.g1_batch_to_affine(eng.g1_msm_device(h, d_s.data_ptr(), n)) == want[0], (n, env)
+        # a scalar >= r is refused on the comb route as on the bucket route
+        bad = (O.R + 3).to_bytes(32, "little") + bytes(32)
+        d_bad = torch.from_numpy(np.frombuffer(bad, dtype=np.uint8).copy()).to(dev)
+        with pytest.raises(pkg.H2AggError) as ei:
+            eng.g1_msm_device(h, d_bad.data_ptr(), 2)
+        assert ei.value.code == pkg.ERR_NONCANONICAL
+    finally:
+        eng.bases_free(h)
