@@ -72,6 +72,17 @@ struct PreTable {   // what msm_run needs of it
 
 }  // namespace
 
+// HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A context owns seven streams (bulk, three
+// tail streams, accumulation, auxiliary, copy), and two streams on one queue run one after the other: a copy stream that lands
+// on the bulk stream's queue sends the slices of the host-buffer MSM across PCIe BEHIND the kernels they were meant to run
+// beside (3.8 instead of 2.9 ms per 2^20 points, seen in the bench process; profiles/r03_sweeps.txt section 12).  Ask for eight
+// before the runtime reads its settings (first HIP call of the process), unless the user has said otherwise.
+namespace {
+struct HwQueues {
+    HwQueues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+} g_hw_queues;
+}   // namespace
+
 constexpr int MSM_MAX_SLICES = 16;
 enum { CHAIN_OFF = 0, CHAIN_FIRST = 1, CHAIN_MID = 2, CHAIN_LAST = 3 };
 

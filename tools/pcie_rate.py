@@ -13,6 +13,11 @@ import __graft_entry__ as entry
 from bench import gen_scalars
 
 pkg = entry.load_package()
+extra = [a for a in sys.argv if a.startswith('--extra-streams=')]
+_keep = [torch.cuda.Stream() for _ in range(int(extra[0].split('=')[1]) if extra else 0)]   # (HIP maps streams onto few hardware queues)
+for st in _keep:
+    with torch.cuda.stream(st):
+        torch.zeros(8, device='cuda').add_(1)
 eng = pkg.H2Agg(0)
 log2n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 20
 if '--torch-stream' in sys.argv:   # what bench.py does: the library works on torch's current stream
