@@ -79,3 +79,30 @@ def test_rejects_non_canonical_and_bad_positions(pkg):
         pkg.poseidon_squeeze_batch_host(bytes(64), 1, [2, 1])       # decreasing
     with pytest.raises(pkg.H2AggError):
         pkg.poseidon_squeeze_batch_host(bytes(64), 1, [3])          # beyond the stream
+
+
+def test_worker_pool_serves_concurrent_callers(pkg):
+    """several caller threads at once (contexts on different threads share the pool: one call's sponges run while another call
+    is on the device): every caller gets its own batch's challenges, whatever the interleaving of the runs"""
+    import threading
+    rng = O.SplitMix64(0xA09)
+    ncallers, nproofs = 6, 7
+    batches = []
+    for c in range(ncallers):
+        rows = [[rng.fr() for _ in range(30 + c)] for _ in range(nproofs)]
+        batches.append((b"".join(fe(r) for r in rows), [5, 30 + c]))
+    want = [pkg.poseidon_squeeze_batch_host(blob, nproofs, upto, max_threads=1) for blob, upto in batches]
+    got = [[None] * 8 for _ in range(ncallers)]
+
+    def run(c):
+        blob, upto = batches[c]
+        for rep in range(8):
+            got[c][rep] = pkg.poseidon_squeeze_batch_host(blob, nproofs, upto)
+
+    ts = [threading.Thread(target=run, args=(c,)) for c in range(ncallers)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    for c in range(ncallers):
+        assert all(g == want[c] for g in got[c]), c
