@@ -209,3 +209,19 @@ def test_small_msms_over_a_fixed_table_take_its_comb(eng, pkg):
         assert ei.value.code == pkg.ERR_NONCANONICAL
     finally:
         eng.bases_free(h)
+
+
+def test_chained_slices_over_projective_points(eng):
+    """h2agg_g1_msm_jac (the trait hands over Vec<C::CurveExt>: x || y || z, normalised on the device slice by slice)"""
+    from tests.util import to_jac_bytes
+    n = 5000
+    ks, ss = _vals(n, 7801), _vals(n, 7802)
+    ks[17] = 0                                   # the identity among the points (z = 0)
+    aff = _bases(eng, ks)
+    zs = [(z % O.P) or 1 for z in _vals(n, 7803)]
+    jac = bytearray(to_jac_bytes(aff, zs))
+    jac[96 * 17:96 * 18] = bytes(32) + (1).to_bytes(32, "little") + bytes(32)
+    want = _want(ks, ss)
+    for slices in (1, 3, 4):
+        with _Env(H2AGG_PCIE_SLICES=slices):
+            assert eng.g1_batch_to_affine(eng.g1_msm_jac(bytes(jac), fr_bytes(ss))) == want, slices
