@@ -739,7 +739,8 @@ __global__ void __launch_bounds__(BLOCK) k_eval_tail_affine2(const uint8_t* __re
                                                              const uint8_t* __restrict__ xyzz1,
                                                              const uint8_t* __restrict__ pts0,
                                                              const uint8_t* __restrict__ pts1, size_t n0, size_t n1,
-                                                             uint8_t* __restrict__ out_aff, uint32_t* flags) {
+                                                             uint8_t* __restrict__ out_aff, uint32_t* flags,
+                                                             uint8_t* __restrict__ out_xyzz = nullptr) {
     __shared__ uint32_t lds[XYZZ_WORDS * BLOCK];
     const bool side = blockIdx.x != 0;
     const uint8_t* msm_xyzz = side ? xyzz1 : xyzz0;
@@ -748,13 +749,33 @@ __global__ void __launch_bounds__(BLOCK) k_eval_tail_affine2(const uint8_t* __re
     G1XYZZ acc = G1XYZZ::identity();
     if (threadIdx.x == 0 && msm_xyzz) acc = xyzz_load(msm_xyzz);
     uint32_t bad = 0;
-    for (size_t i = threadIdx.x; i < n; i += BLOCK) xyzz_add_affine(acc, affine_load_canonical(pts_aff + 64 * i, bad));
-    if (bad) atomicOr(flags, FLAG_NONCANONICAL);
-    G1XYZZ tot = block_sum_xyzz(acc, lds);
+    G1XYZZ tot;
+    if (n <= 8) {
+        // the usual case (a handful of scalar-less points, often none): one lane adds them in a row — the workgroup tree
+        // below is eight levels of general additions (~50 us at a lone wave's latency) whatever the count
+        if (threadIdx.x == 0)
+            for (size_t i = 0; i < n; ++i) xyzz_add_affine(acc, affine_load_canonical(pts_aff + 64 * i, bad));
+        if (bad) atomicOr(flags, FLAG_NONCANONICAL);
+        tot = acc;
+    } else {
+        for (size_t i = threadIdx.x; i < n; i += BLOCK) xyzz_add_affine(acc, affine_load_canonical(pts_aff + 64 * i, bad));
+        if (bad) atomicOr(flags, FLAG_NONCANONICAL);
+        tot = block_sum_xyzz(acc, lds);
+    }
     if (threadIdx.x == 0) {
-        const G1Affine a = affine_from_xyzz(tot);
-        fp_store<FqParams>(out_aff + 64 * blockIdx.x, fp_from_mont<FqParams>(a.x));
-        fp_store<FqParams>(out_aff + 64 * blockIdx.x + 32, fp_from_mont<FqParams>(a.y));
+        if (out_xyzz) {
+            // the coordinates as they are (X, Y, ZZ, ZZZ; canonical integers): the caller divides on the host, where one field
+            // inversion is ~10 us — here it is ~55 us of a lone wave's latency at the very end of the evaluation's chain
+            uint8_t* o = out_xyzz + 128 * blockIdx.x;
+            fp_store<FqParams>(o, fp_from_mont<FqParams>(tot.x));
+            fp_store<FqParams>(o + 32, fp_from_mont<FqParams>(tot.y));
+            fp_store<FqParams>(o + 64, fp_from_mont<FqParams>(tot.zz));
+            fp_store<FqParams>(o + 96, fp_from_mont<FqParams>(tot.zzz));
+        } else {
+            const G1Affine a = affine_from_xyzz(tot);
+            fp_store<FqParams>(out_aff + 64 * blockIdx.x, fp_from_mont<FqParams>(a.x));
+            fp_store<FqParams>(out_aff + 64 * blockIdx.x + 32, fp_from_mont<FqParams>(a.y));
+        }
     }
 }
 
