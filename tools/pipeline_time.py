@@ -26,6 +26,8 @@ proofs_all = [([b"".join(fr() for _ in range(64))], shape.random_transcript(pool
 g2 = bytes.fromhex(
     "edf692d95cbdde46ddda5ef7d422436779445c5e66006a42761e1f12efde0018c212f3aeb785e49712e7a9353349aaf1255dfb31b7bf60723a480d9293938e19"
     "aa7dfa6601cce64c7bd3430c69e7d1e38f40cb8d8071ab4aeb6d8cdba55ec8125b9722d1dcdaac55f38eb37033314bbc95330c69ad999eec75f05f58d0890609")
+import gc
+gc.disable()   # (the 35-45 ms calls this tool used to report as `max` were CPython's full collections — tools/stall_hunt.py — not the library)
 print("host worker threads:", pkg.host_threads())
 for n in sizes:
     arg = [(vk, "syn", g_table, proofs_all[:n])]
