@@ -216,6 +216,7 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
             d_inst[j] = torch.randint(0, 256, (n_inst, 32), dtype=torch.uint8, device=dev, generator=gen)
         d_inst[:, :, 31] &= 0x1F                               # < 2^253 < r: canonical
         d_inst_out = torch.zeros((len(my_idx), 96), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize(dev)   # (the inputs are complete before anything reads them, whatever stream it runs on)
     last_commits = {}
 
     def build(b, idx):
@@ -419,7 +420,9 @@ def full_pipeline_leg(pkg, eng, args, g_table):
             def __init__(self, idx):
                 self.eng = pkg.H2Agg(0)
                 _, gk = gen_scalars(7, 1 << 17)
-                self.g = self.eng.bases_generate(torch.from_numpy(gk.copy()).cuda().data_ptr(), 1 << 17)
+                d_gk = torch.from_numpy(gk.copy()).cuda()
+                torch.cuda.synchronize()
+                self.g = self.eng.bases_generate(d_gk.data_ptr(), 1 << 17)
                 self.eng.bases_precompute(self.g)
                 self.vk = ver.VerifyingKey(self.eng, ver.encode_vk(shape, lambda p: p))
                 frw = syn.fr_stream(0xBEEF + idx)
@@ -550,8 +553,13 @@ def main():
 
     pkg = entry.load_package()
     eng = pkg.H2Agg(dev_index)
-    stream = torch.cuda.current_stream(dev)
-    eng.set_stream(stream.cuda_stream)
+    # The library runs on its context's OWN (non-blocking) stream; torch only prepares inputs here.  torch's default stream has
+    # the handle 0, which h2agg_set_stream reads as "the context's own stream", so earlier revisions' `set_stream(current_stream)`
+    # never put the two on one stream — and torch kernels that fill an input (torch.randint, torch.zeros) were not ordered before
+    # the library's kernels that read it: a sort whose scalars change under it faulted in ~20 % of the two-rank runs once the
+    # streams really ran side by side (profiles/r03_sweeps.txt section 18).  Every torch-side fill below is therefore followed by
+    # torch.cuda.synchronize() before the library sees the buffer.  (A torch-made stream for both was tried: 1.66 instead of
+    # 1.27 ms per step — it shares a hardware queue with the tail streams.)
     if args.window or args.seg:
         eng.msm_configure(window_bits=args.window, reduce_segment=args.seg)
     if args.glv:
@@ -574,6 +582,7 @@ def main():
     table = eng.bases_generate(d_k.data_ptr(), n)       # P_i = k_i*G, stays in HBM (64 MiB at 2^20)
     t_gen = time.perf_counter() - t0
     d_out = torch.zeros((max(args.steps, args.warmup, 1), 96), dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize(dev)
 
     def step(i):
         eng.g1_msm_device_async(table, d_s.data_ptr(), n, d_out[i].data_ptr())
@@ -735,6 +744,7 @@ def main():
                 gk = torch.randint(0, 256, (1 << args.agg_instance_log2, 32), dtype=torch.uint8, generator=gen)
                 gk[:, 31] &= 0x1F
                 gk = gk.to(dev)
+                torch.cuda.synchronize(dev)
                 g_table = eng.bases_generate(gk.data_ptr(), 1 << args.agg_instance_log2)
                 if args.agg_instance_log2 <= 18 and not args.no_fixed_base:
                     eng.bases_precompute(g_table)          # g_lagrange is fixed per circuit size: one-off SRS-style setup

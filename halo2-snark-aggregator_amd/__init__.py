@@ -223,6 +223,10 @@ class H2Agg:
         return self._lib.h2agg_describe(self._ctx).decode()
 
     def set_stream(self, stream_ptr: Optional[int]):
+        """a hipStream_t handle for every launch of this context; None or 0 = the context's OWN non-blocking stream.  torch's
+        default stream has the handle 0: `set_stream(torch.cuda.current_stream().cuda_stream)` therefore does NOT put the
+        library on torch's stream — make a real one (`torch.cuda.Stream()`, `torch.cuda.set_stream`) or synchronise before
+        handing device buffers over (include/h2agg.h)."""
         self._check(self._lib.h2agg_set_stream(self._ctx, stream_ptr))
 
     def synchronize(self):

@@ -10,6 +10,9 @@
 #include <cstdio>
 #include <cstring>
 #include <algorithm>
+#include <csignal>
+#include <dlfcn.h>
+#include <unistd.h>
 #include <atomic>
 #include <condition_variable>
 #include <functional>
@@ -342,6 +345,65 @@ struct StageTimer {
     }
 };
 
+// Debugging aid (H2AGG_BREADCRUMBS=1): the return addresses of the last C-ABI entries (every entry point binds its context
+// first) and the sizes of the last MSMs, dumped when the process aborts — the HSA runtime abort()s on a GPU memory fault, long
+// after the host call that queued the faulting kernel has returned.  Resolve the addresses against libh2agg.so (they are
+// printed relative to its load address).
+struct Crumbs {
+    static constexpr int N = 48;
+    std::atomic<uint32_t> at{0};
+    uintptr_t addr[N] = {};
+    uint64_t note[N] = {};
+    bool on = false;
+};
+Crumbs g_crumbs;
+void crumbs_dump(int) {
+    Dl_info info;
+    uintptr_t base = 0;
+    if (dladdr((void*)&crumbs_dump, &info)) base = (uintptr_t)info.dli_fbase;
+    const uint32_t end = g_crumbs.at.load();
+    fprintf(stderr, "[h2agg breadcrumbs pid %d] last entries, oldest first (addresses relative to libh2agg.so):\n", (int)getpid());
+    for (uint32_t k = end > Crumbs::N ? end - Crumbs::N : 0; k < end; ++k)
+        fprintf(stderr, "  #%u  +0x%zx  note %llu\n", k, (size_t)(g_crumbs.addr[k % Crumbs::N] - base), (unsigned long long)g_crumbs.note[k % Crumbs::N]);
+    fflush(stderr);
+    signal(SIGABRT, SIG_DFL);
+    abort();
+}
+inline void crumb(uintptr_t a, uint64_t note) {
+    if (!g_crumbs.on) return;
+    const uint32_t k = g_crumbs.at.fetch_add(1) % Crumbs::N;
+    g_crumbs.addr[k] = a;
+    g_crumbs.note[k] = note;
+}
+struct CrumbsInit {
+    CrumbsInit() {
+        if (getenv("H2AGG_BREADCRUMBS")) {
+            g_crumbs.on = true;
+            signal(SIGABRT, crumbs_dump);
+        }
+    }
+} g_crumbs_init;
+
+// Debugging aid (H2AGG_CHAOS=<bits>, off by default): a one-lane kernel that just waits, put in front of work on a stream to
+// shift the streams against one another — a missing event dependency then shows as a wrong result in the test suites instead of
+// as a once-in-twenty-runs memory fault.  bit 0: in front of every tail; bit 1: in front of every accumulation; bit 2: in
+// front of every sort.
+__global__ void k_chaos_wait(uint32_t us) {
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < (uint64_t)us * 100u) __builtin_amdgcn_s_sleep(32);   // wall_clock64 ticks at 100 MHz
+}
+inline int chaos_bits() {
+    static const int bits = getenv("H2AGG_CHAOS") ? atoi(getenv("H2AGG_CHAOS")) : 0;
+    return bits;
+}
+inline void debug_sync(int bit) {   // H2AGG_SYNC_AT=<bits>: a device-wide wait at that point of msm_run (bisecting a race)
+    static const int bits = getenv("H2AGG_SYNC_AT") ? atoi(getenv("H2AGG_SYNC_AT")) : 0;
+    if (bits & bit) hipDeviceSynchronize();
+}
+inline void chaos_wait(int bit, hipStream_t s, uint32_t us = 300) {
+    if (chaos_bits() & bit) hipLaunchKernelGGL(k_chaos_wait, dim3(1), dim3(1), 0, s, us);
+}
+
 // harvest one ring slot (blocks until that call's events have completed)
 void profile_harvest(h2agg_ctx* c, int slot) {
     h2agg_ctx::ProfSlot& ps = c->prof[slot];
@@ -407,6 +469,7 @@ int join_tails(h2agg_ctx* c) {
 int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size_t n_base, uint8_t* d_out_jac,
             uint32_t batch = 1, const uint8_t* d_endo_x = nullptr, const PreTable* pre = nullptr) {
     const size_t n = n_base * batch;   // scalars
+    crumb((uintptr_t)__builtin_return_address(0), ((uint64_t)batch << 40) | n_base);
     if (n >= ((size_t)1 << 30)) return fail(c, H2AGG_ERR_INVALID, "n must be < 2^30");
     const int chain = (pre || batch != 1) ? CHAIN_OFF : c->chain;
     MsmPlan p = make_plan(c, chain ? c->chain_n : n_base, batch);
@@ -586,6 +649,8 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
                                (uint8_t*)c->endo_buf.p);
         d_endo_x = (const uint8_t*)c->endo_buf.p;
     }
+    debug_sync(1);
+    chaos_wait(4, st);
     if (p.glv) {  // k = k1 + lambda*k2: the sort below reads the decomposed words instead of the scalars
         TRY(ensure(c, c->glv_buf, n * 32));
         StageTimer t(c, ST_PART_COUNT);
@@ -720,6 +785,8 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     // (experiment knob: 256-thread workgroups + H2AGG_ACC_LDS pin the accumulation at exactly N waves per SIMD and leave the rest
     // of the CU — registers and LDS — to whatever else is in flight; see profiles/r03_sweeps.txt section 10)
     static const int acc_block = getenv("H2AGG_ACC_BLOCK") ? atoi(getenv("H2AGG_ACC_BLOCK")) : 64;
+    debug_sync(2);
+    chaos_wait(2, st);
     {
         StageTimer t(c, ST_ACCUM, st);
         // one-wave workgroups: a 4-wave workgroup needs a free slot on all four SIMDs of a CU at once and its waves retire
@@ -791,6 +858,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         }
         ticket = (uint32_t*)tk.p;
     }
+    debug_sync(4);
     const bool tails_off_stream = c->tail_overlap && c->overlap_level >= 2;
     const bool final_off_stream = c->tail_overlap;
     uint8_t* const res_xyzz = c->d_res_xyzz;
@@ -803,6 +871,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
             HIP_TRY(c, hipStreamWaitEvent(ts, c->ev_bulk[par], 0));
             if (behind_sort) HIP_TRY(c, hipStreamWaitEvent(ts, c->ev_sortdone, 0));
         }
+        chaos_wait(1, ts);
         if (tail_big) {
             big_kernels(ts);
             HIP_TRY(c, hipMemsetAsync(meta, 0, M_WORDS * 4, ts));
@@ -875,6 +944,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     // the slot (buckets / segsum / wsum / XYZZ result) rotates on every MSM, overlap or not: a caller may queue
     // two MSMs and read both results afterwards (evaluate_multiopen_proof does)
     c->parity = (c->parity + 1) % h2agg_ctx::TAIL_SLOTS;
+    debug_sync(8);
     HIP_TRY(c, hipGetLastError());
     profile_end_call(c);
     return H2AGG_OK;
@@ -895,6 +965,7 @@ int fetch_result_jac(h2agg_ctx* c, uint8_t out[96]) {
 }
 
 int bind(h2agg_ctx* c) {
+    crumb((uintptr_t)__builtin_return_address(0), 0);
     if (!c) return H2AGG_ERR_INVALID;
     hipError_t e = hipSetDevice(c->device);
     if (e != hipSuccess) return fail(c, H2AGG_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));

@@ -56,7 +56,10 @@ enum { H2AGG_OP_ADD = 0, H2AGG_OP_SUB = 1, H2AGG_OP_MUL = 2, H2AGG_OP_SQR = 3, H
 int h2agg_create(int device_ordinal, h2agg_ctx** out);
 void h2agg_destroy(h2agg_ctx* ctx);
 const char* h2agg_last_error(const h2agg_ctx* ctx);
-/* Use an existing HIP stream (hipStream_t) for every launch of this context; NULL = the context's own. */
+/* Use an existing HIP stream (hipStream_t) for every launch of this context; NULL = the context's own (a non-blocking stream:
+ * it does NOT synchronise with the legacy default stream).  Device buffers handed to the asynchronous entry points must be
+ * complete on THAT stream (or the device synchronised) before the call and must not change until the result has been joined:
+ * the sort reads the scalars more than once.  Note that a framework's "default stream" usually has the handle 0 (= NULL here). */
 int h2agg_set_stream(h2agg_ctx* ctx, void* hip_stream);
 /* Block until everything queued on the context's stream (and its tail streams) has finished.  Also where device-side
  * status raised by ASYNCHRONOUS calls surfaces: a non-canonical scalar handed to h2agg_g1_msm_device_async / _batch_async is

@@ -201,6 +201,7 @@ def test_config5_sixteen_instance_msms_of_2pow22(eng):
             prod = eng.fr_batch_op(2, s_bytes, O.fe_to_bytes(cj) * n)                  # c_j * s_i, all i
             d_inst[j] = torch.frombuffer(bytearray(prod), dtype=torch.uint8).to(dev).view(n, 32)
         d_out = torch.zeros((batch, 96), dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()   # torch filled d_inst on ITS stream; the library reads it on the context's own
         eng.g1_msm_device_batch_async(table, d_inst.data_ptr(), n, batch, d_out.data_ptr())
         aff = eng.g1_batch_to_affine_device(d_out.data_ptr(), batch)
         for j, cj in enumerate(cs):

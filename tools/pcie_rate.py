@@ -21,7 +21,8 @@ for st in _keep:
 eng = pkg.H2Agg(0)
 log2n = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 20
 if '--torch-stream' in sys.argv:   # what bench.py does: the library works on torch's current stream
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    _st = torch.cuda.Stream(); torch.cuda.set_stream(_st)   # (the default stream's handle is 0 = "the context's own stream")
+    eng.set_stream(_st.cuda_stream)
 n = 1 << log2n
 _, k_np = gen_scalars(1, n)
 _, s_np = gen_scalars(2, n)

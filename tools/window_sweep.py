@@ -21,7 +21,8 @@ def main():
     pkg = entry.load_package()
     eng = pkg.H2Agg(0)
     dev = torch.device("cuda:0")
-    eng.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+    _st = torch.cuda.Stream(dev); torch.cuda.set_stream(_st)   # (the default stream's handle is 0 = "the context's own stream")
+    eng.set_stream(_st.cuda_stream)
     eng.msm_set_tail_overlap(args.overlap)
     rng = np.random.Generator(np.random.PCG64(7))
     nmax = 1 << args.hi
