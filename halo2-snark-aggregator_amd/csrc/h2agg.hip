@@ -387,7 +387,8 @@ struct CrumbsInit {
 // Debugging aid (H2AGG_CHAOS=<bits>, off by default): a one-lane kernel that just waits, put in front of work on a stream to
 // shift the streams against one another — a missing event dependency then shows as a wrong result in the test suites instead of
 // as a once-in-twenty-runs memory fault.  bit 0: in front of every tail; bit 1: in front of every accumulation; bit 2: in
-// front of every sort.
+// front of every sort; bit 3: in front of the auxiliary stream's transcript work (verifier.inc); bit 4: in front of every
+// slice's copies of the host-buffer MSM.
 __global__ void k_chaos_wait(uint32_t us) {
     const uint64_t t0 = wall_clock64();
     while (wall_clock64() - t0 < (uint64_t)us * 100u) __builtin_amdgcn_s_sleep(32);   // wall_clock64 ticks at 100 MHz
@@ -1826,6 +1827,7 @@ int msm_host(h2agg_ctx* c, const uint8_t* bases, size_t stride, const uint8_t* s
     size_t done = 0, k = 0;
     for (; done < n && rc == H2AGG_OK; done += per, ++k) {
         const size_t m = n - done < per ? n - done : per;
+        chaos_wait(16, c->copy_stream);
         hipError_t e = hipMemcpyAsync((uint8_t*)c->in_b.p + 32 * done, scalars + 32 * done, 32 * m, hipMemcpyHostToDevice,
                                       c->copy_stream);
         if (e == hipSuccess) e = hipEventRecord(c->ev_copy_s[k], c->copy_stream);
