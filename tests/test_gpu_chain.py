@@ -225,3 +225,58 @@ def test_chained_slices_over_projective_points(eng):
     for slices in (1, 3, 4):
         with _Env(H2AGG_PCIE_SLICES=slices):
             assert eng.g1_batch_to_affine(eng.g1_msm_jac(bytes(jac), fr_bytes(ss))) == want, slices
+
+
+@pytest.mark.parametrize("fill", ["random", "ones"])
+def test_non_canonical_scalars_are_refused_on_every_device_route(eng, pkg, fill):
+    """random 256-bit values / all ones as scalars (what a buffer that was never filled looks like): every resident-table route
+    — fixed-base batches, the packed and the digit-major sort, GLV or not, overlap on or off — must end in ERR_NONCANONICAL,
+    never in a fault (an input that CHANGES during the call is another matter: include/h2agg.h)"""
+    dev = torch.device("cuda", 0)
+    rng = np.random.Generator(np.random.PCG64(7901))
+    k = rng.integers(0, 256, size=(1 << 17, 32), dtype=np.uint8)
+    k[:, 31] &= 0x1F
+    d_k = torch.from_numpy(k.copy()).to(dev)
+    torch.cuda.synchronize()
+    t_small = eng.bases_generate(d_k.data_ptr(), 4096)
+    t_big = eng.bases_generate(d_k.data_ptr(), 1 << 17)
+    eng.bases_precompute(t_small)
+
+    def garbage(shape):
+        if fill == "ones":
+            g = torch.full(shape, 255, dtype=torch.uint8, device=dev)
+        else:
+            g = torch.from_numpy(rng.integers(0, 256, size=shape, dtype=np.uint8)).to(dev)
+            g[..., 31] |= 0x80                     # (every value >= 2^255 > r)
+        torch.cuda.synchronize()
+        return g
+
+    def refused(fn):
+        with pytest.raises(pkg.H2AggError) as ei:
+            fn()
+            eng.synchronize()
+        assert ei.value.code == pkg.ERR_NONCANONICAL
+
+    try:
+        for ovl in (0, 2):
+            eng.msm_set_tail_overlap(ovl)
+            for batch in (2, 8):
+                g, o = garbage((batch, 4090, 32)), torch.zeros((batch, 96), dtype=torch.uint8, device=dev)
+                torch.cuda.synchronize()
+                refused(lambda: eng.g1_msm_device_batch_async(t_small, g.data_ptr(), 4090, batch, o.data_ptr()))
+            for n in (5, 200, 4090, 1 << 16, 1 << 17):
+                g, o = garbage((n, 32)), torch.zeros(96, dtype=torch.uint8, device=dev)
+                torch.cuda.synchronize()
+                for glv in (1, -1):
+                    eng.msm_configure_glv(glv)
+                    refused(lambda: eng.g1_msm_device_async(t_big, g.data_ptr(), n, o.data_ptr()))
+                eng.msm_configure_glv(0)
+        # the context still works
+        good = torch.from_numpy(k[:1000].copy()).to(dev)
+        torch.cuda.synchronize()
+        eng.g1_msm_device(t_big, good.data_ptr(), 1000)
+    finally:
+        eng.msm_configure_glv(0)
+        eng.msm_set_tail_overlap(0)
+        eng.bases_free(t_small)
+        eng.bases_free(t_big)
