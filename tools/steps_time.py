@@ -19,6 +19,8 @@ dk = torch.from_numpy(k).to(dev); ds = torch.from_numpy(s).to(dev)
 out = torch.zeros(96 * K, dtype=torch.uint8, device=dev)
 t = eng.bases_generate(dk.data_ptr(), n)
 import os
+if os.environ.get('TORCH_STREAM'):   # the caller's own stream as the context's main stream (a torch-made one: torch keeps a pool of them)
+    _st = torch.cuda.Stream(dev); torch.cuda.set_stream(_st); eng.set_stream(_st.cuda_stream)
 eng.msm_set_tail_overlap(int(os.environ.get('LEVEL', '2')))
 if os.environ.get('WINDOW'):
     eng.msm_configure(int(os.environ['WINDOW']), 0, 0)
