@@ -6,7 +6,16 @@ import sys, time, numpy as np, torch
 import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as e
 pkg = e.load_package()
+_early = None
+if os.environ.get('HIP_STREAM_EARLY'):   # the caller's stream made BEFORE the context (and its tail streams) exists
+    import ctypes
+    torch.zeros(1, device='cuda')
+    _hip0 = ctypes.CDLL("libamdhip64.so")
+    _early = ctypes.c_void_p()
+    assert _hip0.hipStreamCreateWithFlags(ctypes.byref(_early), 1) == 0
 eng = pkg.H2Agg(0)
+if _early is not None:
+    eng.set_stream(_early.value)
 n = 1 << int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 PROF = int(sys.argv[3]) if len(sys.argv) > 3 else 0
@@ -19,6 +28,13 @@ dk = torch.from_numpy(k).to(dev); ds = torch.from_numpy(s).to(dev)
 out = torch.zeros(96 * K, dtype=torch.uint8, device=dev)
 t = eng.bases_generate(dk.data_ptr(), n)
 import os
+if os.environ.get('HIP_STREAM'):     # a stream made with the HIP API directly: "blocking" (hipStreamCreate) or "nonblocking"
+    import ctypes
+    _hip = ctypes.CDLL("libamdhip64.so")
+    _h = ctypes.c_void_p()
+    rc = _hip.hipStreamCreateWithFlags(ctypes.byref(_h), 1 if os.environ['HIP_STREAM'] == 'nonblocking' else 0)
+    assert rc == 0 and _h.value
+    eng.set_stream(_h.value)
 if os.environ.get('TORCH_STREAM'):   # the caller's own stream as the context's main stream (a torch-made one: torch keeps a pool of them)
     _st = torch.cuda.Stream(dev); torch.cuda.set_stream(_st); eng.set_stream(_st.cuda_stream)
 eng.msm_set_tail_overlap(int(os.environ.get('LEVEL', '2')))
