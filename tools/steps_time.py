@@ -7,6 +7,9 @@ import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__
 import __graft_entry__ as e
 pkg = e.load_package()
 _early = None
+_tearly = None
+if os.environ.get('TORCH_STREAM_EARLY'):   # a torch-made stream that exists before the context's own streams do
+    _tearly = torch.cuda.Stream(torch.device('cuda', 0))
 if os.environ.get('HIP_STREAM_EARLY'):   # the caller's stream made BEFORE the context (and its tail streams) exists
     import ctypes
     torch.zeros(1, device='cuda')
@@ -16,6 +19,8 @@ if os.environ.get('HIP_STREAM_EARLY'):   # the caller's stream made BEFORE the c
 eng = pkg.H2Agg(0)
 if _early is not None:
     eng.set_stream(_early.value)
+if _tearly is not None:
+    torch.cuda.set_stream(_tearly); eng.set_stream(_tearly.cuda_stream)
 n = 1 << int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 PROF = int(sys.argv[3]) if len(sys.argv) > 3 else 0
