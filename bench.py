@@ -20,9 +20,6 @@ from __future__ import annotations
 import argparse
 import json
 import os
-# (before the HIP runtime reads its settings — first HIP call of the process: a context's seven streams want their own hardware
-# queues; libh2agg.so asks for the same when it is loaded, csrc/h2agg.hip `HwQueues`)
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 import sys
 import time
 
@@ -557,7 +554,7 @@ def main():
     # the handle 0, which h2agg_set_stream reads as "the context's own stream", so earlier revisions' `set_stream(current_stream)`
     # never put the two on one stream — and torch kernels that fill an input (torch.randint, torch.zeros) were not ordered before
     # the library's kernels that read it: a sort whose scalars change under it faulted in ~20 % of the two-rank runs once the
-    # streams really ran side by side (profiles/r03_sweeps.txt section 18).  Every torch-side fill below is therefore followed by
+    # streams really ran side by side (GPU_MAX_HW_QUEUES=8; profiles/r03_sweeps.txt section 18).  Every torch-side fill below is therefore followed by
     # torch.cuda.synchronize() before the library sees the buffer.  (A torch-made stream for both was tried: 1.66 instead of
     # 1.27 ms per step — it shares a hardware queue with the tail streams.)
     if args.window or args.seg:

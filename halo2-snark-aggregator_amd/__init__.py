@@ -11,7 +11,6 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")   # see csrc/h2agg.hip `HwQueues` (the HIP runtime reads it at its first call)
 from typing import Optional, Sequence
 
 _HERE = os.path.dirname(os.path.abspath(__file__))

@@ -75,17 +75,6 @@ struct PreTable {   // what msm_run needs of it
 
 }  // namespace
 
-// HIP maps a process's streams onto GPU_MAX_HW_QUEUES hardware queues (default 4).  A context owns seven streams (bulk, three
-// tail streams, accumulation, auxiliary, copy), and two streams on one queue run one after the other: a copy stream that lands
-// on the bulk stream's queue sends the slices of the host-buffer MSM across PCIe BEHIND the kernels they were meant to run
-// beside (3.8 instead of 2.9 ms per 2^20 points, seen in the bench process; profiles/r03_sweeps.txt section 12).  Ask for eight
-// before the runtime reads its settings (first HIP call of the process), unless the user has said otherwise.
-namespace {
-struct HwQueues {
-    HwQueues() { setenv("GPU_MAX_HW_QUEUES", "8", 0); }
-} g_hw_queues;
-}   // namespace
-
 constexpr int MSM_MAX_SLICES = 16;
 enum { CHAIN_OFF = 0, CHAIN_FIRST = 1, CHAIN_MID = 2, CHAIN_LAST = 3 };
 
@@ -1022,6 +1011,22 @@ int h2agg_create(int device_ordinal, h2agg_ctx** out) try {
         h2agg_destroy(c);
         return H2AGG_ERR_HIP;
     }
+    // The auxiliary and the copy stream are made HERE, in a fixed order behind the others, not at their first use: where the
+    // runtime places a stream depends on how many streams the process has made before it (profiles/r03_sweeps.txt section 18:
+    // back-to-back MSMs run at 1.25 or at 1.55 ms per step depending on the number of streams made between the main stream and
+    // the tail streams), and a placement that changes with what else the process did first is not reproducible.
+    if (hipStreamCreateWithFlags(&c->aux_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+        h2agg_destroy(c);
+        return H2AGG_ERR_HIP;
+    }
+    hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming);
+    hipEventCreateWithFlags(&c->ev_aux_go, hipEventDisableTiming);
+    for (int k = 0; k < MSM_MAX_SLICES; ++k) {
+        hipEventCreateWithFlags(&c->ev_copy[k], hipEventDisableTiming);
+        hipEventCreateWithFlags(&c->ev_copy_s[k], hipEventDisableTiming);
+    }
+    hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming);
     hipEventCreateWithFlags(&c->ev_sortdone, EV_SYNC_FLAGS);
     for (int q = 0; q < 2; ++q) {
         hipEventCreateWithFlags(&c->ev_sorted[q], EV_SYNC_FLAGS);
@@ -1796,14 +1801,6 @@ int msm_host(h2agg_ctx* c, const uint8_t* bases, size_t stride, const uint8_t* s
                                (uint8_t*)c->tmp_bases.p, c->d_flags);
         TRY(msm_run(c, (const uint8_t*)c->tmp_bases.p, (const uint8_t*)c->in_b.p, n, c->d_res_jac));
         return fetch_result_jac(c, out);
-    }
-    if (!c->copy_stream) {
-        HIP_TRY(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
-        for (int k = 0; k < MSM_MAX_SLICES; ++k) {
-            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_copy[k], hipEventDisableTiming));
-            HIP_TRY(c, hipEventCreateWithFlags(&c->ev_copy_s[k], hipEventDisableTiming));
-        }
-        HIP_TRY(c, hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
     }
     TRY(ensure(c, c->out, 96 * MSM_MAX_SLICES));
     // the copy stream must not overwrite in_a / in_b while earlier work on the main stream still reads them
