@@ -118,6 +118,7 @@ struct h2agg_ctx {
 
     // host-buffer MSM: slices are copied on this stream while the previous slice is computed
     hipStream_t copy_stream = nullptr;
+    hipStream_t spare_streams[4] = {};   // what place_streams() did not give a role (see there)
     // verifier pipeline: point decompression of a circuit's proofs runs here, beside the instance-column MSMs
     hipStream_t aux_stream = nullptr;
     hipEvent_t ev_aux = nullptr, ev_aux_go = nullptr;
@@ -392,6 +393,63 @@ inline void debug_sync(int bit) {   // H2AGG_SYNC_AT=<bits>: a device-wide wait 
 }
 inline void chaos_wait(int bit, hipStream_t s, uint32_t us = 300) {
     if (chaos_bits() & bit) hipLaunchKernelGGL(k_chaos_wait, dim3(1), dim3(1), 0, s, us);
+}
+
+// Which of the context's streams may run BESIDE the main stream?  HIP gives a stream its hardware queue when it is first used,
+// round robin over GPU_MAX_HW_QUEUES (default 4) queues, so which streams share a queue depends on everything the process used
+// before — and a tail stream on the main stream's queue puts its latency chains (0.5 ms kernels of one wave) IN FRONT of the next
+// MSM's sort and accumulation: back-to-back 2^20-point MSMs then take 1.55-1.65 instead of 1.25 ms (profiles/r03_sweeps.txt
+// section 18; a lazily made copy stream on that queue cost the host-buffer MSM 0.9 ms).  So the roles are handed out by
+// measurement: every candidate is kept busy with a waiting kernel in turn while a tiny kernel goes to the main stream; the
+// candidates that hold it up share its queue and get no role that matters.  ~4 ms per call; h2agg_create and h2agg_set_stream.
+int place_streams(h2agg_ctx* c) {
+    if (getenv("H2AGG_NO_PLACE")) return H2AGG_OK;
+    constexpr int NP = h2agg_ctx::TAIL_SLOTS + 3 + 4;
+    hipStream_t pool[NP];
+    int np = 0;
+    for (int k = 0; k < h2agg_ctx::TAIL_SLOTS; ++k) pool[np++] = c->tail_streams[k];
+    pool[np++] = c->aux_stream;
+    pool[np++] = c->copy_stream;
+    for (int k = 0; k < 4; ++k) pool[np++] = c->spare_streams[k];
+    pool[np++] = c->acc_stream;
+    // first use (= queue assignment) in a fixed order: the main stream, then the candidates
+    hipLaunchKernelGGL(k_chaos_wait, dim3(1), dim3(1), 0, c->stream, 1u);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (int i = 0; i < np; ++i) {
+        hipLaunchKernelGGL(k_chaos_wait, dim3(1), dim3(1), 0, pool[i], 1u);
+        HIP_TRY(c, hipStreamSynchronize(pool[i]));
+    }
+    bool blocks[NP];
+    int nfree = 0;
+    for (int i = 0; i < np; ++i) {
+        hipLaunchKernelGGL(k_chaos_wait, dim3(1), dim3(1), 0, pool[i], 250u);
+        const auto t0 = std::chrono::steady_clock::now();
+        hipLaunchKernelGGL(k_chaos_wait, dim3(1), dim3(1), 0, c->stream, 1u);
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+        HIP_TRY(c, hipStreamSynchronize(pool[i]));
+        blocks[i] = us > 120.0;
+        nfree += !blocks[i];
+    }
+    if (getenv("H2AGG_TRACE_STREAMS")) {
+        fprintf(stderr, "[h2agg] streams that hold the main stream up when busy:");
+        for (int i = 0; i < np; ++i) fprintf(stderr, " %d%s", i, blocks[i] ? "*" : "");
+        fprintf(stderr, "  (* = shares its queue)\n");
+    }
+    if (nfree < h2agg_ctx::TAIL_SLOTS + 2) return H2AGG_OK;   // (not enough to choose from: keep the creation order)
+    hipStream_t ordered[NP];
+    int no = 0;
+    for (int i = 0; i < np; ++i)
+        if (!blocks[i]) ordered[no++] = pool[i];
+    for (int i = 0; i < np; ++i)
+        if (blocks[i]) ordered[no++] = pool[i];
+    int at = 0;
+    for (int k = 0; k < h2agg_ctx::TAIL_SLOTS; ++k) c->tail_streams[k] = ordered[at++];
+    c->aux_stream = ordered[at++];
+    c->copy_stream = ordered[at++];
+    c->acc_stream = ordered[at++];
+    for (int k = 0; k < 4; ++k) c->spare_streams[k] = ordered[at++];
+    return H2AGG_OK;
 }
 
 // harvest one ring slot (blocks until that call's events have completed)
@@ -1020,6 +1078,11 @@ int h2agg_create(int device_ordinal, h2agg_ctx** out) try {
         h2agg_destroy(c);
         return H2AGG_ERR_HIP;
     }
+    for (int k = 0; k < 4; ++k)
+        if (hipStreamCreateWithFlags(&c->spare_streams[k], hipStreamNonBlocking) != hipSuccess) {
+            h2agg_destroy(c);
+            return H2AGG_ERR_HIP;
+        }
     hipEventCreateWithFlags(&c->ev_aux, hipEventDisableTiming);
     hipEventCreateWithFlags(&c->ev_aux_go, hipEventDisableTiming);
     for (int k = 0; k < MSM_MAX_SLICES; ++k) {
@@ -1036,6 +1099,10 @@ int h2agg_create(int device_ordinal, h2agg_ctx** out) try {
     c->d_res_xyzz = (uint8_t*)c->small.p + 1024;   // 144 B
     c->d_res_jac = (uint8_t*)c->small.p + 256;   // 96 B
     hipMemset(c->small.p, 0, 2048);
+    if (place_streams(c) != H2AGG_OK) {
+        h2agg_destroy(c);
+        return H2AGG_ERR_HIP;
+    }
     *out = c;
     return H2AGG_OK;
 } catch (const std::bad_alloc&) {
@@ -1106,6 +1173,8 @@ void h2agg_destroy(h2agg_ctx* c) {
         if (c->ev_accdone[q]) hipEventDestroy(c->ev_accdone[q]);
     }
     if (c->acc_stream) hipStreamDestroy(c->acc_stream);
+    for (int k = 0; k < 4; ++k)
+        if (c->spare_streams[k]) hipStreamDestroy(c->spare_streams[k]);
     if (c->own_stream) hipStreamDestroy(c->own_stream);
     delete c;
 }
@@ -1117,7 +1186,12 @@ int h2agg_set_stream(h2agg_ctx* c, void* hip_stream) try {
     TRY(bind(c));
     TRY(join_tails(c));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    const hipStream_t was = c->stream;
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
+    if (c->stream != was) {   // another main stream, another queue: hand the roles out again
+        HIP_TRY(c, hipDeviceSynchronize());
+        TRY(place_streams(c));
+    }
     return H2AGG_OK;
 } catch (const std::bad_alloc&) {
     return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI

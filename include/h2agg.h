@@ -59,7 +59,9 @@ const char* h2agg_last_error(const h2agg_ctx* ctx);
 /* Use an existing HIP stream (hipStream_t) for every launch of this context; NULL = the context's own (a non-blocking stream:
  * it does NOT synchronise with the legacy default stream).  Device buffers handed to the asynchronous entry points must be
  * complete on THAT stream (or the device synchronised) before the call and must not change until the result has been joined:
- * the sort reads the scalars more than once.  Note that a framework's "default stream" usually has the handle 0 (= NULL here). */
+ * the sort reads the scalars more than once.  Note that a framework's "default stream" usually has the handle 0 (= NULL here).
+ * The call takes a few milliseconds: the context measures which of its other streams share a hardware queue with the new main
+ * stream and hands their roles (tails, copies, ...) out again, so that none of them queues in front of the main stream's work. */
 int h2agg_set_stream(h2agg_ctx* ctx, void* hip_stream);
 /* Block until everything queued on the context's stream (and its tail streams) has finished.  Also where device-side
  * status raised by ASYNCHRONOUS calls surfaces: a non-canonical scalar handed to h2agg_g1_msm_device_async / _batch_async is
