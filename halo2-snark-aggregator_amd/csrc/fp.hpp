@@ -527,6 +527,16 @@ FP_INLINE bool fp_maybe_zero_mod(const Fp<P>& a) {
     const uint32_t k = (a.l[0] * ((1u << 29) - P::NINV)) & M29;
     return k < (uint32_t)K;
 }
+// The same filter on TWO limbs (2^-58 instead of 2^-29 per candidate): for callers whose "maybe" is expensive — the lean
+// accumulation hands every "maybe" to a separate fix-up pass.  Still never misses a multiple.  a: tight limbs.
+template <int K, class P>
+FP_INLINE bool fp_maybe_zero_mod2(const Fp<P>& a) {
+    const uint32_t k = (a.l[0] * ((1u << 29) - P::NINV)) & M29;
+    if (k >= (uint32_t)K) return false;
+    const uint64_t c = (uint64_t)k * P::MOD[0];   // limb 1 of k * m
+    const uint32_t l1 = (uint32_t)((c >> 29) + (uint64_t)k * P::MOD[1]) & M29;
+    return a.l[1] == l1;
+}
 // exact test a == 0 (mod m), value(a) < K*m
 template <int K, class P>
 FP_INLINE bool fp_is_zero_mod(const Fp<P>& a) {
@@ -724,5 +734,8 @@ FP_INLINE bool fp_is_canonical(const Fp<P>& a) {
 
 using Fq = Fp<FqParams>;
 using Fr = Fp<FrParams>;
+
+// Montgomery products as single inline-asm blocks with fixed temporaries (v108..v127): for kernels that must fit 128 VGPRs
+#include "fp_asm.inc"
 
 }  // namespace h2agg

@@ -100,6 +100,7 @@ struct h2agg_ctx {
     DevBuf inst_vals, inst_jac, inst_aff, agg_elems;
     DevBuf hist[2], offs[2], pmeta[2], order[2], entries[2];   // what the accumulation reads: one set per sort slot (overlap level 3)
     DevBuf big_list[2], big_keys[2], big_part[2];              // written by the accumulation, read by the over-long-bucket kernels
+    DevBuf fix_list[2];                                        // buckets the lean accumulation left to the general formulas
     bool meta_clean[2] = {};                                   // pmeta[q] was zeroed behind its last use (tail stream)
     DevBuf item_idx, item_sub,
         glv_buf, parts, small, endo_buf, tile_counts;  // MSM (bulk side: main stream only)
@@ -833,6 +834,13 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     // (experiment knob: 256-thread workgroups + H2AGG_ACC_LDS pin the accumulation at exactly N waves per SIMD and leave the rest
     // of the CU — registers and LDS — to whatever else is in flight; see profiles/r03_sweeps.txt section 10)
     static const int acc_block = getenv("H2AGG_ACC_BLOCK") ? atoi(getenv("H2AGG_ACC_BLOCK")) : 64;
+    static const bool lean = !(getenv("H2AGG_ACC") && !strcmp(getenv("H2AGG_ACC"), "generic"));
+    static const bool lean_dual = !(getenv("H2AGG_ACC") && !strcmp(getenv("H2AGG_ACC"), "lean1"));
+    uint32_t* fix_list = nullptr;
+    if (lean) {
+        TRY(ensure(c, c->fix_list[sq], (size_t)p.NBT * lpb * 8));
+        fix_list = (uint32_t*)c->fix_list[sq].p;
+    }
     debug_sync(2);
     chaos_wait(2, st);
     {
@@ -840,10 +848,18 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         // one-wave workgroups: a 4-wave workgroup needs a free slot on all four SIMDs of a CU at once and its waves retire
         // at different times; single waves fill any slot as it frees up (2^20 points: 1.74 -> 1.67 ms/step)
         static const int acc_lds = getenv("H2AGG_ACC_LDS") ? atoi(getenv("H2AGG_ACC_LDS")) : 0;   // experiment: unused LDS per wave caps the occupancy
+        if (lean) {   // 128 VGPRs, four waves per SIMD; exceptional cases go to fix_list (msm_kernels.hpp)
+            auto kacc = lean_dual ? (chain == CHAIN_FIRST ? k_msm_accumulate_lean<1, true> : (chain == CHAIN_MID || chain == CHAIN_LAST) ? k_msm_accumulate_lean<2, true> : k_msm_accumulate_lean<0, true>)
+                                  : (chain == CHAIN_FIRST ? k_msm_accumulate_lean<1, false> : (chain == CHAIN_MID || chain == CHAIN_LAST) ? k_msm_accumulate_lean<2, false> : k_msm_accumulate_lean<0, false>);
+            hipLaunchKernelGGL(kacc, dim3((unsigned)(((size_t)p.NBT * lpb + 63) / 64)), dim3(64), (size_t)acc_lds,
+                               st, d_bases, d_endo_x, entries, offs, hist, ordered ? order : (uint32_t*)nullptr, p.NBT, p.big, lpb, acc_out,
+                               big_list, big_keys, big_count, fix_list);
+        } else {
         auto kacc = chain == CHAIN_FIRST ? k_msm_accumulate<1> : (chain == CHAIN_MID || chain == CHAIN_LAST) ? k_msm_accumulate<2> : k_msm_accumulate<0>;
         hipLaunchKernelGGL(kacc, dim3((unsigned)(((size_t)p.NBT * lpb + acc_block - 1) / acc_block)), dim3(acc_block), (size_t)acc_lds,
                            st, d_bases, d_endo_x, entries, offs, hist, ordered ? order : (uint32_t*)nullptr, p.NBT, p.big, lpb, acc_out,
                            big_list, big_keys, big_count);
+        }
     }
     // Buckets longer than `big` (skewed scalars; none for uniform ones, where the two launches below only find empty lists):
     // with alternating sort outputs they leave the bulk stream and go in front of the bucket reduction on the tail stream,
@@ -856,6 +872,9 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     const bool big_possible = nent / WT > p.big;
     auto big_kernels = [=](hipStream_t bs) {
         StageTimer t(c, ST_ACCUM_BIG, bs);
+        if (lean)   // (grid-stride over a list that is empty but for the one-limb filter's false positives and adversarial inputs)
+            hipLaunchKernelGGL(k_msm_accumulate_fix, dim3((unsigned)(c->cu_count * 12)), dim3(64), 0, bs, d_bases, d_endo_x, entries, offs,
+                               hist, lpb, acc_out, (const uint32_t*)big_count, (const uint32_t*)fix_list);
         if (!big_possible && lpb == 1) return;
         size_t grid = max_slots;
         const size_t cap = (size_t)c->cu_count * 8;   // one-wave workgroups, grid-stride over the (usually empty) lists
@@ -1131,7 +1150,7 @@ void h2agg_destroy(h2agg_ctx* c) {
     DevBuf* bufs[] = {&c->in_a,  &c->in_b,     &c->in_c,     &c->out,   &c->tmp_bases, &c->comb, &c->psd_spec, &c->tr_in, &c->tr_points, &c->tr_elems, &c->tr_chal, &c->inst_vals, &c->inst_jac, &c->inst_aff, &c->agg_elems, &c->hist[0], &c->hist[1],
                       &c->offs[0], &c->offs[1], &c->pmeta[0], &c->pmeta[1], &c->item_idx, &c->item_sub, &c->order[0], &c->order[1], &c->entries[0], &c->entries[1],
                       &c->r2d_ticket[0], &c->r2d_ticket[1], &c->r2d_ticket[2], &c->buckets[0], &c->buckets[1], &c->buckets[2], &c->segsum[0], &c->segsum[1], &c->segsum[2],
-                      &c->wsum[0], &c->wsum[1], &c->wsum[2], &c->big_list[0], &c->big_list[1], &c->big_keys[0], &c->big_keys[1], &c->big_part[0], &c->big_part[1], &c->glv_buf, &c->parts, &c->small, &c->endo_buf, &c->tile_counts,
+                      &c->wsum[0], &c->wsum[1], &c->wsum[2], &c->big_list[0], &c->big_list[1], &c->big_keys[0], &c->big_keys[1], &c->big_part[0], &c->big_part[1], &c->fix_list[0], &c->fix_list[1], &c->glv_buf, &c->parts, &c->small, &c->endo_buf, &c->tile_counts,
                       &c->sch_regs, &c->sch_in, &c->sch_scalars[0], &c->sch_scalars[1], &c->sch_bases[0], &c->sch_bases[1]};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);

@@ -172,6 +172,212 @@ __global__ void __launch_bounds__(BLOCK) k_msm_accumulate(const uint8_t* __restr
     xyzz_store(buckets + XYZZ_BYTES * ((size_t)key * lpb + part), acc);
 }
 
+// ---- the lean accumulation: 128 VGPRs, no scratch, four waves per SIMD ---------------------------------------------
+// k_msm_accumulate above keeps ~166 VGPRs alive (LLVM interleaves the independent products of a mixed addition), which
+// pins it at three waves per SIMD with nothing beside it.  Here every Montgomery product is one opaque inline-asm block
+// with hand-picked temporaries (fp_asm.inc, generated by tools/gen_fp_asm.py) and the insertion is STRAIGHT-LINE: the
+// exceptional cases of the group law — an identity operand, q = +-acc — are not decided in the loop at all; a lane that
+// meets one (a one-limb filter that cannot miss a multiple of p) stores the sum it has, appends (slot, entry index) to
+// fix_list and leaves; k_msm_accumulate_fix finishes those buckets with the general formulas.  For uniform scalars the
+// list holds the filter's false positives: ~10 * 2^-58 per insertion (two limbs), i.e. it is empty.
+struct RawPt { uint4 a, b, c, d; };   // x (a, b) || y (c, d) as loaded: 16 registers while the gather is in flight
+FP_INLINE RawPt raw_gather(const uint8_t* __restrict__ bases, const uint8_t* __restrict__ endo_x, uint32_t e) {
+    const size_t idx = e & ENT_IDX;
+    const uint4* px = reinterpret_cast<const uint4*>((e & ENT_ENDO) ? endo_x + 32 * idx : bases + 64 * idx);
+    const uint4* py = reinterpret_cast<const uint4*>(bases + 64 * idx + 32);
+    RawPt r;
+    r.a = px[0]; r.b = px[1]; r.c = py[0]; r.d = py[1];
+    return r;
+}
+FP_INLINE G1Affine raw_unpack(const RawPt& r, uint32_t e) {
+    G1Affine p;
+    { uint32_t w[8] = {r.a.x, r.a.y, r.a.z, r.a.w, r.b.x, r.b.y, r.b.z, r.b.w}; p.x = fp_unpack<FqParams>(w); }
+    { uint32_t w[8] = {r.c.x, r.c.y, r.c.z, r.c.w, r.d.x, r.d.y, r.d.z, r.d.w}; p.y = fp_unpack<FqParams>(w); }
+    return (e & ENT_NEG) ? affine_neg(p) : p;
+}
+// acc += q (madd-2008-s, same bounds as xyzz_add_affine).  Returns false, acc untouched, when the general formula is
+// needed.  issue_next() starts the gather of the following entry (16 registers while in flight) at the point of the formula where
+// the fewest values are alive: behind (PPP, Q), with the last four products still to come.  (Measured alternative: the gather as
+// LDS-DMA, global_load_lds_dwordx4 into a per-wave stage, a whole addition ahead and no registers at all — 1 102 us per 2^20-point
+// launch against 1 076: the lead is not what bounds the kernel.)
+// DUAL: independent products as two chains in lock step (no dependent back-to-back multiply-adds: what three waves per SIMD
+// need); otherwise one chain per product (fewest temporaries; four waves per SIMD hide the dependent issue).
+template <bool DUAL, class NextF>
+FP_INLINE bool xyzz_add_affine_lean(G1XYZZ& acc, G1Affine q, NextF&& issue_next) {
+    bool ok = !q.is_identity() && !acc.is_identity();
+    if (DUAL) {
+        fpa_mul_dual_ip<FqParams>(q.x, acc.zz, q.y, acc.zzz);   // U2 [2], S2 [2]
+    } else {
+        fpa_mul_ip<FqParams>(q.x, acc.zz);
+        fpa_mul_ip<FqParams>(q.y, acc.zzz);
+    }
+    Fq p = FQ_SUB(8, q.x, acc.x);                        // [10]
+    Fq r = FQ_SUB(4, q.y, acc.y);                        // [6]
+    ok = ok && !fp_maybe_zero_mod2<10, FqParams>(p);
+    if (!ok) return false;
+    Fq pp, rr;
+    if (DUAL) {
+        fpa_sqr_dual<FqParams>(pp, rr, p, r);            // 100 -> [2], 36 -> [2]
+        fpa_mul_dual_ip<FqParams>(p, pp, acc.x, pp);     // PPP 20 -> [2], Q 16 -> [2]
+    } else {
+        fpa_sqr<FqParams>(pp, p);
+        fpa_sqr<FqParams>(rr, r);
+        fpa_mul_ip<FqParams>(p, pp);
+        fpa_mul_ip<FqParams>(acc.x, pp);
+    }
+    Fq x3 = fp_sub_sub2<6, FqParams>(rr, p, acc.x);      // PPP + 2Q [6] -> [8]
+    Fq d = FQ_SUB(8, acc.x, x3);                         // Q - X3 [10]
+    acc.x = x3;
+    Fq ny = fp_neg<4, FqParams>(acc.y);                  // [4]
+    if (DUAL) {
+        fpa_mul_dual_ip<FqParams>(acc.zz, pp, acc.zzz, p);   // [2], [2]
+        issue_next();
+        fpa_mul2_ip<FqParams>(ny, p, r, d);              // (4p - Y1)*PPP + R*(Q - X3): (4*2 + 6*10)/169 + 1 -> [2]
+    } else {
+        fpa_mul_ip<FqParams>(acc.zz, pp);
+        fpa_mul_ip<FqParams>(acc.zzz, p);
+        fpa_mul2_ip1<FqParams>(ny, p, r, d);
+    }
+    acc.y = ny;
+    return true;
+}
+// a + q for two affine points (mmadd-2008-s, 4M + 2S): the second point of a bucket.  Same contract as above.
+template <bool DUAL>
+FP_INLINE bool xyzz_add_affine_affine_lean(G1XYZZ& o, const G1Affine& a, const G1Affine& q) {
+    Fq p = FQ_SUB(2, q.x, a.x);                          // [4]
+    Fq r = FQ_SUB(2, q.y, a.y);                          // [4]
+    if (q.is_identity() || fp_maybe_zero_mod2<4, FqParams>(p)) return false;
+    Fq pp, rr;
+    Fq qq = a.x;
+    if (DUAL) {
+        fpa_sqr_dual<FqParams>(pp, rr, p, r);            // 16 -> [2], [2]
+        fpa_mul_dual_ip<FqParams>(p, pp, qq, pp);        // PPP [2], Q [2]
+    } else {
+        fpa_sqr<FqParams>(pp, p);
+        fpa_sqr<FqParams>(rr, r);
+        fpa_mul_ip<FqParams>(p, pp);
+        fpa_mul_ip<FqParams>(qq, pp);
+    }
+    o.x = fp_sub_sub2<6, FqParams>(rr, p, qq);           // [8]
+    Fq d = FQ_SUB(8, qq, o.x);                           // [10]
+    Fq ny = fp_neg<2, FqParams>(a.y);                    // [2]
+    if (DUAL) fpa_mul2_ip<FqParams>(ny, p, r, d);        // (2*2 + 4*10)/169 + 1 -> [2]
+    else fpa_mul2_ip1<FqParams>(ny, p, r, d);
+    o.y = ny;
+    o.zz = pp;
+    o.zzz = p;
+    return true;
+}
+
+// Same contract as k_msm_accumulate<CHAIN>; counters[2] counts fix_list's {slot, first unfinished entry} pairs.
+template <int CHAIN, bool DUAL>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4)))
+k_msm_accumulate_lean(const uint8_t* __restrict__ bases, const uint8_t* __restrict__ endo_x,
+                      const uint32_t* __restrict__ entries, const uint32_t* __restrict__ offs,
+                      const uint32_t* __restrict__ hist, const uint32_t* __restrict__ order, uint32_t nbt, uint32_t big,
+                      uint32_t lpb, uint8_t* __restrict__ buckets, uint32_t* __restrict__ big_list,
+                      uint32_t* __restrict__ big_keys, uint32_t* __restrict__ counters, uint32_t* __restrict__ fix_list) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nbt * lpb) return;
+    const uint32_t part = t % lpb;
+    const uint32_t key = order ? order[t / lpb] : t / lpb;
+    const uint32_t len = hist[key];
+    const uint32_t slot = key * lpb + part;
+    if (len > big) {   // over-long bucket: chunk list for k_msm_accumulate_big (as in k_msm_accumulate)
+        if (part != 0) {
+            if (CHAIN == 1) xyzz_store(buckets + XYZZ_BYTES * (size_t)slot, G1XYZZ::identity());
+            return;
+        }
+        const uint32_t cs = big_chunk_size(len);
+        const uint32_t nch = (len + cs - 1) / cs;
+        const uint32_t base = atomicAdd(&counters[0], nch);
+        for (uint32_t j = 0; j < nch; ++j) {
+            big_list[3 * (base + j)] = key;
+            big_list[3 * (base + j) + 1] = j;
+            big_list[3 * (base + j) + 2] = nch;
+        }
+        if (nch > 1) {
+            const uint32_t kk = atomicAdd(&counters[1], 1u);
+            big_keys[3 * kk] = key;
+            big_keys[3 * kk + 1] = base;
+            big_keys[3 * kk + 2] = nch;
+        }
+        return;
+    }
+    const uint32_t lo = (uint32_t)(((uint64_t)len * part) / lpb), hi = (uint32_t)(((uint64_t)len * (part + 1)) / lpb);
+    // (register budget: the run is addressed as entries[roff + k] off the kernel argument, not through a per-lane 64-bit pointer)
+    const uint32_t roff = offs[key];
+    auto run = [&](uint32_t i) { return entries[roff + i]; };
+    G1XYZZ acc = G1XYZZ::identity();
+    if (CHAIN == 2) {
+        if (hi == lo) return;
+        acc = xyzz_load(buckets + XYZZ_BYTES * (size_t)slot);
+    }
+    uint32_t k = lo;
+    if (hi > lo) {
+        uint32_t e_cur = run(lo);
+        RawPt nxt = raw_gather(bases, endo_x, e_cur);
+        uint32_t e_nxt = run(lo + 1 < hi ? lo + 1 : hi - 1);
+        auto advance = [&](uint32_t k_now) {   // gather entry k_now + 1 (past the end: the last entry again, unused), fetch the index of entry k_now + 2
+            e_cur = e_nxt;
+            nxt = raw_gather(bases, endo_x, e_nxt);
+            e_nxt = run(k_now + 2 < hi ? k_now + 2 : hi - 1);
+        };
+        bool go = true;
+        if (acc.is_identity()) {   // the first point of a bucket is a copy, the second an affine + affine addition (4M + 2S)
+            const G1Affine first = raw_unpack(nxt, e_cur);
+            go = !first.is_identity();
+            if (go) {
+                advance(lo);
+                k = lo + 1;
+                acc = G1XYZZ::from_affine(first);
+                if (k < hi) {
+                    const G1Affine second = raw_unpack(nxt, e_cur);
+                    advance(lo + 1);
+                    go = xyzz_add_affine_affine_lean<DUAL>(acc, first, second);
+                    if (go) k = lo + 2;
+                }
+            }
+        }
+        if (go) {
+#pragma unroll 1
+            for (; k < hi; ++k) {
+                const G1Affine cur = raw_unpack(nxt, e_cur);
+                if (!xyzz_add_affine_lean<DUAL>(acc, cur, [&]() { advance(k); })) break;
+            }
+        }
+        if (k < hi) {
+            const uint32_t f = atomicAdd(&counters[2], 1u);
+            fix_list[2 * f] = slot;
+            fix_list[2 * f + 1] = k;
+        }
+    }
+    uint32_t oslot = slot;
+    asm volatile("" : "+v"(oslot));   // (keeps the 64-bit store address out of the loop's live set)
+    xyzz_store(buckets + XYZZ_BYTES * (size_t)oslot, acc);
+}
+// the buckets the lean kernel left unfinished, with the general formulas: one lane per list entry, from entry k on
+__global__ void __launch_bounds__(64) k_msm_accumulate_fix(const uint8_t* __restrict__ bases, const uint8_t* __restrict__ endo_x,
+                                                           const uint32_t* __restrict__ entries,
+                                                           const uint32_t* __restrict__ offs,
+                                                           const uint32_t* __restrict__ hist, uint32_t lpb,
+                                                           uint8_t* __restrict__ buckets,
+                                                           const uint32_t* __restrict__ counters,
+                                                           const uint32_t* __restrict__ fix_list) {
+    const uint32_t nfix = counters[2];
+    for (uint32_t f = blockIdx.x * 64 + threadIdx.x; f < nfix; f += gridDim.x * 64) {
+        const uint32_t slot = fix_list[2 * f], k0 = fix_list[2 * f + 1];
+        const uint32_t key = slot / lpb, part = slot - key * lpb;
+        const uint32_t len = hist[key];
+        const uint32_t hi = (uint32_t)(((uint64_t)len * (part + 1)) / lpb);
+        const uint32_t* run = entries + offs[key];
+        G1XYZZ acc = xyzz_load(buckets + XYZZ_BYTES * (size_t)slot);
+#pragma unroll 1
+        for (uint32_t k = k0; k < hi; ++k) xyzz_add_affine(acc, msm_gather(bases, endo_x, run[k]));
+        xyzz_store(buckets + XYZZ_BYTES * (size_t)slot, acc);
+    }
+}
+
 // buckets[key] = sum of the lpb slice sums written by k_msm_accumulate (skipped for over-long buckets, whose
 // sum the chunk path writes to slot key*lpb directly)
 __global__ void __launch_bounds__(BLOCK) k_msm_bucket_combine(const uint8_t* __restrict__ parts,
