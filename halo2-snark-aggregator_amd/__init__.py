@@ -124,6 +124,7 @@ def load_library():
         "h2agg_vk_destroy": (None, [C.c_void_p]),
         "h2agg_verify_aggregation": (i32, [ctxp, vp, sz, u8p, u8p, vp, vp, vp, C.POINTER(i32)]),   # see verifier.py
         "h2agg_verify_aggregation_ex": (i32, [ctxp, vp, sz, u8p, u8p, vp, vp, vp, C.POINTER(i32), vp, sz]),
+        "h2agg_verify_aggregation_sharded": (i32, [ctxp, vp, sz, vp, u8p, u8p, vp, vp, vp, C.POINTER(i32), vp, sz]),   # see verifier.py
         "h2agg_verify_plan_stats": (i32, [ctxp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "h2agg_transcript_configure": (i32, [ctxp, i32]),
         "h2agg_poseidon_squeeze_batch_host": (i32, [u8p, sz, sz, C.POINTER(C.c_uint32), sz, vp, i32]),

@@ -175,3 +175,17 @@ def aggregate_sharded(backend, build_local_proofs, n_total: int, lam: bytes, dis
     dist.all_gather(gathered, mine)                                   # the only collective: 128 B per rank
     parts = [bytes(g.cpu().numpy().tobytes()) for g in gathered]
     return (backend.sum_affine([p[:64] for p in parts]), backend.sum_affine([p[64:] for p in parts]))
+
+
+def aggregate_sharded_from_bytes(verifier_mod, eng, circuits_local, global_index, n_total: int, rank: int, world: int,
+                                 dist=None, device=None, s_g2=None, g2=None):
+    """The sharded aggregation FROM PROOF BYTES: no challenge is passed in.  Each rank hands its proofs' transcripts to
+    h2agg_verify_aggregation_sharded, which replays them, exchanges every proof's last squeeze (32 B) so that every rank
+    derives the SAME lambda (halo2-snark-aggregator-api/src/systems/halo2/verify.rs:909-913, :924), folds its proofs with the
+    powers lambda^(N-1-i) (:926-938), evaluates its partial pair on its GPU and exchanges + sums the partials.
+
+    circuits_local / global_index: as verifier.verify_aggregation_sharded.  dist: an initialised torch.distributed group used
+    as the transport (gloo, or nccl = RCCL with `device`); None: the engine's own RCCL communicator (eng.comm_init_rank), the
+    exchange then never leaves the C ABI.  Returns (left_aff, right_aff, lambda, pairing_ok or None), equal on every rank."""
+    allgather = verifier_mod.dist_allgather(dist, device) if dist is not None else None
+    return verifier_mod.verify_aggregation_sharded(eng, circuits_local, global_index, n_total, rank, world, allgather, s_g2, g2)

@@ -2224,5 +2224,5 @@ int h2agg_final_pair_check(h2agg_ctx* c, const uint8_t left_aff[64], const uint8
 
 #include "schema_api.inc"
 #include "transcript.inc"
-#include "verifier.inc"
 #include "comm.inc"
+#include "verifier.inc"

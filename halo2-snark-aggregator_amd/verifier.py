@@ -102,12 +102,8 @@ class VerifyingKey:
             pass
 
 
-def verify_aggregation(eng, circuits: Sequence[Tuple[VerifyingKey, str, int, Sequence[Tuple[Sequence[bytes], bytes]]]],
-                       s_g2: Optional[bytes] = None, g2: Optional[bytes] = None, with_commits: bool = False):
-    """circuits: [(vk, name, g_lagrange_handle, [(instance columns as bytes (32 B per value), transcript bytes), ...])].
-    -> (left_aff, right_aff, lambda, pairing_ok or None); with_commits: a fifth element, the advice commitments per proof
-    in aggregation order ([[64-byte affine point per advice column] per proof]: `commits` of verify.rs:852-856)"""
-    lib = eng._lib
+def _marshal_circuits(circuits):
+    """-> (array of h2agg_circuit_proofs, objects to keep alive)"""
     arr = (_CircuitProofs * len(circuits))()
     keep = []
     for k, (vk, name, g_lagrange, proofs) in enumerate(circuits):
@@ -125,6 +121,16 @@ def verify_aggregation(eng, circuits: Sequence[Tuple[VerifyingKey, str, int, Seq
         nm = name.encode()
         keep += [tr, tl, inst, lens, nm]
         arr[k] = _CircuitProofs(vk._vk, nm, g_lagrange, n, tr, tl, inst, lens)
+    return arr, keep
+
+
+def verify_aggregation(eng, circuits: Sequence[Tuple[VerifyingKey, str, int, Sequence[Tuple[Sequence[bytes], bytes]]]],
+                       s_g2: Optional[bytes] = None, g2: Optional[bytes] = None, with_commits: bool = False):
+    """circuits: [(vk, name, g_lagrange_handle, [(instance columns as bytes (32 B per value), transcript bytes), ...])].
+    -> (left_aff, right_aff, lambda, pairing_ok or None); with_commits: a fifth element, the advice commitments per proof
+    in aggregation order ([[64-byte affine point per advice column] per proof]: `commits` of verify.rs:852-856)"""
+    lib = eng._lib
+    arr, keep = _marshal_circuits(circuits)
     left, right, lam = C.create_string_buffer(64), C.create_string_buffer(64), C.create_string_buffer(32)
     ok = C.c_int(-1)
     ncommit = [vk.num_advice_columns for vk, _n, _g, proofs in circuits for _p in proofs]
@@ -141,3 +147,64 @@ def verify_aggregation(eng, circuits: Sequence[Tuple[VerifyingKey, str, int, Seq
         commits.append([adv.raw[off + 64 * j: off + 64 * (j + 1)] for j in range(n)])
         off += 64 * n
     return res + (commits,)
+
+
+_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p)
+
+
+class _Shard(C.Structure):
+    _fields_ = [("rank", C.c_uint32), ("world", C.c_uint32), ("total_proofs", C.c_size_t),
+                ("global_index", C.POINTER(C.c_uint32)), ("allgather", _ALLGATHER_FN), ("user", C.c_void_p)]
+
+
+def dist_allgather(dist, device=None):
+    """an `allgather(payload: bytes) -> [bytes per rank]` over an initialised torch.distributed group (gloo on CPU tensors,
+    nccl = RCCL on `device`)"""
+    import torch
+
+    def allgather(payload: bytes):
+        mine = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
+        if device is not None:
+            mine = mine.to(device)
+        out = [torch.empty_like(mine) for _ in range(dist.get_world_size())]
+        dist.all_gather(out, mine)
+        return [bytes(t.cpu().numpy().tobytes()) for t in out]
+    return allgather
+
+
+def verify_aggregation_sharded(eng, circuits, global_index: Sequence[int], total_proofs: int, rank: int, world: int,
+                               allgather=None, s_g2: Optional[bytes] = None, g2: Optional[bytes] = None):
+    """h2agg_verify_aggregation_sharded: `circuits` holds THIS rank's proofs (same layout as verify_aggregation),
+    global_index[j] = position of the j-th local proof in the aggregation order, total_proofs = N over all ranks.
+    allgather: callable(bytes) -> list of `world` byte strings in rank order (the host's transport; dist_allgather wraps
+    torch.distributed), or None to use the engine's RCCL communicator (comm_init_rank).  Every rank gets
+    (left_aff, right_aff, lambda, pairing_ok or None), equal to verify_aggregation over all N proofs."""
+    lib = eng._lib
+    arr, keep = _marshal_circuits(circuits)
+    nlocal = sum(len(proofs) for _vk, _n, _g, proofs in circuits)
+    if len(global_index) != nlocal:
+        raise ValueError("global_index must name every local proof (%d given, %d proofs)" % (len(global_index), nlocal))
+    gi = (C.c_uint32 * max(nlocal, 1))(*global_index)
+    err: List[BaseException] = []
+
+    def cb(_user, send, nbytes, recv):
+        try:
+            parts = allgather(C.string_at(send, nbytes))
+            if len(parts) != world or any(len(p) != nbytes for p in parts):
+                raise ValueError("allgather returned %r parts for world %d" % ([len(p) for p in parts], world))
+            C.memmove(recv, b"".join(parts), nbytes * world)
+            return 0
+        except BaseException as e:   # no exception crosses the C ABI
+            err.append(e)
+            return 1
+    fn = _ALLGATHER_FN(cb) if allgather is not None else _ALLGATHER_FN()
+    shard = _Shard(rank, world, total_proofs, gi, fn, None)
+    left, right, lam = C.create_string_buffer(64), C.create_string_buffer(64), C.create_string_buffer(32)
+    ok = C.c_int(-1)
+    rc = lib.h2agg_verify_aggregation_sharded(eng._ctx, C.cast(arr, C.c_void_p), len(circuits), C.byref(shard), s_g2,
+                                              g2 if s_g2 is not None else None, left, right, lam,
+                                              C.byref(ok) if s_g2 is not None else None, None, 0)
+    if err:
+        raise err[0]
+    eng._check(rc)
+    return left.raw, right.raw, lam.raw, (bool(ok.value) if s_g2 is not None else None)

@@ -337,6 +337,31 @@ int h2agg_verify_aggregation(h2agg_ctx* ctx, const h2agg_circuit_proofs* circuit
 int h2agg_verify_aggregation_ex(h2agg_ctx* ctx, const h2agg_circuit_proofs* circuits, size_t ncircuits, const uint8_t* s_g2,
                                 const uint8_t* g2, uint8_t left_aff[64], uint8_t right_aff[64], uint8_t lambda_out[32],
                                 int* pairing_ok, uint8_t* advice_out, size_t advice_cap);
+/* The same aggregation with its proofs SHARDED over `world` ranks, one GPU each (first grain; BASELINE.json
+ * configs[3], configs[4]).  This rank passes ITS proofs in `circuits` (any subset, typically round-robin; a rank may hold none)
+ * and says where each sits in the aggregation order: global_index[j] for the j-th local proof, counting circuits in order and
+ * proofs within a circuit in order; total_proofs = N, the length of the whole aggregation.  Two exchanges, both inside the call:
+ *   1. every proof's last squeeze (32 B) goes to every rank, which absorbs them in aggregation order and squeezes the SAME
+ *      lambda as the one-rank call (halo2-snark-aggregator-api/src/systems/halo2/verify.rs:909-913, :924);
+ *   2. the rank's partial pair  sum_j lambda^(N-1-global_index[j]) * (W_x_j, W_g_j)  (the fold of verify.rs:926-938, which is
+ *      linear) goes to every rank and is summed with the group law (RCCL has no reduction over group elements).
+ * Transport: `allgather` (the host's own: MPI, a torch.distributed store, sockets — send = this rank's `bytes`, recv = [world]
+ * [bytes] in rank order, returns 0) or, if NULL, the context's RCCL communicator over xGMI (h2agg_comm_init_rank with the same
+ * rank / world).  Every rank returns the same pair, lambda and pairing verdict as h2agg_verify_aggregation on all N proofs in
+ * one context, bit for bit.  advice_out: this rank's proofs only, local order.  Errors as h2agg_verify_aggregation; two ranks
+ * claiming one position, or a position nobody holds -> H2AGG_ERR_INVALID on every rank. */
+typedef int (*h2agg_allgather_fn)(void* user, const void* send, size_t bytes, void* recv);
+typedef struct {
+    uint32_t rank, world;
+    size_t total_proofs;
+    const uint32_t* global_index;
+    h2agg_allgather_fn allgather;
+    void* user;
+} h2agg_shard;
+int h2agg_verify_aggregation_sharded(h2agg_ctx* ctx, const h2agg_circuit_proofs* circuits, size_t ncircuits,
+                                     const h2agg_shard* shard, const uint8_t* s_g2, const uint8_t* g2, uint8_t left_aff[64],
+                                     uint8_t right_aff[64], uint8_t lambda_out[32], int* pairing_ok, uint8_t* advice_out,
+                                     size_t advice_cap);
 /* The host-side recording of an aggregation (every proof's queries of params.rs:74-224, the multiopen fold, both eval_prepare
  * walks of evaluation.rs:205-293) depends on the SHAPE of the call only — which keys, how many proofs of each, their length —
  * so a context keeps the last few recordings and a later call of the same shape only refills the proof scalars, challenges and

@@ -441,3 +441,60 @@ def verify_aggregation_proofs_in_chip(pchip, circuits: List[CircuitProofs], ctx=
     agg = S.aggregate_fold([p for p, _c in proofs], lam)                               # :926-938
     left, right, _names = S.evaluate_multiopen_proof(ctx, S.OracleFieldChip(), pchip, agg)
     return left, right, plain, [c for _p, c in proofs], lam
+
+
+def verify_aggregation_sharded_rank(pchip, circuits_local: List[CircuitProofs], global_index: List[int], n_total: int,
+                                    allgather, ctx=None, make_transcript=None):
+    """One rank of a SHARDED verify_aggregation_proofs_in_chip (first grain): this rank holds the proofs of
+    `circuits_local`, whose positions in the aggregation order are global_index (circuits in order, proofs in order);
+    n_total = N.  `allgather(payload: bytes) -> [bytes per rank]` is the only communication.  Restates what the reference
+    does in one process (verify.rs:835-942) as the rank-local computation it distributes to:
+      exchange 1   every proof's last squeeze, absorbed in aggregation order by the main transcript  (:909-913, :924)
+      local fold   sum_j lambda^(N-1-g_j) * proof_j — the nested fold acc = acc * lambda + proof expanded   (:926-938)
+      exchange 2   the partial (left, right) of every rank, added with the group law
+    Returns (left, right, lambda), the same on every rank and the same as the one-process function."""
+    ctx = ctx if ctx is not None else S.OracleCtx()
+    mk = make_transcript or (lambda data: P.PoseidonTranscriptRead(data))
+    proofs, squeezes = [], []
+    for circuit in circuits_local:
+        transcripts = []
+        for i, (instances, data) in enumerate(circuit.proofs):
+            t = mk(data)
+            transcripts.append(t)
+            _assigned, commitments = assign_instance_commitment(pchip, ctx, instances, circuit.cs, circuit.g_lagrange)
+            p, _c, _vp = verify_single_proof_no_eval(t, pchip, ctx, commitments, circuit.cs, "%s_p%d" % (circuit.name, i))
+            proofs.append(p)
+        squeezes += [t.squeeze_challenge_scalar() for t in transcripts]
+    assert len(proofs) == len(global_index)
+    # exchange 1: {position, squeeze} records, n_total slots per rank
+    rec = b"".join(g.to_bytes(4, "little") + O.fe_to_bytes(q) for g, q in zip(global_index, squeezes))
+    rec += b"\xff" * (36 * (n_total - len(global_index)))
+    slots = [None] * n_total
+    for part in allgather(rec):
+        for k in range(n_total):
+            g = int.from_bytes(part[36 * k:36 * k + 4], "little")
+            if g != 0xFFFFFFFF:
+                assert slots[g] is None, "two ranks claim one proof position"
+                slots[g] = int.from_bytes(part[36 * k + 4:36 * k + 36], "little")
+    assert all(q is not None for q in slots), "a proof position nobody holds"
+    main = mk(b"")
+    for q in slots:
+        main.common_scalar(q)
+    lam = main.squeeze_challenge_scalar()
+    # local fold with the powers the nested fold would have applied
+    acc = None
+    for p, g in zip(proofs, global_index):
+        e = n_total - 1 - g
+        term = p if e == 0 else S.MultiOpenProof(p.w_x * S.scalar(pow(lam, e, O.R)), p.w_g * S.scalar(pow(lam, e, O.R)))
+        acc = term if acc is None else S.MultiOpenProof(acc.w_x + term.w_x, acc.w_g + term.w_g)
+    if acc is None:
+        left, right = None, None                                                       # the identity
+    else:
+        left, right, _names = S.evaluate_multiopen_proof(ctx, S.OracleFieldChip(), pchip, acc)
+    # exchange 2
+    mine = (O.aff_to_bytes(left) if left is not None else bytes(64)) + (O.aff_to_bytes(right) if right is not None else bytes(64))
+    tot_l, tot_r = None, None
+    for part in allgather(mine):
+        tot_l = O.add(tot_l, O.aff_from_bytes(part[:64]))
+        tot_r = O.add(tot_r, O.aff_from_bytes(part[64:]))
+    return tot_l, tot_r, lam
