@@ -128,6 +128,25 @@ def pmc_evidence(stage_name: str, log2n: int):
     return t["bytes_per_launch"], valu, "csrc_sha " + t["csrc_sha"]
 
 
+def pmc_evidence_for(stage_name: str, log2n: int, batch: int):
+    """committed counter evidence for an aggregation leg's dominant kernel (profiles/r*_batch_traffic.json, written by
+    tools/profile_round.sh for the 16 x 2^22 share of BASELINE.json configs[4]); tied to the kernel sources by hash like
+    pmc_evidence.  None when there is none for this shape."""
+    import glob
+    for cand in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*batch_traffic.json")), reverse=True):
+        try:
+            with open(cand) as f:
+                got = json.load(f)
+        except (OSError, ValueError):
+            continue
+        if got.get("log2n") == log2n and got.get("batch") == batch:
+            if got.get("csrc_sha") != csrc_sha():
+                return {"stale": "kernel sources changed since %s was collected" % os.path.relpath(cand, ROOT)}
+            return {"file": os.path.relpath(cand, ROOT), "bytes_per_aggregation": got.get("bytes_per_launch"),
+                    "traffic_over_algorithmic": got.get("traffic_over_algorithmic"), "csrc_sha": got.get("csrc_sha")}
+    return None
+
+
 def check_pair_second_path(eng, pkg, agg, mo, syn, specs, lam, commits, pair):
     """The aggregate leg's final pair recomputed along a DIFFERENT route through the product: every proof evaluated on
     its own (N separate evaluate_multiopen_proof calls: other tapes, other MSM sizes and plans), the N pairs then folded
@@ -201,26 +220,31 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
     # Instance scalars are resident in HBM (seeded per global proof id); the first 2^k entries of `g_table` stand in
     # for g_lagrange.
     n_inst = ((1 << args.agg_instance_log2) - 6) if args.agg_instance_log2 else 0
-    d_inst = d_inst_out = None
     my_idx = agg.shard_indices(n_total, world, rank)
-    if n_inst and my_idx:
-        # generated on the device, seeded per GLOBAL proof id (sharding-independent; SURVEY.md 8(d) config 5: "scalars
-        # generated on device from (seed, proof-id) to keep PCIe out of the measurement")
-        d_inst = torch.empty((len(my_idx), n_inst, 32), dtype=torch.uint8, device=dev)
+
+    def instance_scalars(ids):
+        """generated on the device, seeded per GLOBAL proof id (sharding-independent; SURVEY.md 8(d) config 5: "scalars
+        generated on device from (seed, proof-id) to keep PCIe out of the measurement")"""
+        t = torch.empty((len(ids), n_inst, 32), dtype=torch.uint8, device=dev)
         gen = torch.Generator(device=dev)
-        for j, i in enumerate(my_idx):
+        for j, i in enumerate(ids):
             gen.manual_seed(0x1A57 + i)
-            d_inst[j] = torch.randint(0, 256, (n_inst, 32), dtype=torch.uint8, device=dev, generator=gen)
-        d_inst[:, :, 31] &= 0x1F                               # < 2^253 < r: canonical
-        d_inst_out = torch.zeros((len(my_idx), 96), dtype=torch.uint8, device=dev)
+            t[j] = torch.randint(0, 256, (n_inst, 32), dtype=torch.uint8, device=dev, generator=gen)
+        t[:, :, 31] &= 0x1F                                    # < 2^253 < r: canonical
+        o = torch.zeros((len(ids), 96), dtype=torch.uint8, device=dev)
         torch.cuda.synchronize(dev)   # (the inputs are complete before anything reads them, whatever stream it runs on)
+        return t, o
+    d_inst = d_inst_out = None
+    if n_inst and my_idx:
+        d_inst, d_inst_out = instance_scalars(my_idx)
+    inst_of = {tuple(my_idx): (d_inst, d_inst_out)}
     last_commits = {}
 
     def build(b, idx):
         """per proof: n x EvaluationQuery::new + batch_multi_open_proofs, both in the C++ host layer"""
         out = []
+        d_inst, d_inst_out = inst_of[tuple(idx)]
         if n_inst and idx:   # queue the instance-column MSMs first; the host builds the schemas underneath them
-            assert list(idx) == my_idx
             # ONE batched MSM: all of this rank's instance columns against the shared g_lagrange table
             eng.g1_msm_device_batch_async(g_table, d_inst.data_ptr(), n_inst, len(idx), d_inst_out.data_ptr())
         first = []
@@ -270,10 +294,47 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
     dt = sorted(times)[len(times) // 2]          # the median repetition: one stray 10-ms hiccup in 8 x 2.5 ms is not the rate
     if pair2 != pair:
         raise SystemExit("aggregate leg: the timed repetitions do not reproduce the verified pair — refusing to report")
+    # ---- sharded run: the whole aggregation once more on ONE rank (rank 0's GPU, no collective, every proof local) must give
+    # the pair the ranks agreed on — the first multi-GPU run checks itself
+    one_rank = None
+    if world > 1:
+        same = 1
+        if rank == 0:
+            all_idx = list(range(n_total))
+            if n_inst:
+                inst_of[tuple(all_idx)] = instance_scalars(all_idx)
+            pair1 = agg.aggregate_sharded(backend, build, n_total, lam, dist=None)
+            inst_of.pop(tuple(all_idx), None)
+            same = 1 if pair1 == pair else 0
+        flag = torch.tensor([same], dtype=torch.int32, device=coll_dev)
+        dist.broadcast(flag, src=0)
+        if int(flag.item()) != 1:
+            raise SystemExit("aggregate leg: the %d-rank pair differs from the one-rank recomputation — refusing to report" % world)
+        one_rank = "the %d proofs aggregated again on rank 0 alone (no collective) give the same pair" % n_total
     t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
+    # the leg's dominant kernel against the HBM roofline: one more aggregation, untimed, with every MSM stage
+    # bracketed by events; algorithmic bytes = 96 B per point of the instance-column MSMs (the two multi_exps of the
+    # evaluation are ~10^3 points: noise beside them)
+    hbm = None
+    if n_inst and my_idx:
+        eng.profile_reset()
+        eng.profile_enable(True)
+        agg.aggregate_sharded(backend, build, n_total, lam, dist=dist, device=coll_dev, comm=comm, rank_world=(rank, world))
+        eng.synchronize()
+        eng.profile_enable(False)
+        st = eng.profile_stages()
+        dom = max(st.items(), key=lambda kv: kv[1][0])
+        pts = n_inst * len(my_idx)
+        if dom[1][0] > 0:
+            gbps = ALGO_BYTES_PER_POINT * pts / (dom[1][0] * 1e-3) / 1e9
+            hbm = {"kernel": dom[0], "kernel_ms_per_aggregation": dom[1][0], "points_per_rank": pts, "achieved": gbps, "unit": "GB/s",
+                   "peak": HBM_PEAK_GBS, "frac": gbps / HBM_PEAK_GBS, "pmc_evidence": pmc_evidence_for(dom[0], args.agg_instance_log2, len(my_idx))}
+        eng.profile_reset()
+    elif dist is not None:
+        agg.aggregate_sharded(backend, build, n_total, lam, dist=dist, device=coll_dev, comm=comm, rank_world=(rank, world))   # (keeps the collectives matched)
     cpu_ctx = None
     if world == 1 and n_total <= 16:
         cpu_ctx = {"specs": specs, "lam": lam, "commits": [last_commits[i] for i in range(n_total)] if n_inst else None,
@@ -289,10 +350,13 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
         "repetitions": reps,
         "commitments_per_proof": specs[0].nq,
         "instance_msm_points_per_proof": n_inst,
-        "instance_msm_fixed_base_levels": bool(n_inst and args.agg_instance_log2 <= 18 and not args.no_fixed_base),
+        "instance_msm_fixed_base_levels": bool(n_inst and getattr(args, "fixed_base_ok", False)),
         "final_pair_sha": __import__("hashlib").sha256(pair[0] + pair[1]).hexdigest()[:16],
         "exchange": exchange_how,
         "rccl_ranks": eng.comm_size() if comm is not None else 0,   # ranks of the C-ABI communicator the exchange ran on (0 = not used)
+        "one_rank_recomputation": one_rank,
+        "roofline": hbm,
+        "proofs_per_gpu": args.agg_proofs,
         "verified": verified if verified else "sharded run: every rank's timed repetitions reproduce the warm-up pair "
                                               "(the single-rank run of the same proofs is cross-checked per proof)",
         "note": "synthetic shape-faithful schemas; per proof: the instance-column commitment MSM against the fixed "
@@ -520,6 +584,8 @@ def main():
     ap.add_argument("--agg-commitments", type=int, default=300, help="advice commitments per synthetic proof")
     ap.add_argument("--no-fixed-base", action="store_true",
                     help="do not precompute fixed-base levels for the g_lagrange stand-in (h2agg_bases_precompute)")
+    ap.add_argument("--agg-config4", type=int, default=1,
+                    help="1: also run BASELINE.json configs[4]'s per-GPU share (16 proofs x 2^22-point instance MSMs); 0: skip")
     ap.add_argument("--agg-instance-log2", type=int, default=17,
                     help="k of the per-proof instance-column commitment MSM (2^k - 6 scalars); 0 = leave it out")
     args = ap.parse_args()
@@ -629,6 +695,17 @@ def main():
     # The W warm-up steps run IMMEDIATELY before the timed region (the self-check above is seconds of host arithmetic during
     # which the GPU idles and drops its clocks: with the warm-up in front of it the first timed steps ran 2-3 % slow), after an
     # untimed spin-up that brings the clocks back up (same MSM, results discarded).
+    # `value_no_spinup`: the same W + K steps WITHOUT the spin-up, measured first (reported beside `value`, which has it)
+    for i in range(args.warmup):
+        step(i)
+    eng.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    eng.synchronize()
+    barrier()
+    dt_cold = time.perf_counter() - t0
     for i in range(args.spinup):
         step(i % d_out.shape[0])
     for i in range(args.warmup):
@@ -645,15 +722,19 @@ def main():
     dt = time.perf_counter() - t0
     eng.profile_enable(False)
 
+    # every one of the K timed outputs, not only the first: all steps ran the same MSM, all must hold the checked result
+    outs_aff = eng.g1_batch_to_affine(bytes(d_out[:max(args.steps, 1)].cpu().numpy().tobytes()))
+    if any(outs_aff[64 * i:64 * i + 64] != want for i in range(args.steps)):
+        raise SystemExit("rank %d: a timed step's output differs from (sum k_i s_i)*G — refusing to report a number" % rank)
     folded_ok = True
     if gathered is not None:
         folded = eng.g1_sum(bytes(gathered.cpu().numpy().tobytes()))     # W = sum of per-rank accumulators
         folded_ok = len(folded) == 96
 
-    t_all = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+    t_all = torch.tensor([dt, dt_cold], dtype=torch.float64, device=coll_dev)
     if dist is not None:
         dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
-    dt_max = float(t_all.item())
+    dt_max, dt_cold_max = float(t_all[0].item()), float(t_all[1].item())
 
     out = None
     if rank == 0:
@@ -671,6 +752,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt_max / args.steps * 1e3,
+            "value_no_spinup": world * n * args.steps / dt_cold_max,
+            "ms_per_step_no_spinup": dt_cold_max / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -689,7 +772,7 @@ def main():
                 "proofs_per_sec": world * args.steps / dt_max,
                 "exchange": "none (1 GPU)" if world == 1 else "1 all-gather of %d x 96 B + local fold" % world,
                 "bases_generate_s": t_gen,
-                "verified": "(sum k_i s_i)*G" + ("" if folded_ok else " FOLD-FAILED"),
+                "verified": "(sum k_i s_i)*G on every one of the %d timed outputs" % args.steps + ("" if folded_ok else " FOLD-FAILED"),
             },
             "roofline": {
                 "bound": "hbm",
@@ -743,8 +826,10 @@ def main():
                 gk = gk.to(dev)
                 torch.cuda.synchronize(dev)
                 g_table = eng.bases_generate(gk.data_ptr(), 1 << args.agg_instance_log2)
+                args.fixed_base_ok = False
                 if args.agg_instance_log2 <= 18 and not args.no_fixed_base:
                     eng.bases_precompute(g_table)          # g_lagrange is fixed per circuit size: one-off SRS-style setup
+                    args.fixed_base_ok = True
             agg_info = aggregation_leg(pkg, eng, args, rank, world, dist, (dev, coll_dev), g_table)  # configs[2]/[3]: 4 proofs per GPU
             cpu_ctx = agg_info.pop("_cpu_ctx", None)
             big = argparse.Namespace(**vars(args))
@@ -756,6 +841,39 @@ def main():
             if agg_info is not None and more is not None:
                 agg_info["at_%d_proofs_per_gpu" % big.agg_proofs] = {
                     k: more[k] for k in ("proofs_per_sec", "proofs", "seconds_per_aggregation")}
+            if agg_info is not None and more is not None:
+                # BASELINE.json configs[3]: 4 proofs per GPU (32 at 8 GPUs) — this leg under the config's name
+                agg_info["config3"] = {k: agg_info.get(k) for k in ("proofs", "proofs_per_gpu", "proofs_per_sec", "seconds_per_aggregation",
+                                                                   "rccl_ranks", "final_pair_sha", "one_rank_recomputation", "roofline",
+                                                                   "instance_msm_points_per_proof", "exchange")}
+            if agg_info is not None and args.agg_config4 and args.agg_instance_log2 < 20:
+                # BASELINE.json configs[4]: 16 proofs per GPU of a k = 22 circuit's shape (2^22 - 6 instance scalars per proof,
+                # generated on the device), 128 proofs at 8 GPUs; at one GPU this is that configuration's per-GPU share
+                c4 = argparse.Namespace(**vars(args))
+                c4.agg_proofs, c4.agg_instance_log2 = 16, 22
+                gen4 = torch.Generator(device="cpu").manual_seed(0x6C62)
+                gk4 = torch.randint(0, 256, (1 << 22, 32), dtype=torch.uint8, generator=gen4)
+                gk4[:, 31] &= 0x1F
+                gk4 = gk4.to(dev)
+                torch.cuda.synchronize(dev)
+                g4 = eng.bases_generate(gk4.data_ptr(), 1 << 22)
+                del gk4
+                try:
+                    c4.fixed_base_ok = False
+                    if not args.no_fixed_base:
+                        try:
+                            eng.bases_precompute(g4)       # fixed-base levels for a 2^22-point g_lagrange (one-off, per circuit size)
+                            c4.fixed_base_ok = True
+                        except Exception as ex:            # noqa: BLE001 - the leg runs without them and says so
+                            print("rank %d: no fixed-base levels for the 2^22 table (%s)" % (rank, ex), file=sys.stderr)
+                    leg4 = aggregation_leg(pkg, eng, c4, rank, world, dist, (dev, coll_dev), g4)
+                    leg4.pop("_cpu_ctx", None)
+                    agg_info["config4" if world > 1 else "config4_share"] = {
+                        k: leg4.get(k) for k in ("proofs", "proofs_per_gpu", "proofs_per_sec", "seconds_per_aggregation", "rccl_ranks",
+                                                 "final_pair_sha", "one_rank_recomputation", "roofline", "instance_msm_points_per_proof",
+                                                 "instance_msm_fixed_base_levels", "exchange", "verified")}
+                finally:
+                    eng.bases_free(g4)
             if agg_info is not None and world == 1 and g_table is not None and args.agg_instance_log2 <= 18:
                 agg_info["full_pipeline"] = full_pipeline_leg(pkg, eng, args, g_table)
             if cpu_ctx is not None and rank == 0 and not args.no_cpu_baseline:

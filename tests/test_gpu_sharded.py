@@ -170,3 +170,23 @@ def test_two_processes_on_one_gpu_over_gloo(eng, pkg):
     for rank, res in got:
         assert not isinstance(res, str), res
         assert res == want, "rank %d differs from the one-context aggregation" % rank
+
+
+def test_sharded_over_the_contexts_rccl_communicator_world_1(pkg, eng):
+    """transport = the context's own RCCL communicator (shard->allgather NULL): ncclAllGather of both exchanges inside the C ABI"""
+    ver = importlib.import_module(entry.PKG_NAME + ".verifier")
+    setup, circuits = make_batch(0x6E4, [SHAPES[1]], 2)
+    want = run_product(pkg, eng, setup, circuits)
+    e2 = pkg.H2Agg(0)
+    try:
+        e2.comm_init_rank(pkg.H2Agg.comm_unique_id(), 0, 1)
+        table, vks, arg = product_args(ver, e2, setup, circuits)
+        try:
+            got = ver.verify_aggregation_sharded(e2, arg, [0, 1], 2, 0, 1, None, g2b(setup.s_g2), g2b(setup.g2))
+        finally:
+            for vk in vks:
+                vk.close()
+            e2.bases_free(table)
+    finally:
+        e2.close()
+    assert got == want
