@@ -460,13 +460,13 @@ def full_pipeline_leg(pkg, eng, args, g_table):
         return ts[len(ts) // 2], first[0]
 
     def both(k):
-        os.environ.pop("H2AGG_PLAN_CACHE", None)
+        eng.debug_configure("plan_cache", 1)
         dt, res = timed(k)
-        os.environ["H2AGG_PLAN_CACHE"] = "0"                     # every call records its schema afresh
+        eng.debug_configure("plan_cache", 0)                     # every call records its schema afresh
         try:
             dt_rec, res_rec = timed(k)
         finally:
-            os.environ.pop("H2AGG_PLAN_CACHE", None)
+            eng.debug_configure("plan_cache", 1)
         if res_rec[:3] != res[:3]:
             raise SystemExit("full pipeline leg: a reused recording and a fresh one disagree — refusing to report")
         return dt, dt_rec, res

@@ -125,6 +125,7 @@ def load_library():
         "h2agg_verify_aggregation": (i32, [ctxp, vp, sz, u8p, u8p, vp, vp, vp, C.POINTER(i32)]),   # see verifier.py
         "h2agg_verify_aggregation_ex": (i32, [ctxp, vp, sz, u8p, u8p, vp, vp, vp, C.POINTER(i32), vp, sz]),
         "h2agg_verify_aggregation_sharded": (i32, [ctxp, vp, sz, vp, u8p, u8p, vp, vp, vp, C.POINTER(i32), vp, sz]),   # see verifier.py
+        "h2agg_debug_configure": (i32, [ctxp, C.c_char_p, i32]),
         "h2agg_verify_plan_stats": (i32, [ctxp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
         "h2agg_transcript_configure": (i32, [ctxp, i32]),
         "h2agg_poseidon_squeeze_batch_host": (i32, [u8p, sz, sz, C.POINTER(C.c_uint32), sz, vp, i32]),
@@ -534,6 +535,10 @@ class H2Agg:
 
     def msm_configure_sort(self, sub_bits: int = 0, tile: int = 0):
         self._check(self._lib.h2agg_msm_configure_sort(self._ctx, sub_bits, tile))
+
+    def debug_configure(self, key: str, value: int):
+        """h2agg_debug_configure: per-context test hooks (include/h2agg.h "Environment")"""
+        self._check(self._lib.h2agg_debug_configure(self._ctx, key.encode(), int(value)))
 
     def msm_set_tail_overlap(self, level: int = 2):
         """0 = off, 1 = only the Horner kernel on a tail stream, 2 = bucket reduction + window sums + Horner"""

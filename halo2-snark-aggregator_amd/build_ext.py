@@ -1,6 +1,9 @@
 """Build libh2agg.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
 
     python halo2-snark-aggregator_amd/build_ext.py [--force]
+    python halo2-snark-aggregator_amd/build_ext.py --measure    -> tools/libh2agg_measure.so, built with -DH2AGG_MEASURE_KNOBS
+        (the experiment switches of csrc/h2agg.hip `knob()`; for A/B runs: copy it over libh2agg.so on the GPU box.  The product
+        build has none of them.)
 """
 from __future__ import annotations
 
@@ -36,6 +39,20 @@ def build(force: bool = False, verbose: bool = True) -> str:
     return OUT
 
 
+def build_measure() -> str:
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    if not os.path.exists(hipcc):
+        hipcc = "hipcc"
+    out = os.path.join(os.path.dirname(HERE), "tools", "libh2agg_measure.so")
+    cmd = [hipcc] + FLAGS + ["-DH2AGG_MEASURE_KNOBS", "-o", out] + [os.path.join(CSRC, s) for s in SOURCES]
+    print("[h2agg] " + " ".join(cmd), flush=True)
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
-    print(OUT)
+    if "--measure" in sys.argv:
+        print(build_measure())
+    else:
+        build(force="--force" in sys.argv)
+        print(OUT)

@@ -36,9 +36,18 @@ using namespace h2agg;
 
 namespace {
 
+// Experiment switches (occupancy caps, kernel variants, priorities, fault injection ...) exist only in a library built with
+// -DH2AGG_MEASURE_KNOBS (tools/ and profiles/ say which runs used one).  A shipped library reads the environment for
+// nothing but what include/h2agg.h documents under "Environment": H2AGG_HOST_THREADS, H2AGG_TRANSCRIPT, H2AGG_HOST_SPONGE,
+// H2AGG_NO_PLACE, H2AGG_TRACE, H2AGG_TRACE_PHASES.  Per-call test hooks go through h2agg_debug_configure.
+#ifdef H2AGG_MEASURE_KNOBS
+static inline const char* knob(const char* name) { return getenv(name); }
+#else
+static inline const char* knob(const char*) { return nullptr; }
+#endif
 // Events that only order streams of this device / time kernels on it: device-scope release.  (The default is a system-scope
-// release — an L2 write-back at every record.)  H2AGG_EVENT_SCOPE=system restores the default for A/B runs.
-static const bool ev_scope_system = getenv("H2AGG_EVENT_SCOPE") && !strcmp(getenv("H2AGG_EVENT_SCOPE"), "system");
+// release — an L2 write-back at every record.)  H2AGG_EVENT_SCOPE=system (a measure knob) restores the default for A/B runs.
+static const bool ev_scope_system = knob("H2AGG_EVENT_SCOPE") && !strcmp(knob("H2AGG_EVENT_SCOPE"), "system");
 #define EV_SYNC_FLAGS (ev_scope_system ? hipEventDisableTiming : (hipEventDisableTiming | hipEventReleaseToDevice))
 #define EV_TIME_FLAGS (ev_scope_system ? hipEventDefault : hipEventReleaseToDevice)
 
@@ -132,6 +141,8 @@ struct h2agg_ctx {
     void* comm = nullptr;
     int comm_rank = 0, comm_size = 0;
 
+    // h2agg_debug_configure: test hooks read per call (chained host-buffer slices, comb route, plan cache)
+    int dbg_pcie_slices = 0, dbg_pcie_glv = 0, dbg_pcie_chain = 1, dbg_comb_msm = 1, dbg_plan_cache = 1;
     // tuning
     int cfg_c = 0, cfg_seg = 0, cfg_big = 0, cfg_sub_bits = 0, cfg_tile = 0;
     int cfg_glv = 0;   // 0 = auto, 1 = on, -1 = off
@@ -368,7 +379,7 @@ inline void crumb(uintptr_t a, uint64_t note) {
 }
 struct CrumbsInit {
     CrumbsInit() {
-        if (getenv("H2AGG_BREADCRUMBS")) {
+        if (knob("H2AGG_BREADCRUMBS")) {
             g_crumbs.on = true;
             signal(SIGABRT, crumbs_dump);
         }
@@ -385,11 +396,11 @@ __global__ void k_chaos_wait(uint32_t us) {
     while (wall_clock64() - t0 < (uint64_t)us * 100u) __builtin_amdgcn_s_sleep(32);   // wall_clock64 ticks at 100 MHz
 }
 inline int chaos_bits() {
-    static const int bits = getenv("H2AGG_CHAOS") ? atoi(getenv("H2AGG_CHAOS")) : 0;
+    static const int bits = knob("H2AGG_CHAOS") ? atoi(knob("H2AGG_CHAOS")) : 0;
     return bits;
 }
 inline void debug_sync(int bit) {   // H2AGG_SYNC_AT=<bits>: a device-wide wait at that point of msm_run (bisecting a race)
-    static const int bits = getenv("H2AGG_SYNC_AT") ? atoi(getenv("H2AGG_SYNC_AT")) : 0;
+    static const int bits = knob("H2AGG_SYNC_AT") ? atoi(knob("H2AGG_SYNC_AT")) : 0;
     if (bits & bit) hipDeviceSynchronize();
 }
 inline void chaos_wait(int bit, hipStream_t s, uint32_t us = 300) {
@@ -432,7 +443,7 @@ int place_streams(h2agg_ctx* c) {
         blocks[i] = us > 120.0;
         nfree += !blocks[i];
     }
-    if (getenv("H2AGG_TRACE_STREAMS")) {
+    if (knob("H2AGG_TRACE_STREAMS")) {
         fprintf(stderr, "[h2agg] streams that hold the main stream up when busy:");
         for (int i = 0; i < np; ++i) fprintf(stderr, " %d%s", i, blocks[i] ? "*" : "");
         fprintf(stderr, "  (* = shares its queue)\n");
@@ -583,7 +594,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     if (sp.PW > (uint32_t)SORT_MAX_PW) return fail(c, H2AGG_ERR_INVALID, "too many sort partitions");
     const uint32_t nseg_total = WT * p.spw;
     // 4 lanes per chain in the bucket reduction / window sums (latency) or 1 (least work): see msm_kernels.hpp
-    static const int par4_env = getenv("H2AGG_PAR4") ? atoi(getenv("H2AGG_PAR4")) : 0;
+    static const int par4_env = knob("H2AGG_PAR4") ? atoi(knob("H2AGG_PAR4")) : 0;
     // measured: wins up to 16384 segments (c <= 13; also a 2^20-point MSM with 32-bucket segments in throughput mode,
     // where 1 024 waves of 94-addition chains would otherwise outlast the step), loses to the extra work above
     const bool par4 = par4_env ? par4_env > 0 : nseg_total <= 16384;
@@ -608,7 +619,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     TRY(ensure(c, c->offs[sq], (size_t)p.NBT * 4));
     TRY(ensure(c, c->order[sq], (size_t)p.NBT * 4));
     // digit-major sort (sort_kernels.hpp): plain 16-bit windows over one table, 2^16 .. 2^22 points
-    static const bool dm_env_off = getenv("H2AGG_SORT") && !strcmp(getenv("H2AGG_SORT"), "packed");
+    static const bool dm_env_off = knob("H2AGG_SORT") && !strcmp(knob("H2AGG_SORT"), "packed");
     const size_t dm_row = p.glv ? 2 * n : n;   // keys per window (GLV: both halves of a scalar land in the same 8 windows)
     // (c = 17, plain scalars: 15 windows of 2^16 buckets, 16-bit magnitude codes + sign / zero bit rows — k_dm_digits17, k_dm_partition<true>)
     const bool dm17 = p.c == 17 && !p.glv;
@@ -833,9 +844,9 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     }
     // (experiment knob: 256-thread workgroups + H2AGG_ACC_LDS pin the accumulation at exactly N waves per SIMD and leave the rest
     // of the CU — registers and LDS — to whatever else is in flight; see profiles/r03_sweeps.txt section 10)
-    static const int acc_block = getenv("H2AGG_ACC_BLOCK") ? atoi(getenv("H2AGG_ACC_BLOCK")) : 64;
-    static const bool lean = !(getenv("H2AGG_ACC") && !strcmp(getenv("H2AGG_ACC"), "generic"));
-    static const bool lean_dual = !(getenv("H2AGG_ACC") && !strcmp(getenv("H2AGG_ACC"), "lean1"));
+    static const int acc_block = knob("H2AGG_ACC_BLOCK") ? atoi(knob("H2AGG_ACC_BLOCK")) : 64;
+    static const bool lean = !(knob("H2AGG_ACC") && !strcmp(knob("H2AGG_ACC"), "generic"));
+    static const bool lean_dual = !(knob("H2AGG_ACC") && !strcmp(knob("H2AGG_ACC"), "lean1"));
     uint32_t* fix_list = nullptr;
     if (lean) {
         TRY(ensure(c, c->fix_list[sq], (size_t)p.NBT * lpb * 8));
@@ -847,7 +858,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         StageTimer t(c, ST_ACCUM, st);
         // one-wave workgroups: a 4-wave workgroup needs a free slot on all four SIMDs of a CU at once and its waves retire
         // at different times; single waves fill any slot as it frees up (2^20 points: 1.74 -> 1.67 ms/step)
-        static const int acc_lds = getenv("H2AGG_ACC_LDS") ? atoi(getenv("H2AGG_ACC_LDS")) : 0;   // experiment: unused LDS per wave caps the occupancy
+        static const int acc_lds = knob("H2AGG_ACC_LDS") ? atoi(knob("H2AGG_ACC_LDS")) : 0;   // experiment: unused LDS per wave caps the occupancy
         if (lean) {   // 128 VGPRs, four waves per SIMD; exceptional cases go to fix_list (msm_kernels.hpp)
             auto kacc = lean_dual ? (chain == CHAIN_FIRST ? k_msm_accumulate_lean<1, true> : (chain == CHAIN_MID || chain == CHAIN_LAST) ? k_msm_accumulate_lean<2, true> : k_msm_accumulate_lean<0, true>)
                                   : (chain == CHAIN_FIRST ? k_msm_accumulate_lean<1, false> : (chain == CHAIN_MID || chain == CHAIN_LAST) ? k_msm_accumulate_lean<2, false> : k_msm_accumulate_lean<0, false>);
@@ -908,12 +919,12 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     // accumulation of the next MSM (launched from that MSM's call, behind its sort: `deferred_tail`); results are picked
     // up by join_tails().
 #ifdef H2AGG_MEASURE_KNOBS   // timing experiments only (WRONG results): 1 skips the bucket reduction, 2 the window sums, 4 the Horner tail
-    static const int dbg_skip = getenv("H2AGG_DBG_SKIP") ? atoi(getenv("H2AGG_DBG_SKIP")) : 0;
+    static const int dbg_skip = knob("H2AGG_DBG_SKIP") ? atoi(knob("H2AGG_DBG_SKIP")) : 0;
 #else
     constexpr int dbg_skip = 0;   // (a shipped library has no switch that changes results)
 #endif
     // two-dimensional bucket reduction for 16-bit windows (msm_kernels.hpp); H2AGG_REDUCE=segments keeps the segment kernels
-    static const bool r2d_env_off = getenv("H2AGG_REDUCE") && !strcmp(getenv("H2AGG_REDUCE"), "segments");
+    static const bool r2d_env_off = knob("H2AGG_REDUCE") && !strcmp(knob("H2AGG_REDUCE"), "segments");
     const int r2d_lc = p.NB == (uint32_t)(R2D_ROWS * R2D<7>::COLS) ? 7 : p.NB == (uint32_t)(R2D_ROWS * R2D<8>::COLS) ? 8 : 0;
     const bool r2d = !r2d_env_off && !c->cfg_seg && !pre && r2d_lc != 0;
     uint32_t* ticket = nullptr;
@@ -1000,7 +1011,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         return H2AGG_OK;
     };
     // deferral needs another MSM to carry it; a full per-stage profiling pass keeps every stage inside its own call
-    static const bool defer_env_off = getenv("H2AGG_DEFER_TAILS") && !strcmp(getenv("H2AGG_DEFER_TAILS"), "0");
+    static const bool defer_env_off = knob("H2AGG_DEFER_TAILS") && !strcmp(knob("H2AGG_DEFER_TAILS"), "0");
     // (and it only pays from 2^20 points on — measured, profiles/r02_sweeps.txt: below that the tail is a large share of the
     // MSM and wants to start at once; the two multi_exps of an evaluation in particular)
     if (tails_off_stream && !defer_env_off && !(c->profiling && c->prof_only < 0) && n >= ((size_t)1 << 20)) {
@@ -1069,7 +1080,7 @@ int h2agg_create(int device_ordinal, h2agg_ctx** out) try {
     c->stream = c->own_stream;
     for (int k = 0; k < h2agg_ctx::TAIL_SLOTS; ++k) {
         // H2AGG_TAIL_PRIO (experiment): -1 = lowest, 1 = highest stream priority for the tail streams
-        static const int tail_prio = getenv("H2AGG_TAIL_PRIO") ? atoi(getenv("H2AGG_TAIL_PRIO")) : 0;
+        static const int tail_prio = knob("H2AGG_TAIL_PRIO") ? atoi(knob("H2AGG_TAIL_PRIO")) : 0;
         int pr_lo = 0, pr_hi = 0;
         hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);   // lo = least (numerically greatest)
         if ((tail_prio ? hipStreamCreateWithPriority(&c->tail_streams[k], hipStreamNonBlocking, tail_prio < 0 ? pr_lo : pr_hi)
@@ -1082,7 +1093,7 @@ int h2agg_create(int device_ordinal, h2agg_ctx** out) try {
     }
     int apr_lo = 0, apr_hi = 0;
     hipDeviceGetStreamPriorityRange(&apr_lo, &apr_hi);
-    static const int acc_prio = getenv("H2AGG_ACC_PRIO") ? atoi(getenv("H2AGG_ACC_PRIO")) : 0;   // experiment: -1 lowest
+    static const int acc_prio = knob("H2AGG_ACC_PRIO") ? atoi(knob("H2AGG_ACC_PRIO")) : 0;   // experiment: -1 lowest
     if ((acc_prio ? hipStreamCreateWithPriority(&c->acc_stream, hipStreamNonBlocking, acc_prio < 0 ? apr_lo : apr_hi)
                   : hipStreamCreateWithFlags(&c->acc_stream, hipStreamNonBlocking)) != hipSuccess) {
         h2agg_destroy(c);
@@ -1351,7 +1362,7 @@ int h2agg_g1_batch_scalar_mul(h2agg_ctx* c, const uint8_t* bases, const uint8_t*
     TRY(clear_flags(c));
     // GLV + signed window-4 ladder, four lanes per point (csrc/scalar_mul_kernels.hpp); H2AGG_SCALAR_MUL=ladder selects the
     // round-1 bit-serial kernel for A/B measurements
-    static const bool ladder = getenv("H2AGG_SCALAR_MUL") && !strcmp(getenv("H2AGG_SCALAR_MUL"), "ladder");
+    static const bool ladder = knob("H2AGG_SCALAR_MUL") && !strcmp(knob("H2AGG_SCALAR_MUL"), "ladder");
     if (ladder) {
         hipLaunchKernelGGL(k_g1_batch_scalar_mul, dim3(grid_for(c, n)), dim3(BLOCK), 0, c->stream,
                            (const uint8_t*)c->in_a.p, (const uint8_t*)c->in_b.p, n, (uint8_t*)c->out.p, c->d_flags);
@@ -1497,7 +1508,7 @@ int h2agg_bases_generate(h2agg_ctx* c, const void* d_k, size_t n, uint64_t* hand
     if (hipMalloc((void**)&t.d, 64 * n) != hipSuccess) return fail(c, H2AGG_ERR_NOMEM, "hipMalloc(base table)");
     int rc = clear_flags(c);
     if (rc == H2AGG_OK) {
-        static const bool ladder = getenv("H2AGG_SCALAR_MUL") && !strcmp(getenv("H2AGG_SCALAR_MUL"), "ladder");
+        static const bool ladder = knob("H2AGG_SCALAR_MUL") && !strcmp(knob("H2AGG_SCALAR_MUL"), "ladder");
         size_t blocks = (n + BLOCK - 1) / BLOCK;
         if (blocks > 65535 * 16) blocks = 65535 * 16;
         if (ladder) {
@@ -1646,7 +1657,7 @@ namespace {
 // `batch` MSMs of n <= COMB_MSM_MAX scalars each over the leading bases of a table with fixed-base levels: through the table's
 // comb (made here on first use).  Returns false when the comb route does not apply.
 bool comb_msm_applies(const h2agg_ctx* c, const Table& t, size_t n) {
-    const bool off = getenv("H2AGG_COMB_MSM") && !strcmp(getenv("H2AGG_COMB_MSM"), "0");
+    const bool off = !c->dbg_comb_msm;
     return !off && t.pre && !c->cfg_c && n >= 1 && n <= (size_t)COMB_MSM_MAX;
 }
 int comb_msm_run(h2agg_ctx* c, Table& t, const uint8_t* d_scalars, size_t n, size_t batch, uint8_t* d_out_jac) {
@@ -1875,7 +1886,7 @@ int msm_host(h2agg_ctx* c, const uint8_t* bases, size_t stride, const uint8_t* s
     // Large inputs are cut into slices that cross PCIe on a copy stream while the previous slice is being computed
     // (an MSM is a sum over points, so the slices' results just add up): 96 B/point of transfer hide under ~1.7 ns/point
     // of arithmetic, instead of preceding it.  Slices of >= 2^19 points keep the per-MSM efficiency (2^18-point slices lose more than the overlap gains).
-    const bool chain_env_off = getenv("H2AGG_PCIE_CHAIN") && !strcmp(getenv("H2AGG_PCIE_CHAIN"), "0");
+    const bool chain_env_off = !c->dbg_pcie_chain;
     const bool chained = !chain_env_off;
     // chained slices (below) of ~200 K points: the transfer (1.73 ns/point) and the slice's sort + accumulation (~90 us +
     // 1.3 ns/point) then take turns of equal length — measured, profiles/r03_sweeps.txt section 10: 2^20 points 3.03 / 2.97 /
@@ -1883,7 +1894,7 @@ int msm_host(h2agg_ctx* c, const uint8_t* bases, size_t stride, const uint8_t* s
     const size_t MIN_SLICE = chained ? (size_t)200 << 10 : (size_t)1 << 19;
     size_t nslices = chained ? (n + MIN_SLICE / 2) / MIN_SLICE : n / MIN_SLICE;
     if (nslices > MSM_MAX_SLICES) nslices = MSM_MAX_SLICES;
-    const int env_slices = getenv("H2AGG_PCIE_SLICES") ? atoi(getenv("H2AGG_PCIE_SLICES")) : 0;   // measurement knob (read per call: tests vary it)
+    const int env_slices = c->dbg_pcie_slices;   // (h2agg_debug_configure "pcie_slices": tests vary it per call)
     if (env_slices >= 1 && env_slices <= MSM_MAX_SLICES && n >= ((size_t)1 << 10) * (size_t)env_slices) nslices = (size_t)env_slices;
     if (nslices < 2) {
         HIP_TRY(c, hipMemcpyAsync(c->in_a.p, bases, stride * n, hipMemcpyHostToDevice, c->stream));
@@ -1910,7 +1921,7 @@ int msm_host(h2agg_ctx* c, const uint8_t* bases, size_t stride, const uint8_t* s
     // sums; ONE reduction / window-sum / Horner chain follows the last slice — that chain (0.6-0.9 ms of pure latency) is what
     // is left exposed behind the last byte of the transfer, so the slices can be small.  H2AGG_PCIE_CHAIN=0: the earlier
     // scheme (every slice a whole MSM, results added) for A/B runs.
-    const int chain_glv_env = getenv("H2AGG_PCIE_GLV") ? atoi(getenv("H2AGG_PCIE_GLV")) : 0;
+    const int chain_glv_env = c->dbg_pcie_glv;
     if (chained) {
         c->chain_n = n;
         c->chain_glv = chain_glv_env ? chain_glv_env > 0 : (c->cfg_glv >= 0 && n < ((size_t)1 << 22));
@@ -2064,6 +2075,20 @@ int h2agg_msm_configure_sort(h2agg_ctx* c, int sub_bits, int tile) try {
     return H2AGG_OK;
 } catch (const std::bad_alloc&) {
     return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
+} catch (...) {
+    return H2AGG_ERR_INVALID;
+}
+
+int h2agg_debug_configure(h2agg_ctx* c, const char* key, int value) try {
+    if (!c || !key) return H2AGG_ERR_INVALID;
+    const std::string k(key);
+    if (k == "pcie_slices") c->dbg_pcie_slices = value;
+    else if (k == "pcie_glv") c->dbg_pcie_glv = value;
+    else if (k == "pcie_chain") c->dbg_pcie_chain = value;
+    else if (k == "comb_msm") c->dbg_comb_msm = value;
+    else if (k == "plan_cache") c->dbg_plan_cache = value;
+    else return fail(c, H2AGG_ERR_INVALID, "h2agg_debug_configure: unknown key " + k);
+    return H2AGG_OK;
 } catch (...) {
     return H2AGG_ERR_INVALID;
 }

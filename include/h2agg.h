@@ -366,8 +366,8 @@ int h2agg_verify_aggregation_sharded(h2agg_ctx* ctx, const h2agg_circuit_proofs*
  * walks of evaluation.rs:205-293) depends on the SHAPE of the call only — which keys, how many proofs of each, their length —
  * so a context keeps the last few recordings and a later call of the same shape only refills the proof scalars, challenges and
  * commitments before running the same tape and multi_exps on them (every value is still computed from that call's inputs).
- * This reports how often that happened; any pointer may be NULL.  H2AGG_PLAN_CACHE=0 in the environment records every call
- * afresh. */
+ * This reports how often that happened; any pointer may be NULL.  h2agg_debug_configure(ctx, "plan_cache", 0) records every
+ * call afresh. */
 int h2agg_verify_plan_stats(h2agg_ctx* ctx, uint64_t* hits, uint64_t* misses, uint64_t* plans_kept);
 
 /* ---- multi-GPU exchange -----------------------------------------------------------
@@ -433,7 +433,7 @@ int h2agg_fr_tape_eval(h2agg_ctx* ctx, const uint8_t* consts, size_t nconst, con
  * workgroup-sized chunks (0 = max(256, 8 x mean)). */
 int h2agg_msm_configure(h2agg_ctx* ctx, int window_bits, int reduce_segment, int big_bucket_threshold);
 /* (16-bit windows reduce their buckets as 256 rows x 128 columns — plain sums, then two weighted sums per window — unless
- * reduce_segment is given, which selects the running-sum segment kernels; environment, for A/B runs: H2AGG_REDUCE=segments.) */
+ * reduce_segment is given, which selects the running-sum segment kernels; a -DH2AGG_MEASURE_KNOBS build also reads H2AGG_REDUCE=segments.) */
 /* GLV / endomorphism split of the scalars (k = k1 + lambda*k2, |k_i| < 2^127; phi(P) = (beta*x, y)): halves the
  * number of windows — same bucket additions, half the bucket reduction and half the serial doubling chain.
  * beta*x is computed once per base (a 32 B/point column beside the table), so the price is the decomposition pass and
@@ -448,8 +448,21 @@ int h2agg_msm_configure_lanes_per_bucket(h2agg_ctx* ctx, int lanes);
  * n does not fit the packed item's index field, n > 2^(31 - sub_bits)); tile = -2 additionally stages level 1
  * through LDS (measured slower; kept as a tested variant); tile = -3 keeps the packed two-level sort where the
  * digit-major sort would apply (plain 16-bit windows over one table, 2^16 .. 2^22 points; any non-default knob
- * here selects the packed kernels as well).  Environment, for A/B runs: H2AGG_SORT=packed. */
+ * here selects the packed kernels as well).  (A -DH2AGG_MEASURE_KNOBS build also reads H2AGG_SORT=packed.) */
 int h2agg_msm_configure_sort(h2agg_ctx* ctx, int sub_bits, int tile);
+/* Environment.  The library reads these variables and no others (experiment switches exist only in builds with
+ * -DH2AGG_MEASURE_KNOBS, which no shipped library is):
+ *   H2AGG_HOST_THREADS=n      worker threads of the host sponge pool (default: the usable cores)
+ *   H2AGG_TRANSCRIPT=device|host, H2AGG_HOST_SPONGE=ifma|portable   overrides of h2agg_transcript_configure's automatic choice
+ *   H2AGG_NO_PLACE            skip the stream-placement probe of h2agg_create / h2agg_set_stream (needed when the caller's
+ *                             stream is being graph-captured: the probe launches and synchronises)
+ *   H2AGG_TRACE, H2AGG_TRACE_PHASES   diagnostics on stderr (schema evaluation / phases of h2agg_verify_aggregation)
+ * Test hooks, per context and per call (tests/ exercise code paths a production call reaches only by size):
+ *   key "pcie_slices" n   cut h2agg_g1_msm's host buffers into n slices (0 = automatic)
+ *       "pcie_glv" -1|0|1 GLV for those slices (0 = automatic)       "pcie_chain" 0|1  slices share one bucket set (default 1)
+ *       "comb_msm" 0|1    small MSMs over tables with fixed-base levels take the comb (default 1)
+ *       "plan_cache" 0|1  h2agg_verify_aggregation keeps the recording of a call shape (default 1) */
+int h2agg_debug_configure(h2agg_ctx* ctx, const char* key, int value);
 /* Overlap the latency-shaped tail of one MSM (enable = 1: the Horner kernel, one wave; 2: bucket reduction + window
  * sums + Horner; 3: as 2, and the bucket accumulation itself leaves the context's stream, so that the NEXT MSM's sort runs
  * under it — measured: a loss at 2^20 points (1.39 -> 1.55 ms per MSM: both kernels slow each other down), +3 % at 2^22) with the bulk kernels of the next ones: the tail runs on one of three tail streams of the context.  With overlap on, a result written by

@@ -39,20 +39,32 @@ def _want(ks, ss):
     return O.aff_to_bytes(O.scalar_mul(sum(k * s for k, s in zip(ks, ss)) % O.R, O.G1))
 
 
+_HOOK = {"H2AGG_PCIE_SLICES": ("pcie_slices", 0), "H2AGG_PCIE_GLV": ("pcie_glv", 0), "H2AGG_PCIE_CHAIN": ("pcie_chain", 1),
+         "H2AGG_COMB_MSM": ("comb_msm", 1)}
+_ENG = []   # the engine the hooks act on (set by the autouse fixture below)
+
+
 class _Env:
+    """per-call test hooks of the library (h2agg_debug_configure; they used to be environment variables, hence the names)"""
+
     def __init__(self, **kv):
-        self.kv = {k: str(v) for k, v in kv.items()}
+        self.kv = {k: int(v) for k, v in kv.items()}
 
     def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.kv}
-        os.environ.update(self.kv)
+        for k, v in self.kv.items():
+            _ENG[0].debug_configure(_HOOK[k][0], v)
 
     def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        for k in self.kv:
+            _ENG[0].debug_configure(*_HOOK[k])
+
+
+@pytest.fixture(autouse=True)
+def _hooks_engine(eng):
+    _ENG[:] = [eng]
+    yield
+    for key, default in _HOOK.values():
+        eng.debug_configure(key, default)
 
 
 def _scalars(kind, n, seed):

@@ -244,12 +244,12 @@ def test_recorded_aggregation_is_reused_for_new_proofs_of_the_same_shape(eng, pk
         r_a = check(subset([3, 0]))                  # the first shape again
         h2, m2, kept = eng.verify_plan_stats()
         assert (h2 - h0, m2 - m0) == (3, 2) and kept >= 2
-        os.environ["H2AGG_PLAN_CACHE"] = "0"
+        eng.debug_configure("plan_cache", 0)
         try:
             assert check(subset([3, 0])) == r_a      # recorded afresh: the same bytes
             assert eng.verify_plan_stats()[:2] == (h2, m2)
         finally:
-            del os.environ["H2AGG_PLAN_CACHE"]
+            eng.debug_configure("plan_cache", 1)
 
         def flip_eval(cs):
             inst, data = cs[0].proofs[1]

@@ -35,9 +35,7 @@ for n in sizes:
     for be in (("device", "host", "auto", "auto/recorded-every-call") if "--host-first" not in sys.argv else ("host", "auto", "device", "host")):
         eng.transcript_configure(be.split("/")[0])
         # (the host-side recording of a call is kept and reused by later calls of the same shape; the last row switches that off)
-        os.environ.pop("H2AGG_PLAN_CACHE", None)
-        if "/" in be:
-            os.environ["H2AGG_PLAN_CACHE"] = "0"
+        eng.debug_configure("plan_cache", 0 if "/" in be else 1)
         for pair in (True, False):
             a = ver.verify_aggregation(eng, arg, g2 if pair else None, g2 if pair else None)
             reps = 9
@@ -53,7 +51,7 @@ for n in sizes:
             print("%3d proofs  %-24s  %s  %8.3f ms  %8.1f proofs/s   (min %.3f max %.3f)" % (
                 n, be, "with pairing" if pair else "no pairing  ", dt * 1e3, n / dt, ts[0] * 1e3, ts[-1] * 1e3), flush=True)
     assert res["device"] == res["host"] == res["auto"] == res.get("auto/recorded-every-call", res["auto"]), "backends disagree"
-os.environ.pop("H2AGG_PLAN_CACHE", None)
+eng.debug_configure("plan_cache", 1)
 eng.transcript_configure("auto")
 print("recorded aggregations: hits %d, misses %d, kept %d" % eng.verify_plan_stats())
 vk.close()
