@@ -75,6 +75,15 @@ struct Table {
     // fixed-base levels, i.e. one its owner declared constant): comb[((b * 32 + w) * 255 + d - 1) * 64] = d * 2^(8w) * P_b
     uint8_t* comb = nullptr;
     size_t comb_n = 0;
+    std::vector<uint8_t*> comb_retired;   // smaller combs this one replaced: kernels in flight may still read them, so they
+                                          // are freed where the table's other buffers are (behind a synchronisation)
+    void free_combs() {
+        if (comb) hipFree(comb);
+        for (uint8_t* p : comb_retired) hipFree(p);
+        comb = nullptr;
+        comb_n = 0;
+        comb_retired.clear();
+    }
 };
 struct PreTable {   // what msm_run needs of it
     const uint8_t* d;
@@ -434,13 +443,18 @@ int place_streams(h2agg_ctx* c) {
     bool blocks[NP];
     int nfree = 0;
     for (int i = 0; i < np; ++i) {
-        hipLaunchKernelGGL(k_chaos_wait, dim3(1), dim3(1), 0, pool[i], 250u);
-        const auto t0 = std::chrono::steady_clock::now();
-        hipLaunchKernelGGL(k_chaos_wait, dim3(1), dim3(1), 0, c->stream, 1u);
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
-        HIP_TRY(c, hipStreamSynchronize(pool[i]));
-        blocks[i] = us > 120.0;
+        int held = 0;   // (majority of three: one slow launch on a busy box must not cost a stream its role)
+        for (int rep = 0; rep < 3; ++rep) {
+            hipLaunchKernelGGL(k_chaos_wait, dim3(1), dim3(1), 0, pool[i], 250u);
+            const auto t0 = std::chrono::steady_clock::now();
+            hipLaunchKernelGGL(k_chaos_wait, dim3(1), dim3(1), 0, c->stream, 1u);
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+            HIP_TRY(c, hipStreamSynchronize(pool[i]));
+            held += us > 120.0;
+            if (rep == 1 && (held == 0 || held == 2)) break;
+        }
+        blocks[i] = held >= 2;
         nfree += !blocks[i];
     }
     if (knob("H2AGG_TRACE_STREAMS")) {
@@ -1168,7 +1182,7 @@ void h2agg_destroy(h2agg_ctx* c) {
     for (auto& kv : c->tables) {
         if (kv.second.d) hipFree(kv.second.d);
         if (kv.second.endo_x) hipFree(kv.second.endo_x);
-        if (kv.second.comb) hipFree(kv.second.comb);
+        kv.second.free_combs();
         if (kv.second.pre) hipFree(kv.second.pre);
     }
     if (c->h_pinned) hipHostFree(c->h_pinned);
@@ -1219,6 +1233,11 @@ int h2agg_set_stream(h2agg_ctx* c, void* hip_stream) try {
     const hipStream_t was = c->stream;
     c->stream = hip_stream ? (hipStream_t)hip_stream : c->own_stream;
     if (c->stream != was) {   // another main stream, another queue: hand the roles out again
+        // The probe launches kernels on the caller's stream and waits for them: not possible while that stream is being
+        // captured into a graph — the roles then stay as they are (H2AGG_NO_PLACE skips the probe altogether).
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hip_stream && hipStreamIsCapturing(c->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) return H2AGG_OK;
+        (void)hipGetLastError();
         HIP_TRY(c, hipDeviceSynchronize());
         TRY(place_streams(c));
     }
@@ -1571,7 +1590,7 @@ int h2agg_bases_free(h2agg_ctx* c, uint64_t handle) try {
     hipFree(it->second.d);
     if (it->second.endo_x) hipFree(it->second.endo_x);
     if (it->second.pre) hipFree(it->second.pre);
-    if (it->second.comb) hipFree(it->second.comb);
+    it->second.free_combs();
     c->tables.erase(it);
     return H2AGG_OK;
 } catch (const std::bad_alloc&) {
@@ -1631,11 +1650,7 @@ int h2agg_bases_precompute(h2agg_ctx* c, uint64_t handle, int window_bits) try {
         hipFree(t.pre);
         t.pre = nullptr;
     }
-    if (t.comb) {
-        hipFree(t.comb);
-        t.comb = nullptr;
-        t.comb_n = 0;
-    }
+    t.free_combs();
     if (hipMalloc((void**)&t.pre, (size_t)W * t.n * 64) != hipSuccess)
         return fail(c, H2AGG_ERR_NOMEM, "hipMalloc(fixed-base levels)");
     HIP_TRY(c, hipMemcpyAsync(t.pre, t.d, t.n * 64, hipMemcpyDeviceToDevice, c->stream));
@@ -1660,15 +1675,26 @@ bool comb_msm_applies(const h2agg_ctx* c, const Table& t, size_t n) {
     const bool off = !c->dbg_comb_msm;
     return !off && t.pre && !c->cfg_c && n >= 1 && n <= (size_t)COMB_MSM_MAX;
 }
-int comb_msm_run(h2agg_ctx* c, Table& t, const uint8_t* d_scalars, size_t n, size_t batch, uint8_t* d_out_jac) {
+// *done = false: the comb could not be made (no memory for it): the caller takes the bucket path, which needs none.
+int comb_msm_run(h2agg_ctx* c, Table& t, const uint8_t* d_scalars, size_t n, size_t batch, uint8_t* d_out_jac, bool* done) {
+    *done = true;
     if (!t.comb || t.comb_n < n) {
-        const size_t nb = t.n < (size_t)COMB_MSM_MAX ? t.n : (size_t)COMB_MSM_MAX;
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (t.comb) hipFree(t.comb);
-        t.comb = nullptr;
-        t.comb_n = 0;
+        // sized for what is asked (a one-point multi_exp does not pay for 256 bases' rows: 520 KiB per base), doubling so that
+        // a caller whose sizes creep up rebuilds O(log) times; everything is ordered by the context's stream, no host wait:
+        // the comb it replaces may still be read by kernels in flight and is only retired (Table::free_combs)
+        const size_t cap_n = t.n < (size_t)COMB_MSM_MAX ? t.n : (size_t)COMB_MSM_MAX;
+        size_t nb = 16;
+        while (nb < n) nb *= 2;
+        if (nb > cap_n) nb = cap_n;
         const size_t entries = nb * (size_t)COMB_WINDOWS * COMB_ROW;
-        if (hipMalloc((void**)&t.comb, entries * 64) != hipSuccess) return fail(c, H2AGG_ERR_NOMEM, "hipMalloc(table comb)");
+        uint8_t* fresh = nullptr;
+        if (hipMalloc((void**)&fresh, entries * 64) != hipSuccess) {
+            (void)hipGetLastError();
+            *done = false;
+            return H2AGG_OK;
+        }
+        if (t.comb) t.comb_retired.push_back(t.comb);
+        t.comb = fresh;
         size_t grid = (entries + SM_GROUPS - 1) / SM_GROUPS;
         const size_t cap = (size_t)c->cu_count * 16;
         if (grid > cap) grid = cap;
@@ -1691,7 +1717,11 @@ int h2agg_g1_msm_device_async(h2agg_ctx* c, uint64_t handle, const void* d_scala
     if (!d_scalars || !d_out_jac) return fail(c, H2AGG_ERR_INVALID, "null buffer");
     if (n == 0) return fail(c, H2AGG_ERR_EMPTY, "multi_exp of zero pairs (reference panics: mock/arith/ecc.rs:128)");
     if (n > it->second.n) return fail(c, H2AGG_ERR_INVALID, "more scalars than bases in the table");
-    if (comb_msm_applies(c, it->second, n)) return comb_msm_run(c, it->second, (const uint8_t*)d_scalars, n, 1, (uint8_t*)d_out_jac);
+    if (comb_msm_applies(c, it->second, n)) {
+        bool done = false;
+        TRY(comb_msm_run(c, it->second, (const uint8_t*)d_scalars, n, 1, (uint8_t*)d_out_jac, &done));
+        if (done) return H2AGG_OK;
+    }
     const uint8_t* endo = nullptr;
     TRY(table_endo(c, it->second, &endo));
     // Beyond 2^22 points the packed (index | sub-bucket) sort item no longer fits 32 bits and the sort would fall back to
@@ -1740,8 +1770,11 @@ int h2agg_g1_msm_device_batch_async(h2agg_ctx* c, uint64_t handle, const void* d
     if (n == 0 || batch == 0)
         return fail(c, H2AGG_ERR_EMPTY, "multi_exp of zero pairs (reference panics: mock/arith/ecc.rs:128)");
     if (n > it->second.n) return fail(c, H2AGG_ERR_INVALID, "more scalars than bases in the table");
-    if (comb_msm_applies(c, it->second, n))
-        return comb_msm_run(c, it->second, (const uint8_t*)d_scalars, n, batch, (uint8_t*)d_out_jac);
+    if (comb_msm_applies(c, it->second, n)) {
+        bool done = false;
+        TRY(comb_msm_run(c, it->second, (const uint8_t*)d_scalars, n, batch, (uint8_t*)d_out_jac, &done));
+        if (done) return H2AGG_OK;
+    }
     // MSMs per set of launches: the level-1 sort partitions (batch * W * NB >> sub_bits, sub_bits <= 11) must fit its
     // LDS counters, and the entry count its 32-bit offsets
     const bool use_pre = it->second.pre && !c->cfg_c;   // fixed-base levels (h2agg_bases_precompute)

@@ -205,7 +205,7 @@ struct Tape {
     static bool is_const(uint32_t r) { return !(r & (OPBIT | LAZYBIT)); }
     uint32_t record(uint32_t opcode, uint32_t a, uint32_t b) {
         a = materialize(a);
-        b = materialize(b);
+        if (opcode != TAPE_SQRN) b = materialize(b);   // (SQRN: b is an immediate count of squarings, never a register id)
         TapeOp o{(uint32_t)ops.size() | OPBIT, a, b, opcode};
         ops.push_back(o);
         chain_by_op.push_back(Chain{NONE, NONE, 0});

@@ -892,7 +892,7 @@ __global__ void __launch_bounds__(1024) k_dm_scan(const uint32_t* __restrict__ i
 
 // grid (ntile, W).  items[w * n_row + tile * DM_T1 + k], k < toff[..][ppw]: the tile's keys ordered by partition;
 // toff[(w * ntile + tile) * (ppw + 1) + p]: where partition p starts inside the tile; pcount[w * ppw + p] += its length
-template <bool WIDE>   // WIDE: 32-bit codes of k_dm_digits17 (`codes` then points at uint32_t), otherwise the 16-bit codes
+template <bool WIDE>   // WIDE: the 17-bit windows of k_dm_digits17 — 16-bit magnitude codes as usual plus one sign and one zero bit per key in bit rows behind them; otherwise the plain 16-bit codes
 __global__ void __launch_bounds__(DM_TB1) k_dm_partition(const uint16_t* __restrict__ codes, DmPlan dp,
                                                          uint32_t* __restrict__ pcount, uint32_t* __restrict__ toff,
                                                          uint32_t* __restrict__ items) {

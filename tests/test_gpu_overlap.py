@@ -31,8 +31,9 @@ def _rotate(eng, table, d_s, scratch, k):
 
 
 def test_sliced_device_msm_ragged_last_slice_every_parity(eng):
-    """n = 2^22 + r: full 2^22-point slices (c = 16, no GLV) followed by a ragged slice that gets GLV and c = 8 / 16 —
-    two different plans on adjacent slots under forced overlap (h2agg_g1_msm_device_async's slicing)."""
+    """n = 2^22 + r: h2agg_g1_msm_device_async cuts the MSM into 2^22-point slices plus a ragged one; the slices share ONE
+    bucket set (msm_run chain modes: c = 16, no GLV, every slice adds to the sums its buckets hold; bucket reduction and Horner
+    tail once, behind the last slice), at every parity of the context's tail slots."""
     rs = [1000, 1 << 15, 1 << 19]
     n_max = (1 << 22) + max(rs)
     ks, k_np = _workload(n_max, 101)
