@@ -1,16 +1,16 @@
-//! GPU-backed drop-in for `halo2_snark_aggregator_api::mock::arith::ecc::MockEccChip`.
+//! FFI + marshalling for libh2agg.so, the MI355X backend of halo2-snark-aggregator's pure-calculation context.
 //!
-//! SOURCE ONLY — never compiled in the build image (no Rust toolchain there).  Layout facts about
-//! halo2curves 0.2.1 used below (`to_repr()` = 32-byte little-endian canonical integer,
-//! `G1Affine { x, y }`, identity = (0, 0)) must be re-verified where Rust exists.
+//! SOURCE ONLY — never compiled in the build image (no Rust toolchain there).  Layout facts about halo2curves 0.2.1 used
+//! below (`to_repr()` = 32-byte little-endian canonical integer, `jacobian_coordinates()` = (x, y, z) of a `CurveExt`,
+//! identity = z == 0) must be re-verified where Rust exists.
 //!
-//! Only `multi_exp` (and, optionally, batched `scalar_mul_constant` for the instance commitment)
-//! crosses the FFI; every other method stays exactly what the reference's Mock chip does, so
-//! `AssignedPoint = C::CurveExt` is preserved and `-api / -circuit / -sdk` compile unchanged.
-use group::{Curve, Group};
-use halo2_proofs::arithmetic::{CurveAffine, FieldExt};
-use halo2_snark_aggregator_api::arith::{common::ArithCommonChip, ecc::ArithEccChip};
-use halo2_snark_aggregator_api::mock::arith::ecc::MockEccChip;
+//! How it is used: `integration/api-h2agg.patch` gives halo2-snark-aggregator-api a feature `h2agg`; under it the body of
+//! `MockEccChip::multi_exp` (mock/arith/ecc.rs:106-129) is `multi_exp_with_point_list` below.  The chip's TYPE, its
+//! associated types (`AssignedPoint = C::CurveExt`) and every other method stay the reference's, so -circuit
+//! (verify_circuit.rs:41-45,115-118) and -sdk compile untouched.
+use group::Group;
+use halo2_proofs::arithmetic::{CurveAffine, CurveExt, FieldExt};
+use std::cell::RefCell;
 use std::os::raw::{c_char, c_int};
 
 #[repr(C)]
@@ -20,44 +20,78 @@ pub struct h2agg_ctx {
 
 extern "C" {
     // include/h2agg.h
-    fn h2agg_create(device_ordinal: c_int, out: *mut *mut h2agg_ctx) -> c_int;
-    fn h2agg_destroy(ctx: *mut h2agg_ctx);
-    fn h2agg_last_error(ctx: *const h2agg_ctx) -> *const c_char;
-    fn h2agg_g1_msm(ctx: *mut h2agg_ctx, bases_aff: *const u8, scalars: *const u8, n: usize, out_jac: *mut u8) -> c_int;
-    fn h2agg_g1_msm_jac(ctx: *mut h2agg_ctx, points_jac: *const u8, scalars: *const u8, n: usize, out_jac: *mut u8) -> c_int;
-    fn h2agg_g1_batch_scalar_mul(ctx: *mut h2agg_ctx, bases_aff: *const u8, scalars: *const u8, n: usize, out_jac: *mut u8) -> c_int;
-    // page-locked marshalling buffers: for large multi_exps, serialise points / scalars straight into memory from
-    // h2agg_host_alloc instead of a Vec<u8> (the 96 B/point then cross PCIe at link rate, sliced under the compute)
-    #[allow(dead_code)]
-    fn h2agg_host_alloc(ctx: *mut h2agg_ctx, bytes: usize, out: *mut *mut u8) -> c_int;
-    #[allow(dead_code)]
-    fn h2agg_host_free(ctx: *mut h2agg_ctx, p: *mut u8) -> c_int;
+    pub fn h2agg_create(device_ordinal: c_int, out: *mut *mut h2agg_ctx) -> c_int;
+    pub fn h2agg_destroy(ctx: *mut h2agg_ctx);
+    pub fn h2agg_last_error(ctx: *const h2agg_ctx) -> *const c_char;
+    pub fn h2agg_g1_msm(ctx: *mut h2agg_ctx, bases_aff: *const u8, scalars: *const u8, n: usize, out_jac: *mut u8) -> c_int;
+    pub fn h2agg_g1_msm_jac(ctx: *mut h2agg_ctx, points_jac: *const u8, scalars: *const u8, n: usize, out_jac: *mut u8) -> c_int;
+    pub fn h2agg_g1_batch_scalar_mul(ctx: *mut h2agg_ctx, bases_aff: *const u8, scalars: *const u8, n: usize, out_jac: *mut u8) -> c_int;
+    pub fn h2agg_host_alloc(ctx: *mut h2agg_ctx, bytes: usize, out: *mut *mut u8) -> c_int;
+    pub fn h2agg_host_free(ctx: *mut h2agg_ctx, p: *mut u8) -> c_int;
 }
 
-/// Wraps the reference's own Mock chip and forwards everything to it except `multi_exp`.
-pub struct GpuEccChip<C: CurveAffine, E> {
-    host: MockEccChip<C, E>,
-    gpu: *mut h2agg_ctx, // single-thread-affine, like the reference's use of the chips
+/// One context per thread (the chips are used single-threaded, verify_circuit.rs:114-201; the SDK's rayon workers each get
+/// their own) with its page-locked marshalling buffers: points and scalars are written STRAIGHT into memory from
+/// h2agg_host_alloc, so the 128 B per pair cross PCIe at link rate, sliced under the device's compute — a pageable `Vec`
+/// costs 4.6 ms per 2^20 pairs instead of 2.9.
+pub struct Gpu {
+    pub ctx: *mut h2agg_ctx,
+    points: *mut u8,
+    scalars: *mut u8,
+    cap_pairs: usize,
 }
-
-impl<C: CurveAffine, E> Default for GpuEccChip<C, E> {
-    fn default() -> Self {
-        let mut gpu = std::ptr::null_mut();
-        let rc = unsafe { h2agg_create(0, &mut gpu) };
-        assert_eq!(rc, 0, "h2agg_create failed: a HIP device is required");
-        Self { host: MockEccChip::default(), gpu }
+impl Gpu {
+    fn new() -> Self {
+        let mut ctx = std::ptr::null_mut();
+        let rc = unsafe { h2agg_create(0, &mut ctx) };
+        assert_eq!(rc, 0, "h2agg_create failed: a HIP device is required (there is no CPU mode)");
+        Gpu { ctx, points: std::ptr::null_mut(), scalars: std::ptr::null_mut(), cap_pairs: 0 }
+    }
+    /// page-locked room for n pairs (grow-only, doubling)
+    fn reserve(&mut self, n: usize) {
+        if n <= self.cap_pairs {
+            return;
+        }
+        let cap = n.next_power_of_two().max(1024);
+        unsafe {
+            if !self.points.is_null() {
+                h2agg_host_free(self.ctx, self.points);
+                h2agg_host_free(self.ctx, self.scalars);
+            }
+            assert_eq!(h2agg_host_alloc(self.ctx, 96 * cap, &mut self.points), 0, "h2agg_host_alloc");
+            assert_eq!(h2agg_host_alloc(self.ctx, 32 * cap, &mut self.scalars), 0, "h2agg_host_alloc");
+        }
+        self.cap_pairs = cap;
     }
 }
-impl<C: CurveAffine, E> Drop for GpuEccChip<C, E> {
+impl Drop for Gpu {
     fn drop(&mut self) {
-        unsafe { h2agg_destroy(self.gpu) }
+        unsafe {
+            if !self.points.is_null() {
+                h2agg_host_free(self.ctx, self.points);
+                h2agg_host_free(self.ctx, self.scalars);
+            }
+            h2agg_destroy(self.ctx)
+        }
     }
 }
-
-fn put_fe<F: FieldExt>(dst: &mut Vec<u8>, f: &F) {
-    dst.extend_from_slice(f.to_repr().as_ref()); // 32-byte LE canonical
+thread_local! {
+    static GPU: RefCell<Option<Gpu>> = RefCell::new(None);
 }
-fn affine_bytes<C: CurveAffine>(dst: &mut Vec<u8>, p: &C) {
+/// run `f` with this thread's context (created on first use)
+pub fn with_gpu<R>(f: impl FnOnce(&mut Gpu) -> R) -> R {
+    GPU.with(|g| f(g.borrow_mut().get_or_insert_with(Gpu::new)))
+}
+
+#[inline]
+fn write_fe<F: FieldExt>(dst: *mut u8, f: &F) {
+    // 32-byte little-endian canonical integer
+    unsafe { std::ptr::copy_nonoverlapping(f.to_repr().as_ref().as_ptr(), dst, 32) }
+}
+pub fn put_fe<F: FieldExt>(dst: &mut Vec<u8>, f: &F) {
+    dst.extend_from_slice(f.to_repr().as_ref());
+}
+pub fn affine_bytes<C: CurveAffine>(dst: &mut Vec<u8>, p: &C) {
     match Option::<_>::from(p.coordinates()) {
         Some(c) => {
             let c: halo2_proofs::arithmetic::Coordinates<C> = c;
@@ -72,102 +106,111 @@ fn fe_from<F: FieldExt>(b: &[u8]) -> F {
     repr.as_mut().copy_from_slice(b);
     Option::from(F::from_repr(repr)).expect("canonical field element")
 }
-/// Jacobian (x, y, z) from the library -> C::CurveExt, via the affine point (one Fq inversion on the host,
-/// the same `to_affine` the reference performs at verify_circuit.rs:180,200).
-fn curve_from_jac<C: CurveAffine>(b: &[u8; 96]) -> C::CurveExt {
+/// Jacobian (x, y, z) from the library -> C::CurveExt, via the affine point (one Fq inversion on the host, the same
+/// `to_affine` the reference performs at verify_circuit.rs:180,200).
+pub fn curve_from_jac<C: CurveAffine>(b: &[u8; 96]) -> C::CurveExt {
     let (x, y, z): (C::Base, C::Base, C::Base) = (fe_from(&b[0..32]), fe_from(&b[32..64]), fe_from(&b[64..96]));
     if bool::from(z.is_zero()) {
         return C::CurveExt::identity();
     }
     let zi = z.invert().unwrap();
     let zi2 = zi.square();
-    C::from_xy(x * zi2, y * zi2 * zi).unwrap().to_curve()
+    C::from_xy(x * zi2, y * zi2 * zi).unwrap().into()
 }
 
-type Host<C, E> = MockEccChip<C, E>;
-type Ctx<C, E> = <Host<C, E> as ArithCommonChip>::Context;
-type Pt<C, E> = <Host<C, E> as ArithCommonChip>::AssignedValue;
-type Sc<C, E> = <Host<C, E> as ArithEccChip>::AssignedScalar;
-
-impl<C: CurveAffine, E> ArithCommonChip for GpuEccChip<C, E> {
-    type Context = Ctx<C, E>;
-    type Value = <Host<C, E> as ArithCommonChip>::Value;
-    type AssignedValue = Pt<C, E>;
-    type Error = E;
-    // element-wise group operations: forwarded to the host chip unchanged
-    fn add(&self, ctx: &mut Self::Context, a: &Pt<C, E>, b: &Pt<C, E>) -> Result<Pt<C, E>, E> {
-        self.host.add(ctx, a, b)
-    }
-    fn sub(&self, ctx: &mut Self::Context, a: &Pt<C, E>, b: &Pt<C, E>) -> Result<Pt<C, E>, E> {
-        self.host.sub(ctx, a, b)
-    }
-    fn assign_zero(&self, ctx: &mut Self::Context) -> Result<Pt<C, E>, E> {
-        self.host.assign_zero(ctx)
-    }
-    fn assign_one(&self, ctx: &mut Self::Context) -> Result<Pt<C, E>, E> {
-        self.host.assign_one(ctx)
-    }
-    fn assign_const(&self, ctx: &mut Self::Context, c: C) -> Result<Pt<C, E>, E> {
-        self.host.assign_const(ctx, c)
-    }
-    fn assign_var(&self, ctx: &mut Self::Context, v: C) -> Result<Pt<C, E>, E> {
-        self.host.assign_var(ctx, v)
-    }
-    fn to_value(&self, v: &Pt<C, E>) -> Result<C, E> {
-        self.host.to_value(v)
-    }
-    fn normalize(&self, ctx: &mut Self::Context, v: &Pt<C, E>) -> Result<Pt<C, E>, E> {
-        self.host.normalize(ctx, v)
+/// write pairs [lo, hi) into the page-locked buffers (x || y || z and the scalar, 32-byte LE canonical each)
+fn marshal_range<C: CurveAffine>(points: &[C::CurveExt], scalars: &[C::ScalarExt], lo: usize, hi: usize, pb: SendPtr, sb: SendPtr) {
+    for i in lo..hi {
+        let (x, y, z) = points[i].jacobian_coordinates();
+        unsafe {
+            write_fe(pb.0.add(96 * i), &x);
+            write_fe(pb.0.add(96 * i + 32), &y);
+            write_fe(pb.0.add(96 * i + 64), &z);
+            write_fe(sb.0.add(32 * i), &scalars[i]);
+        }
     }
 }
+#[derive(Clone, Copy)]
+struct SendPtr(*mut u8);
+unsafe impl Send for SendPtr {} // disjoint ranges of one page-locked buffer, written by scoped threads
+unsafe impl Sync for SendPtr {}
 
-impl<C: CurveAffine, E> ArithEccChip for GpuEccChip<C, E> {
-    type Point = C;
-    type AssignedPoint = Pt<C, E>;
-    type Scalar = <Host<C, E> as ArithEccChip>::Scalar;
-    type AssignedScalar = Sc<C, E>;
-    type Native = <Host<C, E> as ArithEccChip>::Native;
-    type AssignedNative = <Host<C, E> as ArithEccChip>::AssignedNative;
-    type ScalarChip = <Host<C, E> as ArithEccChip>::ScalarChip;
-    type NativeChip = <Host<C, E> as ArithEccChip>::NativeChip;
+fn run_msm<C: CurveAffine>(g: &mut Gpu, n: usize) -> C::CurveExt {
+    let mut out = [0u8; 96];
+    let rc = unsafe { h2agg_g1_msm_jac(g.ctx, g.points, g.scalars, n, out.as_mut_ptr()) };
+    if rc != 0 {
+        // H2AGG_ERR_EMPTY (3) reproduces the reference's `acc.unwrap()` panic on zero pairs
+        let msg = unsafe { std::ffi::CStr::from_ptr(h2agg_last_error(g.ctx)) };
+        panic!("h2agg_g1_msm_jac failed ({}): {:?}", rc, msg);
+    }
+    curve_from_jac::<C>(&out)
+}
 
-    // single products stay on the host chip (a kernel launch costs more than one scalar multiplication)
-    fn scalar_mul(&self, ctx: &mut Self::Context, lhs: &Sc<C, E>, rhs: &Pt<C, E>) -> Result<Pt<C, E>, E> {
-        self.host.scalar_mul(ctx, lhs, rhs)
-    }
-    fn scalar_mul_constant(&self, ctx: &mut Self::Context, lhs: &Sc<C, E>, rhs: C) -> Result<Pt<C, E>, E> {
-        self.host.scalar_mul_constant(ctx, lhs, rhs)
-    }
+/// sum_i scalars[i] * points[i]  (MockEccChip::multi_exp, mock/arith/ecc.rs:106-129, without its `point_list` side effect).
+/// The points go over as they are — projective x || y || z — and are normalised on the device (h2agg_g1_msm_jac):
+/// `batch_normalize` over 2^20 points is a third of a second on one host core, the whole MSM is ~3.6 ms from host buffers.
+pub fn multi_exp<C: CurveAffine>(points: &[C::CurveExt], scalars: &[C::ScalarExt]) -> C::CurveExt {
+    let n = points.len().min(scalars.len()); // `zip` semantics of the reference's loop
+    with_gpu(|g| {
+        g.reserve(n.max(1));
+        marshal_range::<C>(points, scalars, 0, n, SendPtr(g.points), SendPtr(g.scalars));
+        run_msm::<C>(g, n)
+    })
+}
 
-    /// mock/arith/ecc.rs:106-129 with the loop of scalar muls replaced by one GPU MSM.
-    fn multi_exp(&self, ctx: &mut Self::Context, points: Vec<Pt<C, E>>, scalars: Vec<Sc<C, E>>) -> Result<Pt<C, E>, E> {
-        // observable side effect kept: `Display for MockChipCtx` prints point_list.len()
-        ctx.point_list = points.iter().map(|x| format!("{:?}", x)).collect();
-        let n = points.len().min(scalars.len());
-        // The points go over as they are — projective x || y || z — and are normalised on the device (h2agg_g1_msm_jac):
-        // `batch_normalize` over 2^20 points is a third of a second on one host core, the whole MSM is 2 ms on the GPU.
-        // (`jacobian_coordinates()` is halo2curves' accessor for the three coordinates of a `CurveExt`.)
-        let (mut pb, mut sb) = (Vec::with_capacity(96 * n), Vec::with_capacity(32 * n));
-        for i in 0..n {
-            let (x, y, z) = points[i].jacobian_coordinates();
-            put_fe(&mut pb, &x);
-            put_fe(&mut pb, &y);
-            put_fe(&mut pb, &z);
-            put_fe(&mut sb, &scalars[i]);
-        }
-        let mut out = [0u8; 96];
-        let rc = unsafe { h2agg_g1_msm_jac(self.gpu, pb.as_ptr(), sb.as_ptr(), n, out.as_mut_ptr()) };
-        if rc != 0 {
-            // H2AGG_ERR_EMPTY (3) reproduces the reference's `acc.unwrap()` panic on zero pairs
-            let msg = unsafe { std::ffi::CStr::from_ptr(h2agg_last_error(self.gpu)) };
-            panic!("h2agg_g1_msm failed ({}): {:?}", rc, msg);
-        }
-        Ok(curve_from_jac::<C>(&out))
+/// `multi_exp` plus the reference's observable side effect: `ctx.point_list = points.map(|x| format!("{:?}", x))`
+/// (mock/arith/ecc.rs:112-116; `MockChipCtx::point_list` is a public field, `Display` prints its length).  Formatting 2^20
+/// points is 0.3-0.6 s on one core — 100x the device's work — so scoped worker threads take one contiguous chunk each:
+/// first they marshal it into the page-locked buffers (33 ms on one thread otherwise), then they format it, WHILE this
+/// thread, once every chunk is marshalled, runs the GPU call.  The strings and their order are exactly the reference's.
+/// Measured with the C++ stand-in tools/dropin_cost.cpp on the GPU box (16 cores' quota): 196 ms end to end per 2^20
+/// pairs against 336 ms in the reference's order — the list, not the multi_exp, is what a drop-in caller waits for.
+pub fn multi_exp_with_point_list<C: CurveAffine>(
+    points: &[C::CurveExt],
+    scalars: &[C::ScalarExt],
+    point_list: &mut Vec<String>,
+) -> C::CurveExt
+where
+    C::CurveExt: Sync,
+    C::ScalarExt: Sync,
+{
+    let n = points.len().min(scalars.len());
+    let workers = std::thread::available_parallelism().map(|v| v.get()).unwrap_or(1).saturating_sub(1).max(1);
+    let chunk = ((points.len() + workers - 1) / workers).max(1);
+    let nchunks = (points.len() + chunk - 1) / chunk;
+    let marshalled = std::sync::Barrier::new(nchunks + 1);
+    let mut parts: Vec<Vec<String>> = Vec::new();
+    let result = with_gpu(|g| {
+        g.reserve(n.max(1));
+        let (pb, sb) = (SendPtr(g.points), SendPtr(g.scalars));
+        std::thread::scope(|s| {
+            let handles: Vec<_> = (0..nchunks)
+                .map(|w| {
+                    let marshalled = &marshalled;
+                    s.spawn(move || {
+                        let (lo, hi) = (w * chunk, ((w + 1) * chunk).min(points.len()));
+                        marshal_range::<C>(points, scalars, lo.min(n), hi.min(n), pb, sb);
+                        marshalled.wait();
+                        points[lo..hi].iter().map(|x| format!("{:?}", x)).collect::<Vec<String>>()
+                    })
+                })
+                .collect();
+            marshalled.wait();
+            let r = run_msm::<C>(g, n); // the GPU call, under the formatting
+            parts = handles.into_iter().map(|h| h.join().expect("point_list worker")).collect();
+            r
+        })
+    });
+    point_list.clear();
+    point_list.reserve(points.len());
+    for p in parts {
+        point_list.extend(p);
     }
+    result
 }
 
 // =====================================================================================================================
-// Round 2: the entry points ABOVE multi_exp — what `calc_verify_circuit_final_pair`
+// The entry points ABOVE multi_exp — what `calc_verify_circuit_final_pair`
 // (halo2-snark-aggregator-circuit/src/verify_circuit.rs:114-201) calls — offloaded as a whole.
 // SOURCE ONLY like the rest of this file; the accessors on `VerifyingKey` / `ConstraintSystem` are the ones the reference
 // itself uses (file:line cited per field), halo2_proofs being unvendored they could not be compiled against here.
@@ -193,6 +236,17 @@ pub mod aggregate {
         pub instances: *const *const u8,
         pub instance_lens: *const u32,
     }
+    /// include/h2agg.h `h2agg_shard`: this rank's place in a sharded aggregation; `allgather` = the host's transport
+    /// (None: the context's RCCL communicator, h2agg_comm_init_rank)
+    #[repr(C)]
+    pub struct h2agg_shard {
+        pub rank: u32,
+        pub world: u32,
+        pub total_proofs: usize,
+        pub global_index: *const u32,
+        pub allgather: Option<unsafe extern "C" fn(user: *mut std::ffi::c_void, send: *const std::ffi::c_void, bytes: usize, recv: *mut std::ffi::c_void) -> c_int>,
+        pub user: *mut std::ffi::c_void,
+    }
     extern "C" {
         fn h2agg_bases_upload(ctx: *mut h2agg_ctx, bases_aff: *const u8, n: usize, handle_out: *mut u64) -> c_int;
         fn h2agg_bases_precompute(ctx: *mut h2agg_ctx, handle: u64, window_bits: c_int) -> c_int;
@@ -203,7 +257,14 @@ pub mod aggregate {
             ctx: *mut h2agg_ctx, circuits: *const h2agg_circuit_proofs, ncircuits: usize, s_g2: *const u8, g2: *const u8,
             left_aff: *mut u8, right_aff: *mut u8, lambda_out: *mut u8, pairing_ok: *mut c_int,
         ) -> c_int;
-        // one process per GPU: rank 0 makes the id, every rank joins, then one exchange per aggregation
+        // the same with the proofs sharded over ranks: both exchanges (every proof's squeeze -> the same lambda everywhere;
+        // the partial pairs -> their sum) happen inside the call
+        pub fn h2agg_verify_aggregation_sharded(
+            ctx: *mut h2agg_ctx, circuits: *const h2agg_circuit_proofs, ncircuits: usize, shard: *const h2agg_shard,
+            s_g2: *const u8, g2: *const u8, left_aff: *mut u8, right_aff: *mut u8, lambda_out: *mut u8, pairing_ok: *mut c_int,
+            advice_out: *mut u8, advice_cap: usize,
+        ) -> c_int;
+        // one process per GPU: rank 0 makes the id, every rank joins
         pub fn h2agg_comm_unique_id(out: *mut u8) -> c_int;
         pub fn h2agg_comm_init_rank(ctx: *mut h2agg_ctx, id: *const u8, rank: c_int, nranks: c_int) -> c_int;
         pub fn h2agg_allgather_add_points(ctxs: *mut *mut h2agg_ctx, nctx: c_int, partial_jac: *const u8, npts: usize, out_aff: *mut u8) -> c_int;
@@ -261,7 +322,15 @@ pub mod aggregate {
     }
 
     /// The "H2VK" description of include/h2agg.h from a halo2 verifying key: every field with the accessor the reference
-    /// reads it through.  `vk_scalar` = the value init_transcript absorbs (verify.rs:57-70).
+    /// reads it through.  `vk_scalar` = the value init_transcript absorbs (verify.rs:57-70).  FIELD ORDER (the decoder is
+    /// csrc/verifier.inc `decode_vk`; the Python encoder halo2-snark-aggregator_amd/verifier.py::encode_vk writes the same
+    /// and is round-tripped against it in tests/test_verifier_pipeline.py::test_h2vk_blob_field_order):
+    ///   magic "H2VK", version 1, k, num_advice_columns, num_instance_columns, num_challenges, degree, blinding_factors,
+    ///   advice_column_phase (bytes, padded to 4), challenge_phase (bytes, padded to 4),
+    ///   advice / instance / fixed queries (count, then (column u32, rotation i32) each),
+    ///   permutation columns (count, then (kind 0 advice | 1 fixed | 2 instance, index) each),
+    ///   fixed commitments (count, 64 B each), permutation commitments (count, 64 B each), vk_scalar (32 B),
+    ///   gates (count; per gate its polynomials as expressions), lookups (count; per lookup input then table expressions).
     pub fn serialize_vk<C: CurveAffine>(vk: &VerifyingKey<C>, k: u32, vk_scalar: C::ScalarExt) -> Vec<u8> {
         let cs = vk.cs();
         let mut o = Vec::new();

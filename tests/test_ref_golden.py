@@ -133,16 +133,29 @@ def test_primitives_against_the_reference():
     assert O.fe_to_bytes(V.FR_ROOT_OF_UNITY).hex() == g["fr_root_of_unity"] and O.fe_to_bytes(V.FR_DELTA).hex() == g["fr_delta"]
 
 
+def _normalise(g):
+    """files of the first ref_dump schema hold ONE circuit flat (circuit / vk_blob / vk_scalar / proofs at the top level); the
+    current one holds `circuits`: [...] (several circuits in one aggregation: ref_multi_*.json)"""
+    if "circuits" not in g:
+        g = dict(g)
+        g["circuits"] = [{k: g[k] for k in ("circuit", "vk_blob", "vk_scalar", "proofs") if k in g}]
+    return g
+
+
 def _circuit_inputs(g):
+    """-> [oracle CircuitProofs] in aggregation order"""
     from oracle import verifier as V
-    cs = decode_vk(bytes.fromhex(g["vk_blob"]))
     gl = bytes.fromhex(g["g_lagrange"])
     g_lagrange = [O.aff_from_bytes(gl[64 * i:64 * i + 64]) for i in range(len(gl) // 64)]
-    proofs = []
-    for pr in g["proofs"]:
-        cols = [[int.from_bytes(bytes.fromhex(c)[32 * j:32 * j + 32], "little") for j in range(len(c) // 64)] for c in pr["instances"]]
-        proofs.append(([cols], bytes.fromhex(pr["transcript"])))
-    return V.CircuitProofs(g["circuit"], cs, g_lagrange, proofs)
+    out = []
+    for c in _normalise(g)["circuits"]:
+        cs = decode_vk(bytes.fromhex(c["vk_blob"]))
+        proofs = []
+        for pr in c["proofs"]:
+            cols = [[int.from_bytes(bytes.fromhex(col)[32 * j:32 * j + 32], "little") for j in range(len(col) // 64)] for col in pr["instances"]]
+            proofs.append(([cols], bytes.fromhex(pr["transcript"])))
+        out.append(V.CircuitProofs(c["circuit"], cs, g_lagrange, proofs))
+    return out
 
 
 @needs_circuits
@@ -156,7 +169,8 @@ def check_oracle(g):
     from oracle import pairing as E
     from oracle import schema as S
     from oracle import verifier as V
-    circ = _circuit_inputs(g)
+    circs = _circuit_inputs(g)
+    g = _normalise(g)
     logs = []
 
     class Rec(P.PoseidonTranscriptRead):
@@ -170,11 +184,14 @@ def check_oracle(g):
             self.log.append(v)
             return v
 
-    left, right, _plain, commits, lam = V.verify_aggregation_proofs_in_chip(S.OracleEccChip(), [circ], make_transcript=Rec)
+    left, right, plain, commits, lam = V.verify_aggregation_proofs_in_chip(S.OracleEccChip(), circs, make_transcript=Rec)
     assert O.fe_to_bytes(lam).hex() == g["lambda"]
-    for i, pr in enumerate(g["proofs"]):                    # logs[0] is the aggregation transcript (created first)
+    all_proofs = [pr for c in g["circuits"] for pr in c["proofs"]]
+    for i, pr in enumerate(all_proofs):                     # logs[0] is the aggregation transcript (created first)
         assert [O.fe_to_bytes(v).hex() for v in logs[1 + i]] == pr["challenges"], i
     assert S.final_pair_bytes(left, right).hex() == g["w_x"] + g["w_g"]
+    if "final_pair_instances" in g:                         # verify_circuit.rs:768-804
+        assert [O.fe_to_bytes(v).hex() for v in S.final_pair_to_instances(left, right, plain)] == g["final_pair_instances"]
     assert [[O.aff_to_bytes(p).hex() for p in per] for per in commits] == g["advice_commitments"]
     fs = importlib.import_module(entry.PKG_NAME + ".fs")
     s_g2, g2 = bytes.fromhex(g["s_g2"]), bytes.fromhex(g["g2"])
@@ -204,21 +221,23 @@ def test_product_reproduces_the_reference(eng, pkg, path):
 
 def check_product(eng, g):
     ver = importlib.import_module(entry.PKG_NAME + ".verifier")
+    g = _normalise(g)
     table = eng.bases_upload(bytes.fromhex(g["g_lagrange"]))
-    vk = ver.VerifyingKey(eng, bytes.fromhex(g["vk_blob"]))
+    vks = [ver.VerifyingKey(eng, bytes.fromhex(c["vk_blob"])) for c in g["circuits"]]
     try:
-        proofs = [([bytes.fromhex(c) for c in pr["instances"]], bytes.fromhex(pr["transcript"])) for pr in g["proofs"]]
+        arg = [(vk, c["circuit"], table, [([bytes.fromhex(col) for col in pr["instances"]], bytes.fromhex(pr["transcript"])) for pr in c["proofs"]])
+               for vk, c in zip(vks, g["circuits"])]
         for backend in ("device", "host"):
             eng.transcript_configure(backend)
-            left, right, lam, ok, commits = ver.verify_aggregation(eng, [(vk, g["circuit"], table, proofs)],
-                                                                   bytes.fromhex(g["s_g2"]), bytes.fromhex(g["g2"]), with_commits=True)
+            left, right, lam, ok, commits = ver.verify_aggregation(eng, arg, bytes.fromhex(g["s_g2"]), bytes.fromhex(g["g2"]), with_commits=True)
             assert lam.hex() == g["lambda"]
             assert (left + right).hex() == g["w_x"] + g["w_g"]
             assert ok is g["pairing_ok"]
             assert [[p.hex() for p in per] for per in commits] == g["advice_commitments"]
     finally:
         eng.transcript_configure("auto")
-        vk.close()
+        for vk in vks:
+            vk.close()
         eng.bases_free(table)
 
 
@@ -279,3 +298,23 @@ def test_loader_selftest_oracle(pkg):
 @pytest.mark.gpu
 def test_loader_selftest_product(eng, pkg):
     check_product(eng, json.loads(json.dumps(oracle_made_golden())))
+
+
+def test_rust_serialize_vk_writes_the_documented_field_order():
+    """The Rust encoder (rust-shim/src/lib.rs aggregate::serialize_vk) cannot be compiled here; what CAN be held fixed is
+    the order in which it writes the H2VK fields: the same as the Python encoder's (verifier.encode_vk), which
+    test_decode_vk_inverts_encode_vk round-trips against the decoder.  (Source check, not a behavioural one.)"""
+    src = open(os.path.join(entry.PKG_DIR, "rust-shim", "src", "lib.rs")).read()
+    body = src[src.index("pub fn serialize_vk"):src.index("pub fn final_pair")]
+    order = ["0x4B56_3248", "k as usize", "num_advice_columns()", "num_instance_columns", "num_challenges()", "cs.degree()",
+             "blinding_factors()", "advice_column_phase", "challenge_phase", "advice_queries", "instance_queries", "fixed_queries",
+             "permutation.columns", "fixed_commitments()", "permutation().commitments", "vk_scalar);", "cs.gates", "cs.lookups"]
+    pos = [body.index(tok) for tok in order]
+    assert pos == sorted(pos), "serialize_vk no longer writes the fields in the order decode_vk / h2agg_vk_create read them"
+    py = open(os.path.join(entry.PKG_DIR, "verifier.py")).read()
+    pbody = py[py.index("def encode_vk"):py.index("class _CircuitProofs")]
+    porder = ["0x4B563248", "cs.k", "num_advice_columns", "num_instance_columns", "num_challenges", "cs.degree", "blinding_factors",
+              "advice_column_phase", "challenge_phase", "advice_queries", "instance_queries", "fixed_queries", "permutation_columns",
+              "fixed_commitments", "permutation_commitments", "vk_scalar", "cs.gates", "cs.lookups"]
+    ppos = [pbody.index(tok) for tok in porder]
+    assert ppos == sorted(ppos)

@@ -18,6 +18,8 @@
 //!   lambda, w_x, w_g    the aggregation challenge and the final pair (verify.rs:909-941)
 //!   advice_commitments  the fourth return value (verify.rs:852-856)
 //!   pairing_ok          multi_miller_loop + final_exponentiation on the pair (verify.rs:733-739)
+//!   final_pair_instances   final_pair_to_instances of the pair + plain instances (verify_circuit.rs:768-804)
+//!   (one file per single-circuit aggregation and one, ref_multi_add_mul_lookup.json, with BOTH circuits in one aggregation)
 //!   poseidon            State::default() words, the first three permutation outputs of the T = 9 spec on a fixed input,
 //!                       mds[0][0..3], constants.start[0][0..3]  (the Grain generator and the absent MDS re-draw)
 //!   encodings           G1Affine::to_bytes / to_repr samples for k*G, k = 1, 2, r-1, and the identity
@@ -75,68 +77,97 @@ impl<'a, T: TranscriptRead<MockEccChip<G1Affine, halo2_proofs::plonk::Error>>> T
     fn common_scalar(&mut self, c: &mut MockChipCtx, n: &MockFieldChip<Fr, halo2_proofs::plonk::Error>, s: &MockFieldChip<Fr, halo2_proofs::plonk::Error>, v: &Fr) -> Result<(), halo2_proofs::plonk::Error> { self.inner.common_scalar(c, n, s, v) }
 }
 
-fn dump_circuit<C: Circuit<Fr> + Clone>(name: &str, k: u32, circuits: Vec<(C, Vec<Vec<Vec<Fr>>>)>, template: C, out_dir: &PathBuf) {
-    let mut setup_rng = XorShiftRng::seed_from_u64(0x4832_4147);          // fixed: the dump is reproducible
-    let params = ParamsKZG::<Bn256>::setup(k, &mut setup_rng);
-    let vk: VerifyingKey<G1Affine> = keygen_vk(&params, &template).expect("keygen_vk");
-    let params_verifier: &ParamsVerifierKZG<Bn256> = params.verifier_params();
+/// One circuit's proofs, made exactly as the reference's test makes them (add_mul_test/verify_aggregation.rs:62-103).
+struct Made {
+    name: String,
+    vk: VerifyingKey<G1Affine>,
+    proofs: Vec<Vec<u8>>,
+    instances: Vec<Vec<Vec<Vec<Fr>>>>,
+}
+fn make<C: Circuit<Fr> + Clone>(name: &str, params: &ParamsKZG<Bn256>, circuits: Vec<(C, Vec<Vec<Vec<Fr>>>)>, template: C) -> Made {
+    let vk: VerifyingKey<G1Affine> = keygen_vk(params, &template).expect("keygen_vk");
     let mut proofs = vec![];
+    let mut all_instances = vec![];
     for (circuit, instances) in circuits.iter() {
-        let pk = keygen_pk(&params, keygen_vk(&params, &template).unwrap(), circuit).expect("keygen_pk");
+        let pk = keygen_pk(params, keygen_vk(params, &template).unwrap(), circuit).expect("keygen_pk");
         let mut transcript = PoseidonWrite::<Vec<u8>, G1Affine, Challenge255<G1Affine>>::init(vec![]);
         let i1: Vec<Vec<&[Fr]>> = instances.iter().map(|x| x.iter().map(|y| &y[..]).collect()).collect();
         let i2: Vec<&[&[Fr]]> = i1.iter().map(|x| &x[..]).collect();
-        create_proof::<KZGCommitmentScheme<Bn256>, ProverGWC<Bn256>, _, _, _, _>(&params, &pk, &[circuit.clone()], &i2[..], Pcg32::seed_from_u64(0), &mut transcript).expect("create_proof");
+        create_proof::<KZGCommitmentScheme<Bn256>, ProverGWC<Bn256>, _, _, _, _>(params, &pk, &[circuit.clone()], &i2[..], Pcg32::seed_from_u64(0), &mut transcript).expect("create_proof");
         proofs.push(transcript.finalize());
+        all_instances.push(instances.clone());
     }
-    // ---- the reference's replay over the Mock chips (verify_aggregation.rs:105-149)
+    Made { name: String::from(name), vk, proofs, instances: all_instances }
+}
+
+/// The reference's replay over the Mock chips (verify_aggregation.rs:105-149) of ONE aggregation holding every circuit of
+/// `made` (several circuits = the multi-circuit case of verify.rs:859-915: each circuit's squeezes enter the aggregation
+/// transcript after its proofs), dumped as ref_<file>.json:
+///   shared: k, params_bytes, g_lagrange, s_g2, g2, lambda, w_x, w_g, pairing_ok, advice_commitments (aggregation order),
+///           final_pair_instances = final_pair_to_instances(w_x, w_g, plain instances)   (verify_circuit.rs:768-804)
+///   circuits[]: circuit, vk_blob, vk_scalar, proofs[] {transcript, instances, challenges}
+fn replay_and_dump(file: &str, k: u32, params: &ParamsKZG<Bn256>, made: &[Made], out_dir: &PathBuf) {
+    let params_verifier: &ParamsVerifierKZG<Bn256> = params.verifier_params();
     let nchip = MockFieldChip::<Fr, halo2_proofs::plonk::Error>::default();
     let schip = MockFieldChip::<Fr, halo2_proofs::plonk::Error>::default();
     let pchip = MockEccChip::<G1Affine, halo2_proofs::plonk::Error>::default();
     let ctx = &mut MockChipCtx::default();
-    let logs: Vec<std::cell::RefCell<Vec<Fr>>> = (0..proofs.len() + 1).map(|_| std::cell::RefCell::new(vec![])).collect();
-    let mut list = vec![];
-    for (i, (_c, instances)) in circuits.iter().enumerate() {
-        let t = PoseidonTranscriptRead::<_, G1Affine, _, PoseidonEncode, 9usize, 8usize>::new(&proofs[i][..], ctx, &nchip, 8usize, 63usize).unwrap();
-        list.push(ProofData { instances, transcript: Recorder { inner: t, log: &logs[i] }, key: format!("p{}", i), _phantom: PhantomData });
+    let total: usize = made.iter().map(|m| m.proofs.len()).sum();
+    let logs: Vec<std::cell::RefCell<Vec<Fr>>> = (0..total + 1).map(|_| std::cell::RefCell::new(vec![])).collect();
+    let mut circuit_proofs = vec![];
+    let mut g = 0usize;
+    for m in made.iter() {
+        let mut list = vec![];
+        for i in 0..m.proofs.len() {
+            let t = PoseidonTranscriptRead::<_, G1Affine, _, PoseidonEncode, 9usize, 8usize>::new(&m.proofs[i][..], ctx, &nchip, 8usize, 63usize).unwrap();
+            list.push(ProofData { instances: &m.instances[i], transcript: Recorder { inner: t, log: &logs[g] }, key: format!("{}_p{}", m.name, i), _phantom: PhantomData });
+            g += 1;
+        }
+        circuit_proofs.push(CircuitProof { name: m.name.clone(), vk: &m.vk, params: params_verifier, proofs: list });
     }
     let empty: Vec<u8> = vec![];
-    let mut main_t = Recorder { inner: PoseidonTranscriptRead::<_, G1Affine, _, PoseidonEncode, 9usize, 8usize>::new(&empty[..], ctx, &nchip, 8usize, 63usize).unwrap(), log: &logs[proofs.len()] };
-    let (w_x, w_g, _plain, commits) = verify_aggregation_proofs_in_chip(ctx, &nchip, &schip, &pchip,
-        vec![CircuitProof { name: String::from(name), vk: &vk, params: params_verifier, proofs: list }], &mut main_t).unwrap();
+    let mut main_t = Recorder { inner: PoseidonTranscriptRead::<_, G1Affine, _, PoseidonEncode, 9usize, 8usize>::new(&empty[..], ctx, &nchip, 8usize, 63usize).unwrap(), log: &logs[total] };
+    let (w_x, w_g, plain, commits) = verify_aggregation_proofs_in_chip(ctx, &nchip, &schip, &pchip, circuit_proofs, &mut main_t).unwrap();
     let (wx, wg) = (w_x.to_affine(), w_g.to_affine());
     // verify.rs:733-739
     let s_g2_prepared = <Bn256 as MultiMillerLoop>::G2Prepared::from(params_verifier.s_g2());
     let n_g2_prepared = <Bn256 as MultiMillerLoop>::G2Prepared::from(-params_verifier.g2());
     let ok = bool::from(Bn256::multi_miller_loop(&[(&wx, &s_g2_prepared), (&wg, &n_g2_prepared)]).final_exponentiation().is_identity());
-    // ---- what the C ABI is handed
+    // the verify circuit's public inputs of this pair (halo2-snark-aggregator-circuit/src/verify_circuit.rs:768-804)
+    let fp_instances = halo2_snark_aggregator_circuit::verify_circuit::final_pair_to_instances::<G1Affine, Bn256>(&(wx, wg, plain.clone()));
     let mut params_bytes = vec![];
     params.write(&mut params_bytes).unwrap();
-    // the value init_transcript absorbs (verify.rs:57-70): blake2b("Halo2-Verify-Key") over the pinned vk, from_bytes_wide
-    let vk_scalar = {
-        let mut h = blake2b_simd::Params::new().hash_length(64).personal(b"Halo2-Verify-Key").to_state();
-        h.update(format!("{:?}", vk.pinned()).as_bytes());
-        Fr::from_bytes_wide(h.finalize().as_array())
-    };
-    let vk_blob = h2agg_sys::aggregate::serialize_vk(&vk, k, vk_scalar);
     let mut o = String::from("{\n");
-    o += &format!("  \"circuit\": \"{}\", \"k\": {}, \"nproofs\": {},\n", name, k, proofs.len());
+    o += &format!("  \"k\": {}, \"nproofs\": {},\n", k, total);
     o += &format!("  \"params_bytes\": \"{}\",\n", hex::encode(&params_bytes));
     o += &format!("  \"g_lagrange\": \"{}\",\n", params.g_lagrange().iter().map(aff64).collect::<String>());   // (Params::g_lagrange accessor of the pinned halo2_proofs)
     o += &format!("  \"s_g2\": \"{}\", \"g2\": \"{}\",\n", g2_128(&params_verifier.s_g2()), g2_128(&params_verifier.g2()));
-    o += &format!("  \"vk_blob\": \"{}\", \"vk_scalar\": \"{}\",\n", hex::encode(&vk_blob), hex_fe(&vk_scalar));
-    o += "  \"proofs\": [\n";
-    for (i, (_c, instances)) in circuits.iter().enumerate() {
-        let cols: Vec<String> = instances[0].iter().map(|col| col.iter().map(hex_fe).collect::<String>()).collect();
-        o += &format!("    {{\"transcript\": \"{}\", \"instances\": {}, \"challenges\": {}}}{}\n", hex::encode(&proofs[i]), json_list(&cols),
-            json_list(&logs[i].borrow().iter().map(hex_fe).collect::<Vec<_>>()), if i + 1 < proofs.len() { "," } else { "" });
+    o += "  \"circuits\": [\n";
+    let mut g = 0usize;
+    for (ci, m) in made.iter().enumerate() {
+        // the value init_transcript absorbs (verify.rs:57-70): blake2b("Halo2-Verify-Key") over the pinned vk, from_bytes_wide
+        let vk_scalar = {
+            let mut h = blake2b_simd::Params::new().hash_length(64).personal(b"Halo2-Verify-Key").to_state();
+            h.update(format!("{:?}", m.vk.pinned()).as_bytes());
+            Fr::from_bytes_wide(h.finalize().as_array())
+        };
+        let vk_blob = h2agg_sys::aggregate::serialize_vk(&m.vk, k, vk_scalar);
+        o += &format!("    {{\"circuit\": \"{}\", \"vk_blob\": \"{}\", \"vk_scalar\": \"{}\", \"proofs\": [\n", m.name, hex::encode(&vk_blob), hex_fe(&vk_scalar));
+        for i in 0..m.proofs.len() {
+            let cols: Vec<String> = m.instances[i][0].iter().map(|col| col.iter().map(hex_fe).collect::<String>()).collect();
+            o += &format!("      {{\"transcript\": \"{}\", \"instances\": {}, \"challenges\": {}}}{}\n", hex::encode(&m.proofs[i]), json_list(&cols),
+                json_list(&logs[g].borrow().iter().map(hex_fe).collect::<Vec<_>>()), if i + 1 < m.proofs.len() { "," } else { "" });
+            g += 1;
+        }
+        o += &format!("    ]}}{}\n", if ci + 1 < made.len() { "," } else { "" });
     }
     o += "  ],\n";
-    o += &format!("  \"lambda\": \"{}\",\n", hex_fe(logs[proofs.len()].borrow().last().unwrap()));
+    o += &format!("  \"lambda\": \"{}\",\n", hex_fe(logs[total].borrow().last().unwrap()));
     o += &format!("  \"w_x\": \"{}\", \"w_g\": \"{}\", \"pairing_ok\": {},\n", aff64(&wx), aff64(&wg), ok);
+    o += &format!("  \"final_pair_instances\": {},\n", json_list(&fp_instances.iter().map(hex_fe).collect::<Vec<_>>()));
     o += &format!("  \"advice_commitments\": [{}]\n", commits.iter().map(|per| json_list(&per.iter().map(|p| aff64(&p.to_affine())).collect::<Vec<_>>())).collect::<Vec<_>>().join(", "));
     o += "}\n";
-    fs::write(out_dir.join(format!("ref_{}.json", name)), o).unwrap();
+    fs::write(out_dir.join(format!("ref_{}.json", file)), o).unwrap();
 }
 
 fn dump_primitives(out_dir: &PathBuf) {
@@ -176,15 +207,28 @@ fn main() {
     fs::create_dir_all(&out_dir).unwrap();
     dump_primitives(&out_dir);
     // add_mul: c = 7 a^2 b^2 (verify_aggregation.rs:75-82), fixed witnesses instead of the clock-seeded ones
-    let mut rng = XorShiftRng::seed_from_u64(0xADD);
-    let add_mul: Vec<_> = (0..NPROOFS).map(|_| {
-        let (a, b) = (Fr::random(&mut rng), Fr::random(&mut rng));
-        (test_circuit_builder(a, b), vec![vec![vec![Fr::from(7) * a.square() * b.square()]]])
-    }).collect();
-    dump_circuit("test_circuit_add_mul", 10, add_mul, test_circuit_builder(Fr::zero(), Fr::zero()), &out_dir);
-    // lookup: the reference's lookup test circuit with its own instance column (lookup_test/verify_aggregation.rs:50-70), K = 6
+    let add_mul = |rng: &mut XorShiftRng| -> Vec<_> {
+        (0..NPROOFS).map(|_| {
+            let (a, b) = (Fr::random(&mut *rng), Fr::random(&mut *rng));
+            (test_circuit_builder(a, b), vec![vec![vec![Fr::from(7) * a.square() * b.square()]]])
+        }).collect()
+    };
+    // lookup: the reference's lookup test circuit with its own instance column (lookup_test/verify_aggregation.rs:50-70)
     let odd_lookup = vec![Fr::from(1), Fr::from(3), Fr::from(5), Fr::from(7), Fr::from(9)];
-    let lookup: Vec<_> = (0..NPROOFS).map(|_| (lookup_circuit_builder(), vec![vec![odd_lookup.clone()]])).collect();
-    dump_circuit("test_circuit_lookup", 6, lookup, lookup_circuit_builder(), &out_dir);
+    let lookup = || -> Vec<_> { (0..NPROOFS).map(|_| (lookup_circuit_builder(), vec![vec![odd_lookup.clone()]])).collect() };
+    let mut rng = XorShiftRng::seed_from_u64(0xADD);
+    {   // one circuit per aggregation, at the sizes the reference's own tests use (K = 10 / K = 6)
+        let p10 = ParamsKZG::<Bn256>::setup(10, &mut XorShiftRng::seed_from_u64(0x4832_4147));     // fixed: the dump is reproducible
+        replay_and_dump("test_circuit_add_mul", 10, &p10, &[make("test_circuit_add_mul", &p10, add_mul(&mut rng), test_circuit_builder(Fr::zero(), Fr::zero()))], &out_dir);
+        let p6 = ParamsKZG::<Bn256>::setup(6, &mut XorShiftRng::seed_from_u64(0x4832_4147));
+        replay_and_dump("test_circuit_lookup", 6, &p6, &[make("test_circuit_lookup", &p6, lookup(), lookup_circuit_builder())], &out_dir);
+    }
+    {   // BOTH circuits in ONE aggregation over one SRS (the multi-circuit fold of verify.rs:859-915, :924-938; lookups +
+        // several keys + the squeeze order across circuits), K = 10 for both
+        let p = ParamsKZG::<Bn256>::setup(10, &mut XorShiftRng::seed_from_u64(0x4832_4148));
+        let made = [make("test_circuit_add_mul", &p, add_mul(&mut rng), test_circuit_builder(Fr::zero(), Fr::zero())),
+                    make("test_circuit_lookup", &p, lookup(), lookup_circuit_builder())];
+        replay_and_dump("multi_add_mul_lookup", 10, &p, &made, &out_dir);
+    }
     eprintln!("wrote {}/ref_*.json — now run: python -m pytest tests/test_ref_golden.py", out_dir.display());
 }
