@@ -80,7 +80,7 @@ def csrc_sha() -> str:
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(entry.PKG_DIR, "csrc")
-    for name in ("fp.hpp", "g1.hpp", "msm_kernels.hpp", "sort_kernels.hpp", "batch_kernels.hpp"):
+    for name in ("fp.hpp", "fp_asm.inc", "g1.hpp", "msm_kernels.hpp", "sort_kernels.hpp", "batch_kernels.hpp"):
         with open(os.path.join(d, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]
@@ -111,7 +111,7 @@ def pmc_evidence(stage_name: str, log2n: int):
     if t is None:
         return None, None, "stale: kernel sources changed since %s was collected (csrc_sha %s != %s)" % (
             os.path.relpath(newest[0], ROOT), newest[1].get("csrc_sha"), csrc_sha())
-    if not (t.get("log2n") == log2n and stage_name == "msm_accumulate" and t.get("kernel") == "k_msm_accumulate"):
+    if not (t.get("log2n") == log2n and stage_name == "msm_accumulate" and t.get("kernel") in ("k_msm_accumulate", "k_msm_accumulate_lean")):
         return None, None, "PMC evidence is for a different workload"
     rel = os.path.relpath(path, ROOT)
     simds = 256 * 4
@@ -124,6 +124,7 @@ def pmc_evidence(stage_name: str, log2n: int):
             # ~5 cycles at even wave counts, not the nominal 4): what the instruction stream can reach at all
             "measured_rate_cycles_per_instruction": t.get("measured_rate_cpi"),
             "issue_frac_at_measured_rates": (t["measured_rate_cpi"] / cpi) if t.get("measured_rate_cpi") else None,
+            "kernel": t.get("kernel"),
             "source": rel + " (rocprofv3 --pmc passes of this command; instruction count, clock AND duration from the same pass)"}
     return t["bytes_per_launch"], valu, "csrc_sha " + t["csrc_sha"]
 

@@ -7,7 +7,8 @@ import torch
 import __graft_entry__ as entry
 pkg = entry.load_package(); eng = pkg.H2Agg(0)
 dev = torch.device("cuda:0")
-for lg in [int(a) for a in sys.argv[1:]] or [20, 22]:
+ORD_ONLY = "--ordinary-only" in sys.argv      # (for counter passes: only the path BASELINE.json configs[4]'s share runs on)
+for lg in [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [20, 22]:
     n = (1 << lg) - 6
     B = 16
     g = torch.Generator().manual_seed(lg)
@@ -17,7 +18,7 @@ for lg in [int(a) for a in sys.argv[1:]] or [20, 22]:
     out = torch.zeros((2, B, 96), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
     res = {}
-    for m, mode in enumerate(("ordinary", "fixed-base")):
+    for m, mode in enumerate(("ordinary",) if ORD_ONLY else ("ordinary", "fixed-base")):
         tp = 0.0
         if mode == "fixed-base":
             t0 = time.perf_counter(); eng.bases_precompute(table, 0); tp = time.perf_counter() - t0
@@ -27,6 +28,10 @@ for lg in [int(a) for a in sys.argv[1:]] or [20, 22]:
             eng.g1_msm_device_batch_async(table, d.data_ptr(), n, B, out[m].data_ptr())
         eng.synchronize()
         res[mode] = ((time.perf_counter() - t0) / 3 * 1e3, tp * 1e3)
+    if ORD_ONLY:
+        print("2^%d - 6 points x %d: ordinary %.2f ms" % (lg, B, res["ordinary"][0]), flush=True)
+        eng.bases_free(table)
+        continue
     same = eng.g1_batch_to_affine(bytes(out[0].cpu().numpy().tobytes())) == eng.g1_batch_to_affine(bytes(out[1].cpu().numpy().tobytes()))
     print("2^%d - 6 points x %d: ordinary %.2f ms | fixed-base levels %.2f ms (precompute %.0f ms) | results equal: %s"
           % (lg, B, res["ordinary"][0], res["fixed-base"][0], res["fixed-base"][1], same), flush=True)

@@ -3,7 +3,7 @@
 # never combined with other traces) for the dominant kernel.  Run on the GPU box from the repo root:
 #   tools/profile_round.sh r01_final      -> gpurun_out/<tag>_*.txt  (copy the ones to keep into profiles/)
 set -u
-tag=${1:-r03_final}
+tag=${1:-r04_final}
 root=$(pwd)
 out=$root/gpurun_out
 mkdir -p $out
@@ -21,6 +21,15 @@ for ctrs in "SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_
 done
 cd $root
 python tools/make_traffic_json.py $out/${tag} > $out/${tag}_traffic.json 2>> $out/${tag}_traffic.err
+# the per-GPU share of BASELINE.json configs[4]: 16 x 2^22-point instance MSMs over one table (bench.py aggregate.config4_share)
+cd /tmp
+for pair in "FETCH_SIZE fetch" "WRITE_SIZE write"; do
+  set -- $pair
+  rm -rf /tmp/prof_pmcb && rocprofv3 --kernel-trace --pmc $1 -d /tmp/prof_pmcb -o pmc -- python $root/tools/fixed_base_big.py 22 --ordinary-only > /dev/null 2>&1
+  python $root/tools/rocpd_summary.py /tmp/prof_pmcb/pmc_results.db > $out/${tag}_pmc_batch_$2.txt 2>&1
+done
+cd $root
+python tools/make_traffic_json.py $out/${tag} batch > $out/${tag}_batch_traffic.json 2>> $out/${tag}_traffic.err
 # batch kernels at n = 2^22 (HBM roofline rows)
 cd /tmp && rm -rf /tmp/prof_b && rocprofv3 --kernel-trace --stats -d /tmp/prof_b -o b -- python $root/tools/batch_roofline.py run > /dev/null 2>&1
 python $root/tools/rocpd_summary.py /tmp/prof_b/b_results.db > $out/${tag}_batch_kernel_stats.txt 2>&1
@@ -33,8 +42,10 @@ cd $root
 # the from-bytes pipeline (h2agg_verify_aggregation) on both sponge backends + its phase split
 python tools/pipeline_time.py 4 16 64 > $out/${tag}_pipeline_time.txt 2>&1
 H2AGG_TRACE_PHASES=1 H2AGG_TRANSCRIPT=host python tools/pipeline_time.py 4 16 64 2>&1 | grep "phases" | awk 'NR%9==3' > $out/${tag}_pipeline_phases.txt
+# kernel timeline of one evaluation (limb-parallel Horner chain)
+bash tools/eval_trace.sh > /dev/null 2>&1; cp $out/eval_trace/eval_timeline.txt $out/${tag}_eval_timeline.txt 2>/dev/null
 # the default bench line itself (no profiler attached); it reads the PMC evidence just collected from profiles/
-mkdir -p profiles && cp $out/${tag}_traffic.json profiles/
+mkdir -p profiles && cp $out/${tag}_traffic.json $out/${tag}_batch_traffic.json profiles/
 python bench.py > $out/${tag}_bench_default.json 2> $out/${tag}_bench_default.err
 # everything to keep goes to profiles/ in ONE step (commit once):
 mkdir -p profiles && cp $out/${tag}_* profiles/

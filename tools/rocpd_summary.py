@@ -18,7 +18,7 @@ def main(path):
     # Kernels that run on a TAIL stream beside the next MSM's k_msm_accumulate (three VALU-saturating waves per SIMD): their
     # traced duration is mostly waiting for wave slots / issue cycles, not work.  They are marked '*' and left out of the
     # percentage column; `min_us` is what they take when they get the machine (DESIGN.md section 5 has the alone figures).
-    waiting = ("k_msm_accumulate_big", "k_msm_big_combine", "k_msm_final", "k_msm_reduce2d_parts", "k_msm_reduce2d_window",
+    waiting = ("k_msm_accumulate_big", "k_msm_accumulate_fix", "k_msm_big_combine", "k_msm_final", "k_msm_final_lp", "k_msm_reduce2d_parts", "k_msm_reduce2d_window",
                "k_msm_reduce_segments", "k_msm_window_sum", "k_msm_bucket_combine")
     def waits(name):
         base = name.split("(")[0].replace("void ", "").replace("h2agg::", "").split("<")[0]
