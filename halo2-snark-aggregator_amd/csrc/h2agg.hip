@@ -130,7 +130,7 @@ struct h2agg_ctx {
 
     // schema-layer scratch (grow-only; the schema API is synchronous, one evaluation is in flight per context):
     // the Fr register file, the uploaded staging block, per-side MSM scalars / Montgomery bases, pinned staging
-    DevBuf sch_regs, sch_in, sch_scalars[2], sch_bases[2];
+    DevBuf sch_regs, sch_in, sch_scalars[2], sch_bases[2], sch_endo;
     uint8_t* h_stage = nullptr;
     size_t h_stage_cap = 0;
     const void* sch_owner = nullptr;  // the schema whose tape sch_regs reflects
@@ -152,7 +152,7 @@ struct h2agg_ctx {
     int comm_rank = 0, comm_size = 0;
 
     // h2agg_debug_configure: test hooks read per call (chained host-buffer slices, comb route, plan cache)
-    int dbg_pcie_slices = 0, dbg_pcie_glv = 0, dbg_pcie_chain = 1, dbg_comb_msm = 1, dbg_plan_cache = 1;
+    int dbg_pcie_slices = 0, dbg_pcie_glv = 0, dbg_pcie_chain = 1, dbg_comb_msm = 1, dbg_plan_cache = 1, dbg_small_sort = 1, dbg_eval_split = 1;
     // tuning
     int cfg_c = 0, cfg_seg = 0, cfg_big = 0, cfg_sub_bits = 0, cfg_tile = 0;
     int cfg_glv = 0;   // 0 = auto, 1 = on, -1 = off
@@ -541,9 +541,23 @@ int join_tails(h2agg_ctx* c) {
 // d_endo_x: beta * x per base (Table::endo_x) or nullptr = compute it here when the plan uses GLV.
 // pre: fixed-base levels of the table (then d_bases is ignored): plain c-bit digits of ALL positions into one bucket set
 // per MSM, bases looked up at level w; no Horner chain.
+// can two MSMs of n_total points in all run as one split MSM (below)?  The one-launch sort's range, nothing forced.
+bool msm_split_ok(const h2agg_ctx* c, size_t n_total) {
+    if (!c->dbg_small_sort || n_total < 2 || n_total > (size_t)SMALL_SORT_N) return false;
+    if (c->cfg_no_stage || c->cfg_stage_l1 || c->cfg_sub_bits || c->cfg_tile || c->chain) return false;
+    const MsmPlan p = make_plan(c, n_total, 2);
+    return p.NB <= (uint32_t)SMALL_SORT_NB;
+}
+
+// split != 0: TWO MSMs over the disjoint parts [0, split) and [split, n_base) of one table (scalars laid out alike), as one
+// set of launches with 2 W windows; results: XYZZ at c->d_res_xyzz and c->d_res_xyzz + XYZZ_BYTES.  Only for sizes the
+// one-launch sort takes (msm_split_ok): the evaluation's two multi_exps.  When the plan (make_plan(c, n_base, 2)) uses GLV,
+// d_scalars are glv_decompose() words and d_endo_x is given (k_eval_prep wrote both); the tail stays on the context's
+// stream — nothing follows that it could hide under, and a stream hand-over costs 10-20 us each way.
 int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size_t n_base, uint8_t* d_out_jac,
-            uint32_t batch = 1, const uint8_t* d_endo_x = nullptr, const PreTable* pre = nullptr) {
-    const size_t n = n_base * batch;   // scalars
+            uint32_t batch = 1, const uint8_t* d_endo_x = nullptr, const PreTable* pre = nullptr, uint32_t split = 0) {
+    if (split) batch = 2;
+    const size_t n = split ? n_base : n_base * batch;   // scalars
     crumb((uintptr_t)__builtin_return_address(0), ((uint64_t)batch << 40) | n_base);
     if (n >= ((size_t)1 << 30)) return fail(c, H2AGG_ERR_INVALID, "n must be < 2^30");
     const int chain = (pre || batch != 1) ? CHAIN_OFF : c->chain;
@@ -591,7 +605,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     sp.SB = 1u << sp.sub_bits;
     sp.ppw = p.NB >> sp.sub_bits;
     sp.PW = WT * sp.ppw;
-    if (batch > 1) {
+    if (batch > 1 && !split) {
         sp.n_base = (uint32_t)n_base;
         sp.W1 = (uint32_t)W1;
     }
@@ -612,7 +626,8 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     static const int par4_env = knob("H2AGG_PAR4") ? atoi(knob("H2AGG_PAR4")) : 0;
     // measured: wins up to 16384 segments (c <= 13; also a 2^20-point MSM with 32-bucket segments in throughput mode,
     // where 1 024 waves of 94-addition chains would otherwise outlast the step), loses to the extra work above
-    const bool par4 = par4_env ? par4_env > 0 : nseg_total <= 16384;
+    // (a split MSM is two such MSMs side by side, each within the range)
+    const bool par4 = par4_env ? par4_env > 0 : nseg_total <= (split ? 32768u : 16384u);
     // pmeta words: pcount [PW] | pstart [PW + 1] | pcursor [PW] | bin_count [SIZE_BINS] | bin_start [SIZE_BINS + 1] |
     //              bin_cursor [SIZE_BINS] | big-bucket counters [2], each padded by 64 words
     constexpr uint32_t META_PW = DM_MAX_PW;   // (the digit-major path has up to 16 x 512 partitions)
@@ -641,6 +656,11 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     const bool dm = !dm_env_off && !c->cfg_no_dm && !c->cfg_no_stage && !c->cfg_stage_l1 && !c->cfg_sub_bits && !c->cfg_tile && !pre && batch == 1 &&
                     (p.c == 16 || dm17) && dm_row >= ((size_t)1 << 16) && dm_row <= ((size_t)1 << 22);
     const uint32_t dm_nwin = p.glv ? 8u : (dm17 ? 15u : 16u);
+    // the one-launch sort of small MSMs (sort_kernels.hpp k_small_sort); a forced sort configuration keeps its own kernels
+    static const bool small_env_off = knob("H2AGG_SMALL_SORT") && !strcmp(knob("H2AGG_SMALL_SORT"), "0");
+    const bool small_sort = !small_env_off && c->dbg_small_sort && !pre && !dm && n <= (size_t)SMALL_SORT_N && p.NB <= (uint32_t)SMALL_SORT_NB &&
+                            !c->cfg_no_stage && !c->cfg_stage_l1 && !c->cfg_sub_bits && !c->cfg_tile;
+    if (split && (!small_sort || split >= n_base)) return fail(c, H2AGG_ERR_INVALID, "split MSM outside the one-launch sort's range");
     DmPlan dp{};
     if (dm) {
         const size_t n = dm_row;   // (shadows the point count inside this block)
@@ -685,6 +705,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     uint16_t* item_sub = (uint16_t*)c->item_sub.p;
     uint32_t* entries = (uint32_t*)c->entries[sq].p;
     c->d_res_xyzz = (uint8_t*)c->small.p + 1024 + 144 * par;   // each tail slot has its own XYZZ result
+    if (split) c->d_res_xyzz = (uint8_t*)c->small.p + 2048 + 2 * 144 * par;   // ... or its own two
     uint8_t* buckets = (uint8_t*)c->buckets[par].p;
     uint8_t* segsum = (uint8_t*)c->segsum[par].p;
     uint8_t* wsum = (uint8_t*)c->wsum[par].p;
@@ -726,14 +747,22 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     }
     debug_sync(1);
     chaos_wait(4, st);
-    if (p.glv) {  // k = k1 + lambda*k2: the sort below reads the decomposed words instead of the scalars
+    if (p.glv && !split) {  // k = k1 + lambda*k2: the sort below reads the decomposed words instead of the scalars
+        // (a split MSM's caller hands over the decomposed words and the beta * x column: k_eval_prep)
         TRY(ensure(c, c->glv_buf, n * 32));
         StageTimer t(c, ST_PART_COUNT);
         hipLaunchKernelGGL(k_glv_decompose, dim3(grid_for(c, n)), dim3(BLOCK), 0, st, d_scalars, n,
                            (uint8_t*)c->glv_buf.p, c->d_flags);
         d_scalars = (const uint8_t*)c->glv_buf.p;
     }
-    if (dm) {
+    if (small_sort) {
+        StageTimer t(c, ST_BUCKET_SORT);
+        // (the length-ordering pass below counts into the scratch words: then they are cleared as a whole)
+        if (nent >= ((size_t)1 << 16) && !meta_was_clean) HIP_TRY(c, hipMemsetAsync(meta, 0, M_WORDS * 4, st));
+        hipLaunchKernelGGL(k_small_sort, dim3(WT), dim3(SMALL_SORT_TB), 0, st, d_scalars, (uint32_t)n, p.c, Wd,
+                           (batch > 1 && !split) ? (uint32_t)n_base : 0u, split, p.glv, p.NB, hist, offs, entries, c->d_flags,
+                           big_count);
+    } else if (dm) {
         const uint32_t PW = dm_nwin * dp.ppw;
         {
             StageTimer t(c, ST_PART_COUNT);
@@ -890,7 +919,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     // Buckets longer than `big` (skewed scalars; none for uniform ones, where the two launches below only find empty lists):
     // with alternating sort outputs they leave the bulk stream and go in front of the bucket reduction on the tail stream,
     // followed by the zeroing of this slot's counters for the MSM after next.
-    const bool tail_big = altbuf && c->overlap_level >= 2 && lpb == 1 && (chain == CHAIN_OFF || chain == CHAIN_LAST);
+    const bool tail_big = altbuf && c->overlap_level >= 2 && lpb == 1 && (chain == CHAIN_OFF || chain == CHAIN_LAST) && !split;
     const uint32_t resume = (chain == CHAIN_MID || chain == CHAIN_LAST) ? 1u : 0u;
     const bool chain_open = chain == CHAIN_FIRST || chain == CHAIN_MID;   // no tail yet
     // (no bucket can hold more keys than its bucket set receives: a multi_exp of a dozen points skips the two launches,
@@ -952,8 +981,8 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         ticket = (uint32_t*)tk.p;
     }
     debug_sync(4);
-    const bool tails_off_stream = c->tail_overlap && c->overlap_level >= 2;
-    const bool final_off_stream = c->tail_overlap;
+    const bool tails_off_stream = c->tail_overlap && c->overlap_level >= 2 && !split;
+    const bool final_off_stream = c->tail_overlap && !split;
     uint8_t* const res_xyzz = c->d_res_xyzz;
     if (tails_off_stream) HIP_TRY(c, hipEventRecord(c->ev_bulk[par], st));
     // `from`: the stream the accumulation ran on.  behind_sort: the tail stream also waits for c->ev_sortdone.
@@ -1019,10 +1048,10 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
             // the Horner chain in the limb-parallel form (lp_kernels.hpp): 1.2 instead of 2.0 us per doubling
             static const bool final_par4 = knob("H2AGG_FINAL") && !strcmp(knob("H2AGG_FINAL"), "par4");
             if (final_par4)
-                hipLaunchKernelGGL(k_msm_final, dim3(batch), dim3(64), 0, ts, wsum, p.c, W1, batch > 1 ? (uint8_t*)nullptr : res_xyzz,
+                hipLaunchKernelGGL(k_msm_final, dim3(batch), dim3(64), 0, ts, wsum, p.c, W1, (batch > 1 && !split) ? (uint8_t*)nullptr : res_xyzz,
                                    d_out_jac);
             else
-                hipLaunchKernelGGL(k_msm_final_lp, dim3(batch), dim3(64), 0, ts, wsum, p.c, W1, batch > 1 ? (uint8_t*)nullptr : res_xyzz,
+                hipLaunchKernelGGL(k_msm_final_lp, dim3(batch), dim3(64), 0, ts, wsum, p.c, W1, (batch > 1 && !split) ? (uint8_t*)nullptr : res_xyzz,
                                    d_out_jac);
         }
         if (final_off_stream) {
@@ -1094,7 +1123,7 @@ int h2agg_create(int device_ordinal, h2agg_ctx** out) try {
     snprintf(buf, sizeof buf, "h2agg 0.1 %s cu=%d", prop.gcnArchName, c->cu_count);
     c->desc = buf;
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipHostMalloc((void**)&c->h_pinned, 4096) != hipSuccess || ensure(c, c->small, 2048) != H2AGG_OK) {
+        hipHostMalloc((void**)&c->h_pinned, 4096) != hipSuccess || ensure(c, c->small, 4096) != H2AGG_OK) {
         h2agg_destroy(c);
         return H2AGG_ERR_HIP;
     }
@@ -1149,7 +1178,7 @@ int h2agg_create(int device_ordinal, h2agg_ctx** out) try {
     c->d_flags = (uint32_t*)c->small.p;
     c->d_res_xyzz = (uint8_t*)c->small.p + 1024;   // 144 B
     c->d_res_jac = (uint8_t*)c->small.p + 256;   // 96 B
-    hipMemset(c->small.p, 0, 2048);
+    hipMemset(c->small.p, 0, 4096);
     if (place_streams(c) != H2AGG_OK) {
         h2agg_destroy(c);
         return H2AGG_ERR_HIP;
@@ -1183,7 +1212,7 @@ void h2agg_destroy(h2agg_ctx* c) {
                       &c->offs[0], &c->offs[1], &c->pmeta[0], &c->pmeta[1], &c->item_idx, &c->item_sub, &c->order[0], &c->order[1], &c->entries[0], &c->entries[1],
                       &c->r2d_ticket[0], &c->r2d_ticket[1], &c->r2d_ticket[2], &c->buckets[0], &c->buckets[1], &c->buckets[2], &c->segsum[0], &c->segsum[1], &c->segsum[2],
                       &c->wsum[0], &c->wsum[1], &c->wsum[2], &c->big_list[0], &c->big_list[1], &c->big_keys[0], &c->big_keys[1], &c->big_part[0], &c->big_part[1], &c->fix_list[0], &c->fix_list[1], &c->glv_buf, &c->parts, &c->small, &c->endo_buf, &c->tile_counts,
-                      &c->sch_regs, &c->sch_in, &c->sch_scalars[0], &c->sch_scalars[1], &c->sch_bases[0], &c->sch_bases[1]};
+                      &c->sch_regs, &c->sch_in, &c->sch_scalars[0], &c->sch_scalars[1], &c->sch_bases[0], &c->sch_bases[1], &c->sch_endo};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);
     for (auto& kv : c->tables) {
@@ -2127,6 +2156,8 @@ int h2agg_debug_configure(h2agg_ctx* c, const char* key, int value) try {
     else if (k == "pcie_chain") c->dbg_pcie_chain = value;
     else if (k == "comb_msm") c->dbg_comb_msm = value;
     else if (k == "plan_cache") c->dbg_plan_cache = value;
+    else if (k == "small_sort") c->dbg_small_sort = value;   // 0: small MSMs take the packed two-level sort again
+    else if (k == "eval_split") c->dbg_eval_split = value;   // 0: an evaluation's two multi_exps are two MSMs again
     else return fail(c, H2AGG_ERR_INVALID, "h2agg_debug_configure: unknown key " + k);
     return H2AGG_OK;
 } catch (...) {

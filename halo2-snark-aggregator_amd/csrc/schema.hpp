@@ -138,6 +138,37 @@ __global__ void __launch_bounds__(BLOCK) k_tape_gather(const uint32_t* __restric
     fp_store<FrParams>(out + 32 * (size_t)i, fp_from_mont<FrParams>(reg_load(regs, idx[i])));
 }
 
+// Everything between the tape and the sort of an evaluation's (split) multi_exp in ONE launch — it was four (gather,
+// bases to Montgomery form, beta * x, GLV decomposition: ~6 us of launch latency each on the evaluation's critical path):
+// pair i = (canonical affine point pts[i], tape register idx[i]).  GLV: scal_out receives the glv_decompose() words,
+// endo_x the beta * x column; otherwise the canonical scalars.
+template <bool GLV>
+__global__ void __launch_bounds__(BLOCK) k_eval_prep(const uint32_t* __restrict__ regs, const uint32_t* __restrict__ idx,
+                                                     const uint8_t* __restrict__ pts, uint32_t n,
+                                                     uint8_t* __restrict__ scal_out, uint8_t* __restrict__ bases_out,
+                                                     uint8_t* __restrict__ endo_x, uint32_t* flags) {
+    const uint32_t i = blockIdx.x * BLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t bad = 0;
+    const G1Affine p = affine_load_canonical(pts + 64 * (size_t)i, bad);
+    affine_store(bases_out + 64 * (size_t)i, p);
+    U256 k;
+    fp_pack<FrParams>(k.w, fp_from_mont<FrParams>(reg_load(regs, idx[i])));
+    if (GLV) {
+        Fq beta;
+#pragma unroll
+        for (int j = 0; j < NL; ++j) beta.l[j] = GlvConst::BETA_MONT[j];
+        fp_store<FqParams>(endo_x + 32 * (size_t)i, FQ_MUL(p.x, beta));
+        U256 d;
+        bad |= !glv_decompose(k, d);
+        k = d;
+    }
+    if (bad) atomicOr(flags, FLAG_NONCANONICAL);
+    uint4* q = reinterpret_cast<uint4*>(scal_out + 32 * (size_t)i);
+    q[0] = make_uint4(k.w[0], k.w[1], k.w[2], k.w[3]);
+    q[1] = make_uint4(k.w[4], k.w[5], k.w[6], k.w[7]);
+}
+
 // ------------------------------------------------------------------ host side: AST + symbolic evaluation
 // The tape is a DAG of Fr operations; its run time on the device is (number of dependency levels) x (one barrier +
 // one multiplication latency), so the recorder keeps it SHALLOW.  Field arithmetic is exact, hence any association

@@ -686,6 +686,100 @@ __global__ void __launch_bounds__(TB) k_bucket_sort_staged(const uint32_t* __res
     }
 }
 
+// ------------------------------------------------------------------ small MSMs: the whole sort in ONE launch
+// n <= SMALL_SORT_N scalars (the two multi_exps of an evaluation: ~350 and ~1 400 points at 4 proofs; short instance columns):
+// the four launches of the packed path (count, scan, scatter, bucket sort) are 35-55 us of mostly launch latency for ~50 K keys,
+// on the critical path of an evaluation that is 0.65 ms in all.  Here a workgroup owns ONE window of ONE MSM: it recodes its MSM's
+// scalars (twice: count, place — 32 B each, out of L2), counts its window's digits in LDS, scans, and writes `entries`
+// bucket-ordered into the window's fixed slice, plus hist / offs: exactly what k_bucket_sort* leave behind.
+// Three shapes: one MSM (n_base = split = 0); a batch over one table (scalar j -> MSM j / n_base, base j % n_base); a SPLIT
+// table — two MSMs over the disjoint parts [0, split) and [split, n) of one table, windows numbered q * W + w like a batch's
+// (the evaluation's w_x and w_g sides as one set of launches).
+constexpr int SMALL_SORT_N = 16384;
+constexpr int SMALL_SORT_TB = 1024;
+constexpr int SMALL_SORT_NB = 8192;    // buckets of a window kept in LDS (c <= 14)
+__global__ void __launch_bounds__(SMALL_SORT_TB) k_small_sort(const uint8_t* __restrict__ scalars, uint32_t n, int c, int W,
+                                                              uint32_t n_base, uint32_t split, bool glv, uint32_t NB,
+                                                              uint32_t* __restrict__ hist, uint32_t* __restrict__ offs,
+                                                              uint32_t* __restrict__ entries, uint32_t* flags,
+                                                              uint32_t* __restrict__ counters) {
+    // the accumulation's list counters (over-long buckets, fix-ups: three words) start at zero; nothing else of the sort's
+    // scratch words is read on this path, so the memset of all of them (~5 us in front of the sort) is not needed
+    if (blockIdx.x == 0 && threadIdx.x < 4) counters[threadIdx.x] = 0;
+    __shared__ uint32_t h[SMALL_SORT_NB];
+    __shared__ uint32_t scan[SMALL_SORT_TB];
+    constexpr uint32_t TB = SMALL_SORT_TB;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t win = blockIdx.x, q = win / (uint32_t)W, w = win - q * (uint32_t)W;
+    const uint32_t g = glv ? 2u : 1u;
+    uint32_t lo, hi, bofs, start;   // this MSM's scalars [lo, hi), what to subtract for the base index, the window's slice of `entries`
+    if (split) {
+        lo = q ? split : 0u;
+        hi = q ? n : split;
+        bofs = 0;
+        start = q ? ((uint32_t)W * split + w * (n - split)) * g : w * split * g;
+    } else if (n_base) {
+        lo = q * n_base;
+        hi = lo + n_base;
+        bofs = lo;
+        start = win * n_base * g;
+    } else {
+        lo = 0;
+        hi = n;
+        bofs = 0;
+        start = win * n * g;
+    }
+    for (uint32_t b = tid; b < NB; b += TB) h[b] = 0;
+    __syncthreads();
+    uint32_t bad = 0;
+    for (uint32_t i = lo + tid; i < hi; i += TB) {
+        const U256 s = u256_load(scalars + 32 * (size_t)i);
+        if (!glv && w == 0) bad |= !u256_is_canonical_fr(s);   // (GLV words were range-checked by k_glv_decompose)
+        msm_for_each_digit(s, c, W, glv, [&](int ww, uint32_t b, bool, bool) {
+            if ((uint32_t)ww == w) atomicAdd(&h[b], 1u);
+        });
+    }
+    if (bad) atomicOr(flags, FLAG_NONCANONICAL);
+    __syncthreads();
+    const uint32_t per = (NB + TB - 1) / TB;
+    const uint32_t first = tid * per;
+    uint32_t mine = 0;
+    for (uint32_t j = 0; j < per; ++j)
+        if (first + j < NB) mine += h[first + j];
+    scan[tid] = mine;
+    __syncthreads();
+#pragma unroll 1
+    for (uint32_t d = 1; d < TB; d <<= 1) {
+        const uint32_t t = (tid >= d) ? scan[tid - d] : 0u;
+        __syncthreads();
+        scan[tid] += t;
+        __syncthreads();
+    }
+    uint32_t run = scan[tid] - mine;
+    const uint32_t key0 = win * NB;
+    for (uint32_t j = 0; j < per; ++j) {
+        const uint32_t b = first + j;
+        if (b < NB) {
+            const uint32_t cnt = h[b];
+            hist[key0 + b] = cnt;
+            offs[key0 + b] = start + run;
+            h[b] = run;   // becomes the cursor
+            run += cnt;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = lo + tid; i < hi; i += TB) {
+        const U256 s = u256_load(scalars + 32 * (size_t)i);
+        const uint32_t bi = i - bofs;
+        msm_for_each_digit(s, c, W, glv, [&](int ww, uint32_t b, bool neg, bool endo) {
+            if ((uint32_t)ww == w) {
+                const uint32_t r = atomicAdd(&h[b], 1u);
+                entries[start + r] = bi | (endo ? ENT_ENDO : 0u) | (neg ? ENT_NEG : 0u);
+            }
+        });
+    }
+}
+
 // ------------------------------------------------------------------ digit-major sort (plain MSM, c = 16, n <= 2^22)
 // Round-2 PMC (profiles/r02_final_pmc_*.txt): the packed level 1 above is bound by its 16.7 M scattered 4-byte stores (one L2
 // request each, 278 MB written for 64 MB of payload) and by occupancy (a thread recodes a whole 256-bit scalar per digit walk,

@@ -461,7 +461,9 @@ int h2agg_msm_configure_sort(h2agg_ctx* ctx, int sub_bits, int tile);
  *   key "pcie_slices" n   cut h2agg_g1_msm's host buffers into n slices (0 = automatic)
  *       "pcie_glv" -1|0|1 GLV for those slices (0 = automatic)       "pcie_chain" 0|1  slices share one bucket set (default 1)
  *       "comb_msm" 0|1    small MSMs over tables with fixed-base levels take the comb (default 1)
- *       "plan_cache" 0|1  h2agg_verify_aggregation keeps the recording of a call shape (default 1) */
+ *       "plan_cache" 0|1  h2agg_verify_aggregation keeps the recording of a call shape (default 1)
+ *       "small_sort" 0|1  MSMs of <= 16384 scalars sort in one launch (default 1; 0 = the packed two-level sort)
+ *       "eval_split" 0|1  the two multi_exps of an evaluation run as one set of launches (default 1) */
 int h2agg_debug_configure(h2agg_ctx* ctx, const char* key, int value);
 /* Overlap the latency-shaped tail of one MSM (enable = 1: the Horner kernel, one wave; 2: bucket reduction + window
  * sums + Horner; 3: as 2, and the bucket accumulation itself leaves the context's stream, so that the NEXT MSM's sort runs

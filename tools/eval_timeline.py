@@ -7,8 +7,15 @@ for f in glob.glob(sys.argv[1] + "/**/*kernel_trace.csv", recursive=True):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]),
                      r["Kernel_Name"].split("(")[0].replace("h2agg::", "").replace("void ", ""), r.get("Queue_Id", "?")))
 rows.sort()
+for f in glob.glob(sys.argv[1] + "/**/*memory_copy_trace.csv", recursive=True):   # (with --memory-copy-trace: the copies too)
+    for r in csv.DictReader(open(f)):
+        rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "copy " + r.get("Direction", "?"), "-"))
+rows.sort()
 i1 = max(i for i, r in enumerate(rows) if r[2].startswith("k_eval_tail_affine2"))
-i0 = max(i for i, r in enumerate(rows[:i1]) if r[2].startswith("k_tape_load_consts"))
+if "--last" in sys.argv:    # the N launches in front of the last evaluation's end (a whole h2agg_verify_aggregation call)
+    i0 = max(0, i1 - int(sys.argv[sys.argv.index("--last") + 1]))
+else:
+    i0 = max(i for i, r in enumerate(rows[:i1]) if r[2].startswith("k_tape_load_consts"))
 t0 = rows[i0][0]
 busy_end, idle = t0, 0
 for s, e, n, q in rows[i0:i1 + 1]:
