@@ -307,7 +307,10 @@ int choose_window(size_t n, bool glv) {
     // though they leave most buckets empty; (2) only widths whose top window is as sparse as the others
     // (GLV 8/13/16, plain 8/15/16: top window as sparse as the others) avoid a dense top window that costs as much as all the
     // other windows together.
-    if (glv) return n <= ((size_t)1 << 10) ? 8 : n <= ((size_t)1 << 14) ? 13 : 16;
+    // (re-measured in round 4 behind the one-launch sort and the limb-parallel Horner chain, profiles/r04_sweeps.txt section 5:
+    // 8 bits up to 2^12 points — 2^11: 0.457 against 0.490 ms alone, 0.194 against 0.250 back to back; 2^12 equal; the two
+    // multi_exps of an evaluation of 4 proofs, 1 750 pairs: 0.68 against 0.76 ms)
+    if (glv) return n <= ((size_t)1 << 12) ? 8 : n <= ((size_t)1 << 14) ? 13 : 16;
     // 17 bits from 1.5 * 2^20 points on: a bucket costs 2 general additions (~2.8 insertions) whatever the point count, a
     // window's insertions grow with it — 15 windows of 2^16 buckets overtake 16 of 2^15 between 2^20 points (+0.7 %) and
     // 2^21 (+5.7 %; 2^22: +8.8 %, profiles/r03_sweeps.txt section 11)
@@ -941,9 +944,19 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
                            acc_out, lpb, resume);
         // (in a chain only the last slice folds the slice slots, and it folds ALL of them: a bucket that is over-long in this
         // slice may hold ordinary partial sums from earlier ones)
-        if (lpb > 1 && !chain_open)
-            hipLaunchKernelGGL(k_msm_bucket_combine, dim3((p.NBT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, bs,
-                               (const uint8_t*)acc_out, hist, p.NBT, chain ? 0xffffffffu : p.big, lpb, buckets);
+        if (lpb > 1 && !chain_open) {
+            const uint32_t cbig = chain ? 0xffffffffu : p.big;
+            const unsigned gq = (unsigned)(((size_t)p.NBT * 2 * lpb + BLOCK - 1) / BLOCK);
+            if (p.NBT > 16384u || (lpb != 2 && lpb != 4 && lpb != 8))   // many buckets: one lane each (work, not latency)
+                hipLaunchKernelGGL(k_msm_bucket_combine, dim3((p.NBT + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, bs,
+                                   (const uint8_t*)acc_out, hist, p.NBT, cbig, lpb, buckets);
+            else if (lpb == 8)
+                hipLaunchKernelGGL(k_msm_bucket_combine_par4<8>, dim3(gq), dim3(BLOCK), 0, bs, (const uint8_t*)acc_out, hist, p.NBT, cbig, buckets);
+            else if (lpb == 4)
+                hipLaunchKernelGGL(k_msm_bucket_combine_par4<4>, dim3(gq), dim3(BLOCK), 0, bs, (const uint8_t*)acc_out, hist, p.NBT, cbig, buckets);
+            else
+                hipLaunchKernelGGL(k_msm_bucket_combine_par4<2>, dim3(gq), dim3(BLOCK), 0, bs, (const uint8_t*)acc_out, hist, p.NBT, cbig, buckets);
+        }
     };
     if (!tail_big) {
         big_kernels(st);

@@ -872,6 +872,43 @@ __global__ void __launch_bounds__(BLOCK, 2) k_msm_reduce_segments_par4(const uin
     if (a != 0 && !running.is_identity()) acc = xyzz_add_par4(acc, xyzz_mul_small_par4(running, a));
     if ((threadIdx.x & 3) == 0) xyzz_store(segsum + XYZZ_BYTES * (size_t)t, acc);
 }
+// k_msm_bucket_combine for few buckets (small MSMs with narrow windows: 4 096 buckets of 8 slice sums at 4 proofs): the seven
+// one-lane additions in a row were 47 us at the head of an evaluation's tail.  Here a bucket has 2 LPB lanes — LPB / 2 groups of
+// four, each adds two slice sums cooperatively, then the groups fold as a tree (the partner's sum comes over by lane shuffle):
+// log2(LPB) cooperative additions deep.
+FP_INLINE G1XYZZ xyzz_shfl_down(const G1XYZZ& v, int delta) {
+    G1XYZZ o;
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        o.x.l[i] = (uint32_t)__shfl_down((int)v.x.l[i], delta, 64);
+        o.y.l[i] = (uint32_t)__shfl_down((int)v.y.l[i], delta, 64);
+        o.zz.l[i] = (uint32_t)__shfl_down((int)v.zz.l[i], delta, 64);
+        o.zzz.l[i] = (uint32_t)__shfl_down((int)v.zzz.l[i], delta, 64);
+    }
+    return o;
+}
+template <int LPB>
+__global__ void __launch_bounds__(BLOCK) k_msm_bucket_combine_par4(const uint8_t* __restrict__ parts,
+                                                                   const uint32_t* __restrict__ hist, uint32_t nbt,
+                                                                   uint32_t big, uint8_t* __restrict__ buckets) {
+    static_assert(LPB == 2 || LPB == 4 || LPB == 8, "lanes per bucket of the accumulation");
+    constexpr int LANES = 2 * LPB;
+    const uint32_t t = blockIdx.x * BLOCK + threadIdx.x;
+    const uint32_t key = t / LANES, l = t % LANES, q = l >> 2;
+    if (key >= nbt) return;                                  // (whole lane groups: BLOCK is a multiple of LANES)
+    const bool whole = hist[key] <= big;                     // an over-long bucket's sum is in slot 0 (chunk path)
+    const uint8_t* P = parts + XYZZ_BYTES * (size_t)key * LPB;
+    G1XYZZ a = (whole || q == 0) ? xyzz_load(P + XYZZ_BYTES * (size_t)(2 * q)) : G1XYZZ::identity();
+    G1XYZZ acc = xyzz_add_par4(a, whole ? xyzz_load(P + XYZZ_BYTES * (size_t)(2 * q + 1)) : G1XYZZ::identity());
+#pragma unroll
+    for (int stride = 4; stride < LANES; stride <<= 1) {
+        G1XYZZ o = xyzz_shfl_down(acc, stride);
+        if (l % (2 * stride) >= 4) o = G1XYZZ::identity();   // not a receiver at this level (its partner may be another bucket's lane)
+        acc = xyzz_add_par4(acc, o);
+    }
+    if (l == 0) xyzz_store(buckets + XYZZ_BYTES * (size_t)key, acc);
+}
+
 constexpr int PAR4_GROUPS = 128, PAR4_THREADS = 4 * PAR4_GROUPS;
 // sum of one (replicated) point per group over a PAR4_THREADS workgroup; the result is replicated in group 0
 __device__ __noinline__ G1XYZZ block_sum_xyzz_par4(G1XYZZ v, uint32_t* lds) {
