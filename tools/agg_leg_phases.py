@@ -8,7 +8,7 @@ import __graft_entry__ as entry
 from bench import gen_scalars
 ap = argparse.ArgumentParser()
 ap.add_argument("--proofs", type=int, default=4); ap.add_argument("--instance-log2", type=int, default=17)
-ap.add_argument("--reps", type=int, default=20); ap.add_argument("--commitments", type=int, default=300)
+ap.add_argument("--reps", type=int, default=20); ap.add_argument("--lpb", type=int, default=0); ap.add_argument("--seg", type=int, default=0); ap.add_argument("--commitments", type=int, default=300)
 args = ap.parse_args()
 pkg = entry.load_package(); eng = pkg.H2Agg(0); eng.msm_set_tail_overlap(2)
 agg = importlib.import_module(entry.PKG_NAME + ".aggregate"); mo = importlib.import_module(entry.PKG_NAME + ".multiopen")
@@ -35,6 +35,8 @@ for rep in range(args.reps + 2):
     if rep == 2: T.clear()
     t00 = time.perf_counter()
     t0 = time.perf_counter(); b = backend.new_builder(); tick("new_builder", t0)
+    if args.lpb: eng.msm_configure_lanes_per_bucket(args.lpb)
+    if args.seg: eng.msm_configure(reduce_segment=args.seg)
     t0 = time.perf_counter(); eng.g1_msm_device_batch_async(g_table, d_inst.data_ptr(), n_inst, args.proofs, d_out.data_ptr()); tick("instance_msm_launch", t0)
     t0 = time.perf_counter()
     proofs, first = [], []
