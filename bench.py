@@ -530,7 +530,8 @@ def full_pipeline_leg(pkg, eng, args, g_table):
         plan_stats = eng.verify_plan_stats()
         conc = None
         try:
-            conc = [concurrent(args.agg_proofs)] + ([concurrent(n_more)] if n_more else [])
+            # (4 threads: the figure of earlier rounds; 8: where one GPU's rate peaks on a 16-core quota, tools/pipeline_concurrent.py)
+            conc = [concurrent(args.agg_proofs), concurrent(args.agg_proofs, nthreads=8)] + ([concurrent(n_more)] if n_more else [])
         except SystemExit:
             raise
         except Exception as ex:      # noqa: BLE001 - a throughput extra must never cost the latency figures

@@ -692,13 +692,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
                                    : p.NB == (uint32_t)(R2D_ROWS * R2D<8>::COLS) ? (size_t)WT * (R2D<8>::THREADS + 2) : 0;
         TRY(ensure(c, c->segsum[par], (nseg_total > r2d_records ? nseg_total : r2d_records) * XYZZ_BYTES));
     }
-    // few windows of many segments (a batch of fixed-base MSMs): several workgroups per window in the window sums
-    static const bool final_par4_knob = knob("H2AGG_FINAL") && !strcmp(knob("H2AGG_FINAL"), "par4");
-    uint32_t wparts = 1;
-    if (par4 && !final_par4_knob && (pre || (p.NB != (uint32_t)(R2D_ROWS * R2D<7>::COLS) && p.NB != (uint32_t)(R2D_ROWS * R2D<8>::COLS))))   // (not the 2-D reduction's plans)
-        while (wparts < 4 && p.spw / wparts >= 1024 && WT * wparts < 64) wparts *= 2;   // (measured: 4 x 2^17-point columns 749 -> 689 us at 4, 654 at 8 — but the Horner kernel's additions take the difference back at 8)
-    if (knob("H2AGG_WPARTS")) wparts = (uint32_t)atoi(knob("H2AGG_WPARTS"));
-    TRY(ensure(c, c->wsum[par], (size_t)WT * wparts * XYZZ_BYTES));
+    TRY(ensure(c, c->wsum[par], (size_t)WT * XYZZ_BYTES));
     const size_t max_slots = nent / BIG_CHUNK + nent / ((size_t)p.big + 1) + 2;   // chunks of over-long buckets
     const size_t max_keys = nent / ((size_t)p.big + 1) + 2;
     TRY(ensure(c, c->big_list[sq], max_slots * 12));
@@ -1052,7 +1046,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
             if (!(dbg_skip & 2)) {
                 StageTimer t(c, ST_WINDOW_SUM, ts);
                 if (par4)
-                    hipLaunchKernelGGL(k_msm_window_sum_par4, dim3(WT, wparts), dim3(PAR4_THREADS), 0, ts, segsum, p.spw, wsum);
+                    hipLaunchKernelGGL(k_msm_window_sum_par4, dim3(WT), dim3(PAR4_THREADS), 0, ts, segsum, p.spw, wsum);
                 else
                     hipLaunchKernelGGL(k_msm_window_sum, dim3(WT), dim3(BLOCK), 0, ts, segsum, p.spw, wsum);
             }
@@ -1065,12 +1059,13 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         if (!(dbg_skip & 4)) {
             StageTimer t(c, ST_FINAL, ts);
             // the Horner chain in the limb-parallel form (lp_kernels.hpp): 1.2 instead of 2.0 us per doubling
-            if (final_par4_knob)
+            static const bool final_par4 = knob("H2AGG_FINAL") && !strcmp(knob("H2AGG_FINAL"), "par4");
+            if (final_par4)
                 hipLaunchKernelGGL(k_msm_final, dim3(batch), dim3(64), 0, ts, wsum, p.c, W1, (batch > 1 && !split) ? (uint8_t*)nullptr : res_xyzz,
                                    d_out_jac);
             else
                 hipLaunchKernelGGL(k_msm_final_lp, dim3(batch), dim3(64), 0, ts, wsum, p.c, W1, (batch > 1 && !split) ? (uint8_t*)nullptr : res_xyzz,
-                                   d_out_jac, (int)wparts);
+                                   d_out_jac);
         }
         if (final_off_stream) {
             HIP_TRY(c, hipEventRecord(c->ev_tail[par], c->tail_streams[par]));

@@ -268,28 +268,20 @@ FP_INLINE LpPoint lp_add_points(const LpPoint& a, const LpPoint& b, const LpCons
 // result = sum_w 2^(c w) wsum[w]  (Horner, top window first): k_msm_final's job (msm_kernels.hpp) in the limb-parallel form,
 // one wave per MSM of a batch.  Writes the XYZZ value (coordinates brought under 2 p: on-device consumers assume g1.hpp's bounds)
 // and the canonical Jacobian encoding of the C ABI.
-// parts: partial sums per window (k_msm_window_sum_par4's gridDim.y; window w of this MSM = sum of wsum[(.. + w) * parts + y]).
 __global__ void __launch_bounds__(64) k_msm_final_lp(const uint8_t* __restrict__ wsum, int c, int W, uint8_t* __restrict__ out_xyzz,
-                                                     uint8_t* __restrict__ out_jac, int parts) {
+                                                     uint8_t* __restrict__ out_jac) {
     __shared__ uint32_t sm[4 * 64];
-    wsum += XYZZ_BYTES * (size_t)blockIdx.x * W * parts;
+    wsum += XYZZ_BYTES * (size_t)blockIdx.x * W;
     if (out_xyzz) out_xyzz += XYZZ_BYTES * (size_t)blockIdx.x;
     if (out_jac) out_jac += 96 * (size_t)blockIdx.x;
     __builtin_amdgcn_s_setprio(3);
     const LpConst k = lp_const();
-    auto window = [&](int w) {
-        const uint8_t* p = wsum + XYZZ_BYTES * (size_t)w * parts;
-        LpPoint v = lp_load(p, k);
-#pragma unroll 1
-        for (int y = 1; y < parts; ++y) v = lp_add_points(v, lp_load(p + XYZZ_BYTES * (size_t)y, k), k, sm);
-        return v;
-    };
-    LpPoint acc = window(W - 1);
+    LpPoint acc = lp_load(wsum + XYZZ_BYTES * (size_t)(W - 1), k);
 #pragma unroll 1
     for (int w = W - 2; w >= 0; --w) {
 #pragma unroll 1
         for (int i = 0; i < c; ++i) acc = lp_double(acc, k);
-        acc = lp_add_points(acc, window(w), k, sm);
+        acc = lp_add_points(acc, lp_load(wsum + XYZZ_BYTES * (size_t)w, k), k, sm);
     }
     G1XYZZ g = lp_to_single(acc, sm);
     if (threadIdx.x == 0) {

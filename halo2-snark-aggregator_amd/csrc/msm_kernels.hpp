@@ -925,19 +925,16 @@ __device__ __noinline__ G1XYZZ block_sum_xyzz_par4(G1XYZZ v, uint32_t* lds) {
     }
     return v;
 }
-// gridDim.y workgroups share a window (few windows of many segments — a batch of fixed-base MSMs is ONE window of 4 096
-// segments per MSM: a lone workgroup walked 32 additions per group before its tree); workgroup (w, y) leaves its partial sum at
-// wsum[w * gridDim.y + y], the Horner kernel adds a window's partials as it loads the window.
 __global__ void __launch_bounds__(PAR4_THREADS) k_msm_window_sum_par4(const uint8_t* __restrict__ segsum, uint32_t spw,
                                                                       uint8_t* __restrict__ wsum) {
     __shared__ uint32_t lds[XYZZ_WORDS * BLOCK];
     const uint32_t w = blockIdx.x;
     G1XYZZ acc = G1XYZZ::identity();
 #pragma unroll 1
-    for (uint32_t s = blockIdx.y * PAR4_GROUPS + (threadIdx.x >> 2); s < spw; s += PAR4_GROUPS * gridDim.y)
+    for (uint32_t s = threadIdx.x >> 2; s < spw; s += PAR4_GROUPS)
         acc = xyzz_add_par4(acc, xyzz_load(segsum + XYZZ_BYTES * ((size_t)w * spw + s)));
     G1XYZZ tot = block_sum_xyzz_par4(acc, lds);
-    if (threadIdx.x == 0) xyzz_store(wsum + XYZZ_BYTES * ((size_t)w * gridDim.y + blockIdx.y), tot);
+    if (threadIdx.x == 0) xyzz_store(wsum + XYZZ_BYTES * (size_t)w, tot);
 }
 
 // result = sum_w 2^(c*w) * wsum[w]  (Horner, top window first).  Writes the XYZZ value (Montgomery, for

@@ -207,7 +207,7 @@ int main() {
         const int c = cW / 100, W = cW % 100;
         uint8_t *dj1, *dj2, *dx1, *dx2; hipMalloc(&dj1, 96); hipMalloc(&dj2, 96); hipMalloc(&dx1, XYZZ_BYTES); hipMalloc(&dx2, XYZZ_BYTES);
         hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, 0, dm + XYZZ_BYTES * 3, c, W, dx1, dj1);
-        hipLaunchKernelGGL(k_msm_final_lp, dim3(1), dim3(64), 0, 0, dm + XYZZ_BYTES * 3, c, W, dx2, dj2, 1);
+        hipLaunchKernelGGL(k_msm_final_lp, dim3(1), dim3(64), 0, 0, dm + XYZZ_BYTES * 3, c, W, dx2, dj2);
         uint8_t j1[96], j2[96];
         hipMemcpy(j1, dj1, 96, hipMemcpyDeviceToHost); hipMemcpy(j2, dj2, 96, hipMemcpyDeviceToHost);
         // time both
@@ -215,7 +215,7 @@ int main() {
         hipEventRecord(e0);
         for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k_msm_final, dim3(1), dim3(64), 0, 0, dm + XYZZ_BYTES * 3, c, W, dx1, dj1);
         hipEventRecord(e1);
-        for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k_msm_final_lp, dim3(1), dim3(64), 0, 0, dm + XYZZ_BYTES * 3, c, W, dx2, dj2, 1);
+        for (int r = 0; r < 5; ++r) hipLaunchKernelGGL(k_msm_final_lp, dim3(1), dim3(64), 0, 0, dm + XYZZ_BYTES * 3, c, W, dx2, dj2);
         hipEventRecord(e2); hipEventSynchronize(e2);
         float t1, t2; hipEventElapsedTime(&t1, e0, e1); hipEventElapsedTime(&t2, e1, e2);
         const int same = memcmp(j1, j2, 96) == 0;

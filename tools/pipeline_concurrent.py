@@ -45,7 +45,7 @@ class Worker:
         self.calls = r
 
 
-for nthreads in (1, 2, 3, 4):
+for nthreads in ([int(a) for a in sys.argv[3].split(",")] if len(sys.argv) > 3 else (1, 2, 3, 4)):
     ws = [Worker(i) for i in range(nthreads)]
     t0 = time.perf_counter()
     ts = [threading.Thread(target=w.run, args=(t0 + secs,)) for w in ws]

@@ -44,6 +44,8 @@ python tools/pipeline_time.py 4 16 64 > $out/${tag}_pipeline_time.txt 2>&1
 H2AGG_TRACE_PHASES=1 H2AGG_TRANSCRIPT=host python tools/pipeline_time.py 4 16 64 2>&1 | grep "phases" | awk 'NR%9==3' > $out/${tag}_pipeline_phases.txt
 # kernel timeline of one evaluation (limb-parallel Horner chain)
 bash tools/eval_trace.sh > /dev/null 2>&1; cp $out/eval_trace/eval_timeline.txt $out/${tag}_eval_timeline.txt 2>/dev/null
+# host-side phases of bench.py's aggregate leg (instance-column MSMs under the schema build, then the evaluation)
+(python tools/agg_leg_phases.py --proofs 4; python tools/agg_leg_phases.py --proofs 16) > $out/${tag}_agg_leg_phases.txt 2>/dev/null
 # the default bench line itself (no profiler attached); it reads the PMC evidence just collected from profiles/
 mkdir -p profiles && cp $out/${tag}_traffic.json $out/${tag}_batch_traffic.json profiles/
 python bench.py > $out/${tag}_bench_default.json 2> $out/${tag}_bench_default.err
