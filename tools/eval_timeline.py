@@ -11,7 +11,8 @@ for f in glob.glob(sys.argv[1] + "/**/*memory_copy_trace.csv", recursive=True): 
     for r in csv.DictReader(open(f)):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "copy " + r.get("Direction", "?"), "-"))
 rows.sort()
-i1 = max(i for i, r in enumerate(rows) if r[2].startswith("k_eval_tail_affine2"))
+end_marker = sys.argv[sys.argv.index("--end") + 1] if "--end" in sys.argv else "k_eval_tail_affine2"   # the launch the window ends at
+i1 = max(i for i, r in enumerate(rows) if r[2].startswith(end_marker))
 if "--last" in sys.argv:    # the N launches in front of the last evaluation's end (a whole h2agg_verify_aggregation call)
     i0 = max(0, i1 - int(sys.argv[sys.argv.index("--last") + 1]))
 else:
