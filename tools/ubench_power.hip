@@ -33,6 +33,23 @@ __global__ void __launch_bounds__(256) k_fma(uint64_t* out, uint32_t seed, int i
     }
     out[blockIdx.x * 256 + threadIdx.x] = __double_as_longlong(c0 + c1 + c2 + c3 + c4 + c5 + c6 + c7);
 }
+// the integer matrix cores for comparison (no field arithmetic is built on them: see DESIGN.md section 9): 32 x 32 x 16 int8 MACs
+typedef int v16i __attribute__((ext_vector_type(16)));
+__global__ void __launch_bounds__(256) k_mfma(uint64_t* out, uint32_t seed, int iters) {
+    long a = 0x0102030405060708L * (long)(seed | 1) + threadIdx.x * 0x0101010101010101L, b = 0x1112131415161718L ^ (long)threadIdx.x * 0x0303030303030303L;
+    v16i c0 = {0}, c1 = {0}, c2 = {0}, c3 = {0};
+    for (int it = 0; it < iters; ++it) {
+        c0 = __builtin_amdgcn_mfma_i32_32x32x16_i8(a, b, c0, 0, 0, 0);
+        c1 = __builtin_amdgcn_mfma_i32_32x32x16_i8(b, a, c1, 0, 0, 0);
+        c2 = __builtin_amdgcn_mfma_i32_32x32x16_i8(a, a, c2, 0, 0, 0);
+        c3 = __builtin_amdgcn_mfma_i32_32x32x16_i8(b, b, c3, 0, 0, 0);
+        a ^= (long)c0[0];   // (operands keep changing)
+        b += 0x0101010101010101L;
+    }
+    uint64_t acc = 0;
+    for (int i = 0; i < 16; ++i) acc += (uint32_t)(c0[i] ^ c1[i] ^ c2[i] ^ c3[i]);
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
 int main() {
     hipDeviceProp_t prop;
     hipGetDeviceProperties(&prop, 0);
@@ -53,6 +70,18 @@ int main() {
             float ms = 0;
             hipEventElapsedTime(&ms, e0, e1);
             const double insts = (double)blocks * 4 * 32.0 * iters;   // wave64 instructions
+            if (which == 0 && round == 0) {   // once: the matrix cores, 4 MFMAs per iteration
+                hipEventRecord(e0);
+                const int mi = iters / 4;
+                hipLaunchKernelGGL(k_mfma, dim3(blocks), dim3(256), 0, 0, out, 3u, mi);
+                hipEventRecord(e1);
+                hipEventSynchronize(e1);
+                float mms = 0;
+                hipEventElapsedTime(&mms, e0, e1);
+                const double mf = (double)blocks * 4 * 4.0 * mi;
+                printf("v_mfma_i32_32x32x16_i8  %.0f ms   %.2f G wave-instructions/s = %.0f T int8 MACs/s = %.2e 1-bit products/s  (v_mad_u64_u32 at 29 x 29 bits: see below x 64 x 841)\n",
+                       mms, mf / (mms * 1e-3) / 1e9, mf * 16384.0 / (mms * 1e-3) / 1e12, mf * 16384.0 * 64.0 / (mms * 1e-3));
+            }
             printf("%s  %.0f ms   %.1f G wave-instructions/s   %.2f cycles per instruction per SIMD at 2.4 GHz\n", which ? "v_fma_f64    " : "v_mad_u64_u32",
                    ms, insts / (ms * 1e-3) / 1e9, 2.4e9 * (ms * 1e-3) / (insts / (prop.multiProcessorCount * 4)));
         }
