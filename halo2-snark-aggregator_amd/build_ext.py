@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libh2agg.so")
 SOURCES = ["h2agg.hip"]
-DEPS = ["h2agg.hip", "pairing.hpp", "fp.hpp", "fp_asm.inc", "g1.hpp", "batch_kernels.hpp", "sort_kernels.hpp", "msm_kernels.hpp", "scalar_mul_kernels.hpp", "lp_kernels.hpp", "schema.hpp", "schema_api.inc", "comm.inc", "transcript.inc", "verifier.inc", "poseidon_kernels.hpp", "poseidon_host.hpp", "poseidon_sponge_host.hpp", "poseidon_ifma_host.hpp", "../../include/h2agg.h"]
+DEPS = ["h2agg.hip", "pairing.hpp", "fp.hpp", "fp_asm.inc", "g1.hpp", "batch_kernels.hpp", "sort_kernels.hpp", "fb_sort_kernels.hpp", "msm_kernels.hpp", "scalar_mul_kernels.hpp", "lp_kernels.hpp", "schema.hpp", "schema_api.inc", "comm.inc", "transcript.inc", "verifier.inc", "poseidon_kernels.hpp", "poseidon_host.hpp", "poseidon_sponge_host.hpp", "poseidon_ifma_host.hpp", "../../include/h2agg.h"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-Wno-unused-value"]
 
 

@@ -1,0 +1,337 @@
+// Sort for MSMs over a table with fixed-base levels at c = 20 (h2agg_bases_precompute on 2^18 .. 2^22-point tables: the
+// g_lagrange of BASELINE.json configs[4], assign_instance_commitment verify.rs:601-603,623-640).
+//
+// With levels 2^(20 w) P_i stored for w < 13, ALL 13 signed 20-bit digits of a scalar land in ONE set of 2^19 buckets: 13
+// insertions per scalar instead of the 15 of the ordinary path at c = 17, one bucket reduction per MSM, no doubling chain.  A
+// bucket entry then names (level, point): 26 bits at 2^22 points, which the packed item of sort_kernels.hpp (sub-bucket | sign |
+// index in 32 bits) cannot carry next to 9 sub-bucket bits — round 4 measured the two-array fallback at 2.1 ms of sort per
+// 2^22-point MSM and refused such tables.  Here the item only travels INSIDE a tile, so it names its scalar tile-locally:
+//
+//   level 1   k_fb_partition: a workgroup takes a tile of 2048 SCALARS (not keys of one window: all levels share the bucket
+//             space, so nothing separates them), recodes each into 13 digits in registers and orders the tile's 26 624 keys by
+//             partition (top 11 bits of the bucket) in 104 KiB of LDS: one returning LDS atomic per key; the tile goes back
+//             coalesced with its table of 2049 partition offsets.  item = low slot bits : 8 (10) | sign | level : 4 | scalar : 11
+//   level 2   k_fb_bucket_sort: one workgroup per partition (256 buckets) collects its ~13-key run from every tile and orders
+//             it by (bucket, LEVEL) in LDS — 3 328 counters, one atomic per key — then writes entries[] / hist[] / offs[] of its
+//             buckets.  entry = sign << 31 | level * n_level + point.
+//
+// Level order inside a bucket is deliberate: the lanes of the accumulation start together and walk their ~104-entry runs at
+// the same pace, so at any moment most of the chip gathers from the same one or two levels (256 MiB each at 2^22 points: what
+// the Infinity Cache holds) instead of from all 3.5 GiB at random.
+#pragma once
+#include "sort_kernels.hpp"
+
+namespace h2agg {
+
+constexpr int FB_C = 20;                       // window bits of the big-table levels
+constexpr int FB_W = 13;                       // ceil(255 / 20) digit positions = levels
+constexpr uint32_t FB_NB = 1u << (FB_C - 1);   // buckets of the one bucket set
+constexpr int FB_T = 2048;                     // scalars per level-1 tile
+constexpr int FB_TB1 = 1024;                   // level-1 threads (two scalars each)
+constexpr int FB_SUB_BITS = 8;                 // low bucket bits resolved in level 2
+constexpr uint32_t FB_SB = 1u << FB_SUB_BITS;
+constexpr uint32_t FB_PPW = FB_NB >> FB_SUB_BITS;   // 2048 partitions
+// The top digit has 14 bits (254 = 12 * 20 + 14): dropped into the same buckets it would put n / 2^14 extra entries into each
+// of the lowest 2^14 — 3.7 x the mean run, on lanes that then outlast the launch.  It gets bucket slots of its own instead:
+// value m of the top digit, scalar i -> slot FB_NB + 16 (m - 1) + (i & 15); k_fb_fold (msm_kernels.hpp) adds the sixteen parts
+// of value m into bucket m - 1 in front of the reduction (same weight).  Sixteen, because the slot count then is 3 x 2^18: the
+// accumulation runs one lane per slot, longest runs first, on 4 096 wave slots (256 CUs x 4 SIMDs x 4 waves of 128 VGPRs) of
+// 64 lanes — three full rounds, and a slot's three waves (long, medium, short) add up alike.  With 2^19 + 2^16 slots (2.25
+// rounds) the last quarter round ran on a quarter-full chip: 70.6 instead of 64.5 ns per million insertions.
+constexpr int FB_XPARTS_LOG = 4;
+constexpr uint32_t FB_XB = (1u << 14) << FB_XPARTS_LOG;          // extra slots (2^18)
+constexpr uint32_t FB_NBT = FB_NB + FB_XB;                        // bucket slots the accumulation walks
+// partitions of the extra slots are four times as wide (1024 slots, one level: 1024 counters in level 2 against 256 x 13) so
+// that their runs in a level-1 tile stay at 8 keys
+constexpr int FB_XSUB_BITS = 10;
+constexpr uint32_t FB_XSB = 1u << FB_XSUB_BITS;
+constexpr uint32_t FB_NPART = FB_PPW + (FB_XB >> FB_XSUB_BITS);   // 2048 + 256 partitions
+constexpr int FB_KEYS1 = FB_T * FB_W;          // keys of a tile (26 624)
+constexpr int FB_MAX_TILES = 2048;             // n <= 2^22
+constexpr int FB_TB2 = 1024;                   // level-2 threads
+constexpr int FB_PER2 = 30;                    // keys per thread staged in LDS by level 2
+constexpr int FB_STAGE = FB_PER2 * FB_TB2;     // 30 720 keys (120 KiB): the mean partition holds 13 n / 2048 <= 26 624
+constexpr uint32_t FB_KEYS2 = FB_SB * FB_W;    // level-2 counters: (bucket, level)
+
+// exclusive scan of v[0 .. cnt) in LDS (cnt <= 4 * blockDim.x, blockDim.x = 1024), total -> v[cnt]; ws: 17 words of LDS
+FP_INLINE void fb_block_scan(uint32_t* v, uint32_t cnt, uint32_t* ws) {
+    __syncthreads();
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    uint32_t x[4], sum = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        x[j] = (4 * tid + j < cnt) ? v[4 * tid + j] : 0u;
+        sum += x[j];
+    }
+    const uint32_t inc = dm_wave_scan_incl(sum, lane);
+    if (lane == 63) ws[wave] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t k = 0; k < wave; ++k) base += ws[k];
+    uint32_t off = base + inc - sum;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (4 * tid + j <= cnt) v[4 * tid + j] = off;
+        off += x[j];
+    }
+    if (4 * tid + 4 == cnt) v[cnt] = off;   // cnt = 4 * blockDim.x: the total has no thread of its own
+    __syncthreads();
+}
+
+// the 13 signed 20-bit digits of a canonical scalar: f(w, bucket, neg) for every non-zero one.  r < 2^254: the top digit
+// (bits 240 .. 253 + carry) never exceeds 2^19, so nothing is carried out.
+template <class F>
+FP_INLINE void fb_for_each_digit(const U256& s, F&& f) {
+    uint32_t carry = 0;
+#pragma unroll
+    for (int w = 0; w < FB_W; ++w) {
+        const int pos = FB_C * w, wd = pos >> 5, sh = pos & 31;
+        uint32_t v = s.w[wd] >> sh;
+        if (sh > 32 - FB_C && wd + 1 < 8) v |= s.w[wd + 1] << (32 - sh);
+        const uint32_t raw = (v & ((1u << FB_C) - 1u)) + carry;
+        const bool neg = raw > (1u << (FB_C - 1));
+        carry = neg ? 1u : 0u;
+        const uint32_t mag = neg ? (1u << FB_C) - raw : raw;
+        f(w, mag - 1u, neg, mag != 0);
+    }
+}
+// digit w of the tile's scalar `local`: its partition, and the low bits of its bucket slot inside the partition (the top
+// digit's own slots: above)
+FP_INLINE uint32_t fb_part(int w, uint32_t bkt) {
+    return w == FB_W - 1 ? FB_PPW + (bkt >> (FB_XSUB_BITS - FB_XPARTS_LOG)) : bkt >> FB_SUB_BITS;
+}
+FP_INLINE uint32_t fb_sub(int w, uint32_t bkt, uint32_t local) {
+    return w == FB_W - 1 ? ((bkt << FB_XPARTS_LOG) + (local & ((1u << FB_XPARTS_LOG) - 1u))) & (FB_XSB - 1u) : bkt & (FB_SB - 1u);
+}
+
+// grid: ceil(n / FB_T) tiles.  items[tile * FB_KEYS1 + k], k < toff[tile][FB_PPW]: the tile's keys ordered by partition;
+// toff[tile * (FB_NPART + 1) + p]: where partition p starts inside the tile; pcount[p] += its length
+__global__ void __launch_bounds__(FB_TB1) k_fb_partition(const uint8_t* __restrict__ scalars, uint32_t n,
+                                                         uint32_t* __restrict__ pcount, uint32_t* __restrict__ toff,
+                                                         uint32_t* __restrict__ items, uint32_t* flags) {
+    SORT_PRIO();
+    __shared__ uint32_t cnt[FB_NPART + 1];
+    __shared__ uint32_t ws[17];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[FB_KEYS1];
+    const uint32_t tile = blockIdx.x, tid = threadIdx.x;
+    for (uint32_t p = tid; p <= FB_NPART; p += FB_TB1) cnt[p] = 0;
+    __syncthreads();
+    constexpr int SPT = FB_T / FB_TB1;   // scalars per thread
+    U256 s[SPT];
+    bool live[SPT];
+    uint32_t bad = 0;
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+        const uint32_t i = tile * FB_T + j * FB_TB1 + tid;
+        live[j] = i < n;
+        if (live[j]) s[j] = u256_load(scalars + 32 * (size_t)i);
+    }
+    uint32_t pr[SPT * FB_W];   // partition << 16 | rank inside (tile, partition); 0xffffffff: no key
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+        if (live[j]) bad |= !u256_is_canonical_fr(s[j]);
+        if (!live[j]) {
+#pragma unroll
+            for (int w = 0; w < FB_W; ++w) pr[j * FB_W + w] = 0xffffffffu;
+            continue;
+        }
+        fb_for_each_digit(s[j], [&](int w, uint32_t bkt, bool, bool ok) {
+            const uint32_t p = fb_part(w, bkt);
+            pr[j * FB_W + w] = ok ? ((p << 16) | atomicAdd(&cnt[p], 1u)) : 0xffffffffu;
+        });
+    }
+    if (bad) atomicOr(flags, FLAG_NONCANONICAL);
+    __syncthreads();
+    for (uint32_t p = tid; p < FB_NPART; p += FB_TB1) {
+        const uint32_t c = cnt[p];
+        if (c) atomicAdd(&pcount[p], c);
+    }
+    fb_block_scan(cnt, FB_NPART, ws);   // cnt[p] = start of partition p, cnt[FB_NPART] = keys in the tile
+    uint32_t* tt = toff + (size_t)tile * (FB_NPART + 1);
+    for (uint32_t p = tid; p <= FB_NPART; p += FB_TB1) tt[p] = cnt[p];
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+        if (!live[j]) continue;
+        fb_for_each_digit(s[j], [&](int w, uint32_t bkt, bool neg, bool) {
+            const uint32_t q = pr[j * FB_W + w];
+            if (q != 0xffffffffu)
+                stage[cnt[q >> 16] + (q & 0xffffu)] = (fb_sub(w, bkt, (uint32_t)(j * FB_TB1) + tid) << 16) | ((neg ? 1u : 0u) << 15) |
+                                                      ((uint32_t)w << 11) | (uint32_t)(j * FB_TB1 + tid);
+        });
+    }
+    __syncthreads();
+    const uint32_t total = cnt[FB_NPART];
+    uint32_t* out = items + (size_t)tile * FB_KEYS1;
+    for (uint32_t k = 4 * tid; k < total; k += 4 * FB_TB1)   // tiles start 16-byte aligned; the tail past `total` is slack inside the tile
+        *reinterpret_cast<uint4*>(out + k) = *reinterpret_cast<const uint4*>(stage + k);
+}
+
+#ifdef FB_TIMING
+__device__ unsigned long long g_fb_dbg[8 * 8];
+__device__ uint32_t g_fb_mask = 0xffffffffu;   // timing experiment (WRONG results): entries confined to the table's first points
+#define FB_MARK(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 8) g_fb_dbg[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define FB_MARK(i) ((void)0)
+#endif
+// level 2, one workgroup per partition p.  Key k of the partition (k < total) lives in tile t with rpre[t] <= k < rpre[t + 1].
+__global__ void __launch_bounds__(FB_TB2) k_fb_bucket_sort(const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ toff,
+                                                           const uint32_t* __restrict__ items, uint32_t n_level, uint32_t ntile,
+                                                           uint32_t* __restrict__ hist, uint32_t* __restrict__ offs,
+                                                           uint32_t* __restrict__ entries) {
+    SORT_PRIO();
+    constexpr int TB = FB_TB2;
+    __shared__ uint32_t h[FB_KEYS2 + 8];
+    __shared__ uint32_t ws[17];
+    __shared__ uint32_t rstart[FB_MAX_TILES];
+    __shared__ uint32_t rpre[FB_MAX_TILES + 8];
+    __shared__ __attribute__((aligned(16))) uint32_t stage[FB_STAGE];
+    __shared__ uint32_t longt[FB_STAGE / 64 + 1];
+    __shared__ uint32_t nlong;
+    const uint32_t p = blockIdx.x, tid = threadIdx.x;
+    FB_MARK(0);
+    const uint32_t start = pstart[p], total = pstart[p + 1] - start;
+    for (uint32_t b = tid; b <= FB_KEYS2; b += TB) h[b] = 0;
+    if (tid == 0) nlong = 0;
+    for (uint32_t t = tid; t < ntile; t += TB) {
+        const uint32_t* tt = toff + (size_t)t * (FB_NPART + 1) + p;
+        const uint32_t a = tt[0];
+        rstart[t] = a;
+        rpre[t] = tt[1] - a;
+    }
+    fb_block_scan(rpre, ntile, ws);
+    FB_MARK(1);
+    // an ordinary partition: 256 buckets x 13 levels; a partition of the top digit's slots: 1024 slots, that one level
+    const bool ext = p >= FB_PPW;
+    const uint32_t key0 = ext ? FB_NB + ((p - FB_PPW) << FB_XSUB_BITS) : p << FB_SUB_BITS;
+    const uint32_t nslot = ext ? FB_XSB : FB_SB, lv = ext ? 1u : (uint32_t)FB_W, nkeys = nslot * lv;
+    // (tile, address) of key k: the last tile t with rpre[t] <= k (runs are ~13 keys, and very unequal for skewed scalars: no
+    // guessing).  Eleven steps without a branch, so that a thread's independent searches interleave.
+    auto locate = [&](uint32_t k, uint32_t& t) -> const uint32_t* {
+        uint32_t lo = 0;
+#pragma unroll
+        for (int sft = 10; sft >= 0; --sft) {
+            const uint32_t mid = lo + (1u << sft);
+            const uint32_t v = rpre[mid < (uint32_t)FB_MAX_TILES ? mid : (uint32_t)FB_MAX_TILES];
+            lo = (mid < ntile && v <= k) ? mid : lo;
+        }
+        t = lo;
+        return items + (size_t)lo * FB_KEYS1 + rstart[lo] + (k - rpre[lo]);
+    };
+    // item (low slot bits : 8 or 10 | sign | level : 4 | scalar : 11) of tile t -> entry, counter index
+    auto entry_of = [&](uint32_t it, uint32_t t) -> uint32_t {
+#ifdef FB_TIMING
+        return ((it >> 15) & 1u) << 31 | ((((it >> 11) & 15u) * n_level + t * FB_T + (it & 2047u)) & g_fb_mask);
+#else
+        return ((it >> 15) & 1u) << 31 | (((it >> 11) & 15u) * n_level + t * FB_T + (it & 2047u));
+#endif
+    };
+    auto key_of = [&](uint32_t it) -> uint32_t { return ext ? it >> 16 : (it >> 16) * FB_W + ((it >> 11) & 15u); };
+    auto write_hist = [&]() {   // hist / offs of the partition's buckets from the (bucket, level) counters; h[] becomes its scan
+        __syncthreads();
+        for (uint32_t b = tid; b < nslot; b += TB) {
+            uint32_t sum = 0;
+            for (uint32_t w = 0; w < lv; ++w) sum += h[b * lv + w];
+            hist[key0 + b] = sum;
+        }
+        fb_block_scan(h, nkeys, ws);
+        for (uint32_t b = tid; b < nslot; b += TB) offs[key0 + b] = start + h[b * lv];
+    };
+    if (total == 0) {   // (a partition nobody has a key for: tiny MSMs)
+        write_hist();
+        return;
+    }
+    if (total <= (uint32_t)FB_STAGE) {
+        // Where key k lives: a search over rpre[] per key (eleven dependent LDS reads) was two thirds of the kernel.  The runs'
+        // owners say it instead: the thread that loaded tile t's offsets writes the source index of every key of its run into
+        // the key's slot of the stage (a dozen words); each key's thread reads its slot and replaces it with the key itself by
+        // LDS-DMA (one dword per lane from its own address, a wave's 64 as one 256-byte row, no registers, thirty in flight per
+        // lane).  Runs longer than 64 keys (skewed scalars) are finished by whole waves.
+        for (uint32_t t = tid; t < ntile; t += TB) {
+            const uint32_t k0 = rpre[t], len = rpre[t + 1] - k0, src0 = t * (uint32_t)FB_KEYS1 + rstart[t];
+            const uint32_t own = len < 64u ? len : 64u;
+            for (uint32_t i = 0; i < own; ++i) stage[k0 + i] = src0 + i;
+            if (len > 64u) longt[atomicAdd(&nlong, 1u)] = t;
+        }
+        __syncthreads();
+        for (uint32_t q = tid >> 6; q < nlong; q += TB / 64) {
+            const uint32_t t = longt[q], k0 = rpre[t], len = rpre[t + 1] - k0, src0 = t * (uint32_t)FB_KEYS1 + rstart[t];
+            for (uint32_t i = 64u + (tid & 63u); i < len; i += 64u) stage[k0 + i] = src0 + i;
+        }
+        if (nlong) __syncthreads();
+        uint32_t ent[FB_PER2], kr[FB_PER2];
+        const uint32_t wave_base = tid & ~63u;
+#pragma unroll
+        for (int j = 0; j < FB_PER2; ++j) {   // (row j of a wave is read and then overwritten by that wave alone: program order)
+            const uint32_t k = tid + j * TB;
+            kr[j] = stage[k < total ? k : total - 1u];
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(items + kr[j]),
+                                             (__attribute__((address_space(3))) void*)(stage + wave_base + j * TB), 4, 0, 0);
+            asm volatile("" ::: "memory");
+        }
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < FB_PER2; ++j) {
+            const uint32_t it = stage[tid + j * TB];
+            ent[j] = entry_of(it, kr[j] / (uint32_t)FB_KEYS1);
+            kr[j] = key_of(it) << 16;
+            if (j % 6 == 5) asm volatile("" ::: "memory");   // (six LDS reads in flight, not thirty: the register budget)
+        }
+        FB_MARK(2);
+#pragma unroll
+        for (int j = 0; j < FB_PER2; ++j) {
+            const uint32_t k = tid + j * TB;
+            if (k < total) kr[j] |= atomicAdd(&h[kr[j] >> 16], 1u);
+            if (j % 6 == 5) asm volatile("" ::: "memory");
+        }
+        FB_MARK(3);
+        write_hist();
+        FB_MARK(4);
+#pragma unroll
+        for (int j = 0; j < FB_PER2; ++j) {
+            const uint32_t k = tid + j * TB;
+            if (k < total) stage[h[kr[j] >> 16] + (kr[j] & 0xffffu)] = ent[j];
+        }
+        __syncthreads();
+        FB_MARK(5);
+        for (uint32_t k = tid; k < total; k += TB) entries[start + k] = stage[k];
+        FB_MARK(6);
+        return;
+    }
+    // over-long partition (skewed scalars): count, scan, place straight into entries[]; a wave's dominant counters take one
+    // LDS atomic (dm_wave_agg_add): with all scalars equal a partition's keys sit on 13 counters
+    constexpr int MB = 4;
+    const uint32_t rounds = (total + MB * TB - 1) / (MB * TB);
+    for (uint32_t r = 0; r < rounds; ++r) {
+        uint32_t it[MB];
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            const uint32_t k = (r * MB + j) * TB + tid;
+            uint32_t t;
+            it[j] = k < total ? *locate(k, t) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            const uint32_t k = (r * MB + j) * TB + tid;
+            dm_wave_agg_add((lds_u32*)h, key_of(it[j]), k < total);
+        }
+    }
+    write_hist();
+    __syncthreads();
+    for (uint32_t r = 0; r < rounds; ++r) {
+        uint32_t it[MB], tt[MB];
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            const uint32_t k = (r * MB + j) * TB + tid;
+            tt[j] = 0;
+            it[j] = k < total ? *locate(k, tt[j]) : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < MB; ++j) {
+            const uint32_t k = (r * MB + j) * TB + tid;
+            const uint32_t at = dm_wave_agg_add((lds_u32*)h, key_of(it[j]), k < total);
+            if (k < total) entries[start + at] = entry_of(it[j], tt[j]);
+        }
+    }
+}
+
+}  // namespace h2agg

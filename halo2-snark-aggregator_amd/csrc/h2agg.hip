@@ -152,7 +152,7 @@ struct h2agg_ctx {
     int comm_rank = 0, comm_size = 0;
 
     // h2agg_debug_configure: test hooks read per call (chained host-buffer slices, comb route, plan cache)
-    int dbg_pcie_slices = 0, dbg_pcie_glv = 0, dbg_pcie_chain = 1, dbg_comb_msm = 1, dbg_plan_cache = 1, dbg_small_sort = 1, dbg_eval_split = 1;
+    int dbg_pcie_slices = 0, dbg_pcie_glv = 0, dbg_pcie_chain = 1, dbg_comb_msm = 1, dbg_plan_cache = 1, dbg_small_sort = 1, dbg_eval_split = 1, dbg_pre_big = 0;
     // tuning
     int cfg_c = 0, cfg_seg = 0, cfg_big = 0, cfg_sub_bits = 0, cfg_tile = 0;
     int cfg_glv = 0;   // 0 = auto, 1 = on, -1 = off
@@ -572,13 +572,17 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         c->cfg_glv = was;
     }
     int Wd = p.W;                             // digit positions per scalar (what the recoding loops over)
+    // fixed-base levels at c = 20 (tables of 2^18 .. 2^22 points): the (level, point) sort of fb_sort_kernels.hpp
+    const bool fbdm = pre && batch == 1 && pre->c == FB_C && pre->W == FB_W && pre->n_level <= ((size_t)FB_MAX_TILES * FB_T) &&
+                      !c->cfg_no_dm && !c->cfg_no_stage && !c->cfg_stage_l1 && !c->cfg_sub_bits && !c->cfg_tile && !c->cfg_seg;
+    const uint32_t fb_ntile = (uint32_t)((n + FB_T - 1) / FB_T);
     if (pre) {
         p.glv = false;
         p.c = pre->c;
         Wd = pre->W;
         p.W = 1;                              // one bucket set per MSM
         p.NB = 1u << (p.c - 1);
-        p.NBT = batch * p.NB;
+        p.NBT = fbdm ? FB_NBT : batch * p.NB;   // (the top digit's own slots: fb_sort_kernels.hpp)
         // measured (tools/instance_seg_sweep.py, 2^17-point columns): 16-bucket segments up to 8 MSMs per batch, 32 beyond
         p.seg = c->cfg_seg ? (uint32_t)c->cfg_seg : (batch >= 16 ? 32u : 16u);
         if (p.seg > p.NB) p.seg = p.NB;
@@ -679,8 +683,8 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         dp.SB = 1u << dp.sub_bits;
         dp.idx_bits = 31 - dp.sub_bits;
     }
-    TRY(ensure(c, c->item_idx, dm ? (size_t)dm_nwin * dp.n_row * 4 : nent * 4));
-    TRY(ensure(c, c->item_sub, dm ? (size_t)dm_nwin * dp.n_pad * 2 + (dm17 ? (size_t)2 * dm_nwin * (dp.n_pad / 8) : 0) : nent * 2));
+    TRY(ensure(c, c->item_idx, fbdm ? (size_t)fb_ntile * FB_KEYS1 * 4 : dm ? (size_t)dm_nwin * dp.n_row * 4 : nent * 4));
+    TRY(ensure(c, c->item_sub, fbdm ? 0 : dm ? (size_t)dm_nwin * dp.n_pad * 2 + (dm17 ? (size_t)2 * dm_nwin * (dp.n_pad / 8) : 0) : nent * 2));
     TRY(ensure(c, c->entries[sq], nent * 4));
     // buckets / segsum / wsum exist once per tail slot: in overlap mode the reduction of MSM k (tail stream)
     // runs while MSM k+1 fills the next slot's set.  (They were one allocation cut at par * this-plan's-size: two MSMs
@@ -690,9 +694,10 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     {   // (the two-dimensional reduction keeps 4096 partial sums per window there)
         const size_t r2d_records = p.NB == (uint32_t)(R2D_ROWS * R2D<7>::COLS) ? (size_t)WT * (R2D<7>::THREADS + 2)
                                    : p.NB == (uint32_t)(R2D_ROWS * R2D<8>::COLS) ? (size_t)WT * (R2D<8>::THREADS + 2) : 0;
-        TRY(ensure(c, c->segsum[par], (nseg_total > r2d_records ? nseg_total : r2d_records) * XYZZ_BYTES));
+        const size_t fb_records = fbdm ? (size_t)FB_R2D_WINDOWS * (R2D<7>::THREADS + 3) : 0;   // parts, halves, bucket sums
+        TRY(ensure(c, c->segsum[par], std::max(std::max((size_t)nseg_total, r2d_records), fb_records) * XYZZ_BYTES));
     }
-    TRY(ensure(c, c->wsum[par], (size_t)WT * XYZZ_BYTES));
+    TRY(ensure(c, c->wsum[par], (size_t)(fbdm ? FB_R2D_WINDOWS + 2 : WT) * XYZZ_BYTES));
     const size_t max_slots = nent / BIG_CHUNK + nent / ((size_t)p.big + 1) + 2;   // chunks of over-long buckets
     const size_t max_keys = nent / ((size_t)p.big + 1) + 2;
     TRY(ensure(c, c->big_list[sq], max_slots * 12));
@@ -720,7 +725,10 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     const unsigned ntiles = (unsigned)((n + sp.tile - 1) / sp.tile);
     // per-tile partition counts from the counting pass, read back by the packed scatter pass (same tiles)
     uint32_t* tile_counts = nullptr;
-    if (dm) {
+    if (fbdm) {
+        TRY(ensure(c, c->tile_counts, (size_t)fb_ntile * (FB_NPART + 1) * 4));
+        tile_counts = (uint32_t*)c->tile_counts.p;
+    } else if (dm) {
         TRY(ensure(c, c->tile_counts, (size_t)dm_nwin * dp.ntile * (dp.ppw + 1) * 4));
         tile_counts = (uint32_t*)c->tile_counts.p;
     } else if (staged && !c->cfg_stage_l1) {
@@ -765,6 +773,19 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         hipLaunchKernelGGL(k_small_sort, dim3(WT), dim3(SMALL_SORT_TB), 0, st, d_scalars, (uint32_t)n, p.c, Wd,
                            (batch > 1 && !split) ? (uint32_t)n_base : 0u, split, p.glv, p.NB, hist, offs, entries, c->d_flags,
                            big_count);
+    } else if (fbdm) {
+        {
+            StageTimer t(c, ST_PART_SCATTER);
+            if (!meta_was_clean) HIP_TRY(c, hipMemsetAsync(meta, 0, M_WORDS * 4, st));
+            hipLaunchKernelGGL(k_fb_partition, dim3(fb_ntile), dim3(FB_TB1), 0, st, d_scalars, (uint32_t)n, pcount, tile_counts, item_idx,
+                               c->d_flags);
+            hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)pcount, FB_NPART, pstart);
+        }
+        {
+            StageTimer t(c, ST_BUCKET_SORT);
+            hipLaunchKernelGGL(k_fb_bucket_sort, dim3(FB_NPART), dim3(FB_TB2), 0, st, (const uint32_t*)pstart, (const uint32_t*)tile_counts,
+                               (const uint32_t*)item_idx, (uint32_t)pre->n_level, fb_ntile, hist, offs, entries);
+        }
     } else if (dm) {
         const uint32_t PW = dm_nwin * dp.ppw;
         {
@@ -985,10 +1006,11 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     const int r2d_lc = p.NB == (uint32_t)(R2D_ROWS * R2D<7>::COLS) ? 7 : p.NB == (uint32_t)(R2D_ROWS * R2D<8>::COLS) ? 8 : 0;
     const bool r2d = !r2d_env_off && !c->cfg_seg && !pre && r2d_lc != 0;
     uint32_t* ticket = nullptr;
-    if (r2d) {
+    if (r2d || fbdm) {
         DevBuf& tk = c->r2d_ticket[par];   // arrival counters of the two half-window workgroups: zero between MSMs
-        if ((size_t)WT * 4 > tk.cap) {
-            TRY(ensure(c, tk, (size_t)WT * 4));
+        const size_t tickets = fbdm ? (size_t)FB_R2D_WINDOWS : (size_t)WT;
+        if (tickets * 4 > tk.cap) {
+            TRY(ensure(c, tk, tickets * 4));
             HIP_TRY(c, hipMemset(tk.p, 0, tk.cap));
         }
         ticket = (uint32_t*)tk.p;
@@ -1013,6 +1035,37 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
             c->meta_clean[sq] = true;
             HIP_TRY(c, hipEventRecord(c->ev_accdone[sq], ts));
             c->accdone_pending[sq] = true;
+        }
+        if (fbdm) {   // one set of 2^19 buckets as 16 grids of 256 x 128 (msm_kernels.hpp, above k_fb_fold)
+            constexpr uint32_t per_w = (uint32_t)R2D<7>::THREADS, total = FB_R2D_WINDOWS * per_w;
+            uint8_t* halves = segsum + XYZZ_BYTES * (size_t)total;
+            uint8_t* tsum = halves + XYZZ_BYTES * (size_t)(2 * FB_R2D_WINDOWS);
+            uint8_t* w2 = wsum + XYZZ_BYTES * (size_t)FB_R2D_WINDOWS;
+            {
+                StageTimer t(c, ST_REDUCE, ts);
+                hipLaunchKernelGGL(k_fb_fold, dim3((FB_XB >> FB_XPARTS_LOG) / 64), dim3(64), 0, ts, buckets);
+                hipLaunchKernelGGL(k_msm_reduce2d_parts<7>, dim3(total / 64), dim3(64), 0, ts, (const uint8_t*)buckets, total, segsum);
+            }
+            {
+                StageTimer t(c, ST_WINDOW_SUM, ts);
+                hipLaunchKernelGGL(k_msm_reduce2d_window<7>, dim3(FB_R2D_WINDOWS, 2), dim3(R2D_TB), 0, ts, (const uint8_t*)segsum, halves, ticket,
+                                   wsum, tsum);
+            }
+            if (final_off_stream && !tails_off_stream) {   // overlap level 1: only the last chain leaves the stream
+                HIP_TRY(c, hipEventRecord(c->ev_bulk[par], st));
+                HIP_TRY(c, hipStreamWaitEvent(c->tail_streams[par], c->ev_bulk[par], 0));
+                ts = c->tail_streams[par];
+            }
+            {
+                StageTimer t(c, ST_FINAL, ts);
+                hipLaunchKernelGGL(k_fb_wsum, dim3(1), dim3(64), 0, ts, (const uint8_t*)wsum, (const uint8_t*)tsum, w2);
+                hipLaunchKernelGGL(k_msm_final_lp, dim3(1), dim3(64), 0, ts, (const uint8_t*)w2, 15, 2, res_xyzz, d_out_jac);
+            }
+            if (final_off_stream) {
+                HIP_TRY(c, hipEventRecord(c->ev_tail[par], c->tail_streams[par]));
+                c->tail_pending[par] = true;
+            }
+            return H2AGG_OK;
         }
         if (r2d) {
             const uint32_t per_w = r2d_lc == 7 ? (uint32_t)R2D<7>::THREADS : (uint32_t)R2D<8>::THREADS;
@@ -1685,13 +1738,17 @@ int h2agg_bases_precompute(h2agg_ctx* c, uint64_t handle, int window_bits) try {
     Table& t = it->second;
     if (window_bits != 0 && (window_bits < 4 || window_bits > 20))
         return fail(c, H2AGG_ERR_INVALID, "fixed-base window must be 0 (auto) or in [4, 20]");
-    const int cc = window_bits ? window_bits : choose_pre_window(t.n);
+    int cc = window_bits ? window_bits : choose_pre_window(t.n);
+    // tables whose levels outgrow the packed sort item take c = 20 and the (level, point) sort of fb_sort_kernels.hpp
+    if (!window_bits && (size_t)((255 + cc - 1) / cc) * t.n > ((size_t)1 << 22)) cc = FB_C;
     const int W = (255 + cc - 1) / cc;
+    if (cc == FB_C && t.n > (size_t)FB_MAX_TILES * FB_T)
+        return fail(c, H2AGG_ERR_INVALID, "table too large for fixed-base levels (at most 2^22 points)");
     // the levels are addressed through the sort's packed 32-bit item (22 index bits next to 9 sub-bucket bits + sign):
     // beyond that the sort falls back to its slower kernels and the levels (W x the table) stop paying for themselves
     // (measured with the limit lifted to 4 GiB of levels, round 4, profiles/r04_sweeps.txt: 16 MSMs over a 2^22-point table
     // 74 ms on the ordinary path, 113 ms through levels at c = 20 + the two-array sort — results equal, levels refused)
-    if ((size_t)W * t.n > ((size_t)1 << 22))
+    if (cc != FB_C && (size_t)W * t.n > ((size_t)1 << 22) && !c->dbg_pre_big)
         return fail(c, H2AGG_ERR_INVALID, "table too large for fixed-base levels (ceil(255 / c) * n must be <= 2^22)");
     TRY(join_tails(c));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -1840,7 +1897,7 @@ int h2agg_g1_msm_device_batch_async(h2agg_ctx* c, uint64_t handle, const void* d
     if (per < 1) per = 1;
     // From 2^20 points on an MSM fills the chip by itself and takes the digit-major sort / two-dimensional reduction, which
     // batches do not: one MSM after another, each one's tail under the next one's bulk (2^22 points: 6.1 -> 5.4 ms each)
-    const bool one_by_one = !use_pre && n >= ((size_t)1 << 20);
+    const bool one_by_one = use_pre ? (pt.c == FB_C && n >= ((size_t)1 << 18)) : n >= ((size_t)1 << 20);
     if (one_by_one) per = 1;
     const uint8_t* endo = nullptr;
     TRY(table_endo(c, it->second, &endo));
@@ -2170,7 +2227,24 @@ int h2agg_debug_configure(h2agg_ctx* c, const char* key, int value) try {
     else if (k == "comb_msm") c->dbg_comb_msm = value;
     else if (k == "plan_cache") c->dbg_plan_cache = value;
     else if (k == "small_sort") c->dbg_small_sort = value;   // 0: small MSMs take the packed two-level sort again
-    else if (k == "eval_split") c->dbg_eval_split = value;   // 0: an evaluation's two multi_exps are two MSMs again
+    else if (k == "eval_split") c->dbg_eval_split = value;
+    else if (k == "pre_big") c->dbg_pre_big = value;
+#ifdef FB_TIMING
+    else if (k == "fb_mask") {
+        const uint32_t m = (uint32_t)value;
+        hipMemcpyToSymbol(HIP_SYMBOL(g_fb_mask), &m, 4);
+    }
+    else if (k == "fb_dump") {
+        unsigned long long h[64];
+        hipDeviceSynchronize();
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fb_dbg), sizeof(h));
+        for (int b = 0; b < 8; ++b) {
+            fprintf(stderr, "fb wg %d:", b);
+            for (int i = 1; i < 7; ++i) fprintf(stderr, " %6.2f", (double)(h[b * 8 + i] - h[b * 8 + i - 1]) / 100.0);
+            fprintf(stderr, " us\n");
+        }
+    }
+#endif   // 0: an evaluation's two multi_exps are two MSMs again
     else return fail(c, H2AGG_ERR_INVALID, "h2agg_debug_configure: unknown key " + k);
     return H2AGG_OK;
 } catch (...) {

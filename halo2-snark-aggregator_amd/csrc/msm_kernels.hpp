@@ -19,6 +19,7 @@
 // it because the arithmetic is exact.
 #pragma once
 #include "sort_kernels.hpp"
+#include "fb_sort_kernels.hpp"
 
 namespace h2agg {
 
@@ -657,7 +658,8 @@ template <int LC>
 __global__ void __launch_bounds__(R2D_TB) k_msm_reduce2d_window(const uint8_t* __restrict__ parts,
                                                                  uint8_t* __restrict__ halves /* [2 * windows] XYZZ */,
                                                                  uint32_t* __restrict__ ticket,
-                                                                 uint8_t* __restrict__ wsum) {
+                                                                 uint8_t* __restrict__ wsum,
+                                                                 uint8_t* __restrict__ tsum = nullptr /* [windows] XYZZ: plain sum of the window's buckets */) {
     typedef R2D<LC> G;
     static_assert(LC == 7 || LC == 8, "128 columns (two threads each) or 256 (one thread each) for 256 threads");
     __shared__ uint32_t lds[XYZZ_WORDS * R2D_TB];
@@ -721,6 +723,7 @@ __global__ void __launch_bounds__(R2D_TB) k_msm_reduce2d_window(const uint8_t* _
             partner = (pos + s2) * sl;
             act = owner && pos < s2;
             if (lv == lg + 1 && rows && tid == 0) {   // S_0 of the rows does not count (weight 0)
+                if (tsum) xyzz_store(tsum + XYZZ_BYTES * (size_t)w, v);   // ... but it is the sum of all the window's buckets
                 v = G1XYZZ::identity();
             }
         }
@@ -746,6 +749,39 @@ __global__ void __launch_bounds__(R2D_TB) k_msm_reduce2d_window(const uint8_t* _
         const G1XYZZ other = xyzz_load(halves + XYZZ_BYTES * (size_t)(2 * w + (1 - blockIdx.y)));
         xyzz_store(wsum + XYZZ_BYTES * (size_t)w, xyzz_add(v, other));
         ticket[w] = 0;
+    }
+}
+
+// ---- the one bucket set of an MSM over fixed-base levels at c = 20 (fb_sort_kernels.hpp): 2^19 buckets = 16 grids of 256 x 128
+// sum_b (b + 1) B_b over b = 2^15 q + b'  =  sum_q [ sum_b' (b' + 1) B_{q, b'} ]  +  2^15 sum_q q T_q,   T_q = sum_b' B_{q, b'}:
+// the two-dimensional reduction above over 16 pseudo-windows (k_msm_reduce2d_window also hands out T_q), then
+// k_fb_wsum: out[0] = sum_q V_q, out[1] = sum_q q T_q, and k_msm_final_lp over those two "windows" of 15 bits.
+constexpr int FB_R2D_WINDOWS = (int)(FB_NB / (uint32_t)(R2D_ROWS * R2D<7>::COLS));   // 16
+// buckets[m - 1] += the sixteen parts of value m of the top digit (slots FB_NB + 16 (m - 1) + part), in front of the reduction
+__global__ void __launch_bounds__(64) k_fb_fold(uint8_t* __restrict__ buckets) {
+    const uint32_t b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= (FB_XB >> FB_XPARTS_LOG)) return;
+    G1XYZZ acc = xyzz_load(buckets + XYZZ_BYTES * (size_t)b);
+#pragma unroll 1
+    for (uint32_t j = 0; j < (1u << FB_XPARTS_LOG); ++j)
+        acc = xyzz_add(acc, xyzz_load(buckets + XYZZ_BYTES * ((size_t)FB_NB + (b << FB_XPARTS_LOG) + j)));
+    xyzz_store(buckets + XYZZ_BYTES * (size_t)b, acc);
+}
+__global__ void __launch_bounds__(64) k_fb_wsum(const uint8_t* __restrict__ vsum, const uint8_t* __restrict__ tsum,
+                                                uint8_t* __restrict__ out) {
+    __shared__ uint32_t lds[XYZZ_WORDS * 64];
+    const uint32_t lane = threadIdx.x;
+    G1XYZZ v = G1XYZZ::identity(), t = G1XYZZ::identity();
+    if (lane < (uint32_t)FB_R2D_WINDOWS) {
+        v = xyzz_load(vsum + XYZZ_BYTES * (size_t)lane);
+        if (lane) t = xyzz_mul_small(xyzz_load(tsum + XYZZ_BYTES * (size_t)lane), lane);
+    }
+    const G1XYZZ sv = wave_sum_xyzz(v, lds);
+    __syncthreads();
+    const G1XYZZ st = wave_sum_xyzz(t, lds);
+    if (lane == 0) {
+        xyzz_store(out, sv);
+        xyzz_store(out + XYZZ_BYTES, st);
     }
 }
 

@@ -298,7 +298,8 @@ def test_throughput_mode_paths(eng):
         eng.bases_free(table)
 
 
-@pytest.mark.parametrize("n,cw", [(5000, 0), (5000, 11), (1 << 15, 0), (300, 20), ((1 << 17) - 6, 0)])
+@pytest.mark.parametrize("n,cw", [(5000, 0), (5000, 11), (1 << 15, 0), (300, 20), ((1 << 17) - 6, 0), (70001, 20), ((1 << 19) - 6, 0),
+                                  ((1 << 20) + 3, 0), ((1 << 22) - 6, 0)])
 def test_fixed_base_levels(eng, n, cw):
     """h2agg_bases_precompute: MSMs over a table with fixed-base levels (single bucket set, digits looked up at level
     w) give the same points as the ordinary path — single, prefix, batched; zero / r-1 / one scalars included."""

@@ -1,0 +1,74 @@
+#!/usr/bin/env python3
+"""Per-kernel resources of the gfx950 code object inside libh2agg.so (VGPRs, scratch bytes, LDS bytes, spills), read from the
+code object's metadata notes — what the library that ships actually contains, no rebuild.
+
+    python tools/kernel_resources.py [pattern ...]            table of the kernels whose demangled name contains a pattern
+    python tools/kernel_resources.py --check                  exit 1 unless the budgets below hold (tests/test_capi_symbols.py)
+
+Budgets: every k_msm_accumulate_lean instantiation <= 128 VGPRs and no scratch (four waves per SIMD is what the kernel is
+built for: if register pressure ever exceeds it the compiler spills silently — ADVICE r4)."""
+import os, re, subprocess, sys, tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB = os.path.join(ROOT, "halo2-snark-aggregator_amd", "libh2agg.so")
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+BUDGETS = [  # (name pattern, max VGPRs, max scratch bytes)
+    ("k_msm_accumulate_lean", 128, 0),
+    ("k_msm_final_lp", 128, 0),
+    ("k_fb_partition", 128, 0),
+    ("k_fb_bucket_sort", 128, 0),
+]
+
+
+def kernels(lib=LIB):
+    with tempfile.TemporaryDirectory() as d:
+        fat, co = os.path.join(d, "fat.bin"), os.path.join(d, "gfx950.co")
+        subprocess.check_call([LLVM + "/llvm-objcopy", "-O", "binary", "--only-section=.hip_fatbin", lib, fat])
+        subprocess.check_call([LLVM + "/clang-offload-bundler", "--unbundle", "--type=o", "--input=" + fat,
+                               "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co])
+        notes = subprocess.check_output([LLVM + "/llvm-readelf", "--notes", co], text=True)
+    out, cur, pending = [], None, {}
+    for line in notes.split("\n"):
+        m = re.match(r"\s*(?:- )?\.(\w+):\s*(.*)$", line)
+        if not m:
+            continue
+        k, v = m.group(1), m.group(2).strip().strip("'")
+        if k in ("agpr_count", "group_segment_fixed_size"):   # (a kernel's keys are sorted: these two precede its .name)
+            pending[k] = int(v)
+        elif k == "name" and v.startswith("_Z"):
+            cur = {"name": v, **pending}
+            pending = {}
+            out.append(cur)
+        elif cur is not None and k in ("vgpr_count", "sgpr_count", "private_segment_fixed_size", "vgpr_spill_count"):
+            cur[k] = int(v)
+    names = subprocess.check_output(["c++filt"], input="\n".join(k["name"] for k in out), text=True).split("\n")
+    for k, n in zip(out, names):
+        k["demangled"] = re.sub(r"\(.*$", "", n).replace("h2agg::", "").replace("void ", "")
+    return [k for k in out if "vgpr_count" in k]
+
+
+def main():
+    ks = kernels()
+    if "--check" in sys.argv:
+        bad = []
+        for pat, vmax, smax in BUDGETS:
+            hit = [k for k in ks if pat in k["demangled"]]
+            if not hit:
+                bad.append("no kernel matches " + pat)
+            for k in hit:
+                if k["vgpr_count"] > vmax or k["private_segment_fixed_size"] > smax or k.get("vgpr_spill_count", 0):
+                    bad.append("%s: %d VGPRs, %d B scratch" % (k["demangled"], k["vgpr_count"], k["private_segment_fixed_size"]))
+        print("\n".join(bad) if bad else "kernel budgets hold (%d kernels in the code object)" % len(ks))
+        sys.exit(1 if bad else 0)
+    pats = [a for a in sys.argv[1:] if not a.startswith("--")]
+    print("%-64s %5s %5s %8s %8s" % ("kernel", "VGPR", "SGPR", "scratch", "LDS"))
+    for k in sorted(ks, key=lambda k: k["demangled"]):
+        if pats and not any(p in k["demangled"] for p in pats):
+            continue
+        print("%-64s %5d %5d %8d %8d" % (k["demangled"][:64], k["vgpr_count"], k["sgpr_count"], k["private_segment_fixed_size"],
+                                         k["group_segment_fixed_size"]))
+
+
+if __name__ == "__main__":
+    main()
