@@ -263,7 +263,7 @@ __global__ void __launch_bounds__(FB_TB2) k_fb_bucket_sort(const uint32_t* __res
 #pragma unroll
         for (int j = 0; j < FB_PER2; ++j) {   // (row j of a wave is read and then overwritten by that wave alone: program order)
             const uint32_t k = tid + j * TB;
-            kr[j] = stage[k < total ? k : total - 1u];
+            kr[j] = k < total ? stage[k] : 0u;   // (past the end: any valid address; the slot of another row may already hold a key)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(items + kr[j]),
                                              (__attribute__((address_space(3))) void*)(stage + wave_base + j * TB), 4, 0, 0);
             asm volatile("" ::: "memory");
