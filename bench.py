@@ -120,14 +120,15 @@ def sample_power(burst, sync, gpu_index: int, seconds: float = 1.2):
 
 
 def csrc_sha() -> str:
-    """hash of the MSM's kernel sources (field / group arithmetic, sort and MSM kernels): committed PMC evidence for
+    """hash of the MSM's kernel sources (field / group arithmetic, sort and MSM kernels, the limb-parallel Horner chain, the evaluation's prep kernel): committed PMC evidence for
     k_msm_accumulate is only valid for the sources it was collected on.  (Host-side files — transcript, verifier, pairing,
     the launch code in h2agg.hip — do not enter the kernel's instruction stream and are left out, so that work on the
     pipeline around the MSM does not void the counter evidence.)"""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(entry.PKG_DIR, "csrc")
-    for name in ("fp.hpp", "fp_asm.inc", "g1.hpp", "msm_kernels.hpp", "sort_kernels.hpp", "batch_kernels.hpp"):
+    for name in ("fp.hpp", "fp_asm.inc", "g1.hpp", "msm_kernels.hpp", "sort_kernels.hpp", "fb_sort_kernels.hpp", "lp_kernels.hpp",
+                 "batch_kernels.hpp", "schema.hpp"):
         with open(os.path.join(d, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
     return h.hexdigest()[:16]

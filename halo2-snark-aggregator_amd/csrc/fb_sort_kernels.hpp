@@ -166,13 +166,6 @@ __global__ void __launch_bounds__(FB_TB1) k_fb_partition(const uint8_t* __restri
         *reinterpret_cast<uint4*>(out + k) = *reinterpret_cast<const uint4*>(stage + k);
 }
 
-#ifdef FB_TIMING
-__device__ unsigned long long g_fb_dbg[8 * 8];
-__device__ uint32_t g_fb_mask = 0xffffffffu;   // timing experiment (WRONG results): entries confined to the table's first points
-#define FB_MARK(i) do { __syncthreads(); if (threadIdx.x == 0 && blockIdx.x < 8) g_fb_dbg[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
-#else
-#define FB_MARK(i) ((void)0)
-#endif
 // level 2, one workgroup per partition p.  Key k of the partition (k < total) lives in tile t with rpre[t] <= k < rpre[t + 1].
 __global__ void __launch_bounds__(FB_TB2) k_fb_bucket_sort(const uint32_t* __restrict__ pstart, const uint32_t* __restrict__ toff,
                                                            const uint32_t* __restrict__ items, uint32_t n_level, uint32_t ntile,
@@ -188,7 +181,6 @@ __global__ void __launch_bounds__(FB_TB2) k_fb_bucket_sort(const uint32_t* __res
     __shared__ uint32_t longt[FB_STAGE / 64 + 1];
     __shared__ uint32_t nlong;
     const uint32_t p = blockIdx.x, tid = threadIdx.x;
-    FB_MARK(0);
     const uint32_t start = pstart[p], total = pstart[p + 1] - start;
     for (uint32_t b = tid; b <= FB_KEYS2; b += TB) h[b] = 0;
     if (tid == 0) nlong = 0;
@@ -199,7 +191,6 @@ __global__ void __launch_bounds__(FB_TB2) k_fb_bucket_sort(const uint32_t* __res
         rpre[t] = tt[1] - a;
     }
     fb_block_scan(rpre, ntile, ws);
-    FB_MARK(1);
     // an ordinary partition: 256 buckets x 13 levels; a partition of the top digit's slots: 1024 slots, that one level
     const bool ext = p >= FB_PPW;
     const uint32_t key0 = ext ? FB_NB + ((p - FB_PPW) << FB_XSUB_BITS) : p << FB_SUB_BITS;
@@ -219,11 +210,7 @@ __global__ void __launch_bounds__(FB_TB2) k_fb_bucket_sort(const uint32_t* __res
     };
     // item (low slot bits : 8 or 10 | sign | level : 4 | scalar : 11) of tile t -> entry, counter index
     auto entry_of = [&](uint32_t it, uint32_t t) -> uint32_t {
-#ifdef FB_TIMING
-        return ((it >> 15) & 1u) << 31 | ((((it >> 11) & 15u) * n_level + t * FB_T + (it & 2047u)) & g_fb_mask);
-#else
         return ((it >> 15) & 1u) << 31 | (((it >> 11) & 15u) * n_level + t * FB_T + (it & 2047u));
-#endif
     };
     auto key_of = [&](uint32_t it) -> uint32_t { return ext ? it >> 16 : (it >> 16) * FB_W + ((it >> 11) & 15u); };
     auto write_hist = [&]() {   // hist / offs of the partition's buckets from the (bucket, level) counters; h[] becomes its scan
@@ -276,25 +263,20 @@ __global__ void __launch_bounds__(FB_TB2) k_fb_bucket_sort(const uint32_t* __res
             kr[j] = key_of(it) << 16;
             if (j % 6 == 5) asm volatile("" ::: "memory");   // (six LDS reads in flight, not thirty: the register budget)
         }
-        FB_MARK(2);
 #pragma unroll
         for (int j = 0; j < FB_PER2; ++j) {
             const uint32_t k = tid + j * TB;
             if (k < total) kr[j] |= atomicAdd(&h[kr[j] >> 16], 1u);
             if (j % 6 == 5) asm volatile("" ::: "memory");
         }
-        FB_MARK(3);
         write_hist();
-        FB_MARK(4);
 #pragma unroll
         for (int j = 0; j < FB_PER2; ++j) {
             const uint32_t k = tid + j * TB;
             if (k < total) stage[h[kr[j] >> 16] + (kr[j] & 0xffffu)] = ent[j];
         }
         __syncthreads();
-        FB_MARK(5);
         for (uint32_t k = tid; k < total; k += TB) entries[start + k] = stage[k];
-        FB_MARK(6);
         return;
     }
     // over-long partition (skewed scalars): count, scan, place straight into entries[]; a wave's dominant counters take one

@@ -152,7 +152,7 @@ struct h2agg_ctx {
     int comm_rank = 0, comm_size = 0;
 
     // h2agg_debug_configure: test hooks read per call (chained host-buffer slices, comb route, plan cache)
-    int dbg_pcie_slices = 0, dbg_pcie_glv = 0, dbg_pcie_chain = 1, dbg_comb_msm = 1, dbg_plan_cache = 1, dbg_small_sort = 1, dbg_eval_split = 1, dbg_pre_big = 0;
+    int dbg_pcie_slices = 0, dbg_pcie_glv = 0, dbg_pcie_chain = 1, dbg_comb_msm = 1, dbg_plan_cache = 1, dbg_small_sort = 1, dbg_eval_split = 1, dbg_pre_big = 0, dbg_lean_acc = 1;
     // tuning
     int cfg_c = 0, cfg_seg = 0, cfg_big = 0, cfg_sub_bits = 0, cfg_tile = 0;
     int cfg_glv = 0;   // 0 = auto, 1 = on, -1 = off
@@ -913,8 +913,10 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     // (experiment knob: 256-thread workgroups + H2AGG_ACC_LDS pin the accumulation at exactly N waves per SIMD and leave the rest
     // of the CU — registers and LDS — to whatever else is in flight; see profiles/r03_sweeps.txt section 10)
     static const int acc_block = knob("H2AGG_ACC_BLOCK") ? atoi(knob("H2AGG_ACC_BLOCK")) : 64;
-    static const bool lean = !(knob("H2AGG_ACC") && !strcmp(knob("H2AGG_ACC"), "generic"));
-    static const bool lean_dual = !(knob("H2AGG_ACC") && !strcmp(knob("H2AGG_ACC"), "lean1"));
+    // the generic kernel stays in the shipped library behind a debug key (lean_acc = 0) so that the lean one — inline-asm
+    // Montgomery blocks, fixed temporaries — can be checked against it bit for bit on any box (tests/test_gpu_parity.py)
+    static const bool lean_env = !(knob("H2AGG_ACC") && !strcmp(knob("H2AGG_ACC"), "generic"));
+    const bool lean = lean_env && c->dbg_lean_acc;
     uint32_t* fix_list = nullptr;
     if (lean) {
         TRY(ensure(c, c->fix_list[sq], (size_t)p.NBT * lpb * 8));
@@ -928,8 +930,13 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         // at different times; single waves fill any slot as it frees up (2^20 points: 1.74 -> 1.67 ms/step)
         static const int acc_lds = knob("H2AGG_ACC_LDS") ? atoi(knob("H2AGG_ACC_LDS")) : 0;   // experiment: unused LDS per wave caps the occupancy
         if (lean) {   // 128 VGPRs, four waves per SIMD; exceptional cases go to fix_list (msm_kernels.hpp)
+#ifdef H2AGG_MEASURE_KNOBS   // (one chain per product instead of two in lock step: an A/B variant, not in the shipped library)
+            static const bool lean_dual = !(knob("H2AGG_ACC") && !strcmp(knob("H2AGG_ACC"), "lean1"));
             auto kacc = lean_dual ? (chain == CHAIN_FIRST ? k_msm_accumulate_lean<1, true> : (chain == CHAIN_MID || chain == CHAIN_LAST) ? k_msm_accumulate_lean<2, true> : k_msm_accumulate_lean<0, true>)
                                   : (chain == CHAIN_FIRST ? k_msm_accumulate_lean<1, false> : (chain == CHAIN_MID || chain == CHAIN_LAST) ? k_msm_accumulate_lean<2, false> : k_msm_accumulate_lean<0, false>);
+#else
+            auto kacc = chain == CHAIN_FIRST ? k_msm_accumulate_lean<1, true> : (chain == CHAIN_MID || chain == CHAIN_LAST) ? k_msm_accumulate_lean<2, true> : k_msm_accumulate_lean<0, true>;
+#endif
             hipLaunchKernelGGL(kacc, dim3((unsigned)(((size_t)p.NBT * lpb + 63) / 64)), dim3(64), (size_t)acc_lds,
                                st, d_bases, d_endo_x, entries, offs, hist, ordered ? order : (uint32_t*)nullptr, p.NBT, p.big, lpb, acc_out,
                                big_list, big_keys, big_count, fix_list);
@@ -1744,10 +1751,10 @@ int h2agg_bases_precompute(h2agg_ctx* c, uint64_t handle, int window_bits) try {
     const int W = (255 + cc - 1) / cc;
     if (cc == FB_C && t.n > (size_t)FB_MAX_TILES * FB_T)
         return fail(c, H2AGG_ERR_INVALID, "table too large for fixed-base levels (at most 2^22 points)");
-    // the levels are addressed through the sort's packed 32-bit item (22 index bits next to 9 sub-bucket bits + sign):
-    // beyond that the sort falls back to its slower kernels and the levels (W x the table) stop paying for themselves
-    // (measured with the limit lifted to 4 GiB of levels, round 4, profiles/r04_sweeps.txt: 16 MSMs over a 2^22-point table
-    // 74 ms on the ordinary path, 113 ms through levels at c = 20 + the two-array sort — results equal, levels refused)
+    // other widths are addressed through the sort's packed 32-bit item (22 index bits next to 9 sub-bucket bits + sign):
+    // beyond that the sort falls back to its two-array kernels and the levels stop paying for themselves (round 4, with the
+    // limit lifted: 16 MSMs over a 2^22-point table 74 ms on the ordinary path, 113 ms through levels at c = 20 + the two-array
+    // sort).  debug key "pre_big" lifts the limit for A/B runs of exactly that.
     if (cc != FB_C && (size_t)W * t.n > ((size_t)1 << 22) && !c->dbg_pre_big)
         return fail(c, H2AGG_ERR_INVALID, "table too large for fixed-base levels (ceil(255 / c) * n must be <= 2^22)");
     TRY(join_tails(c));
@@ -2227,24 +2234,9 @@ int h2agg_debug_configure(h2agg_ctx* c, const char* key, int value) try {
     else if (k == "comb_msm") c->dbg_comb_msm = value;
     else if (k == "plan_cache") c->dbg_plan_cache = value;
     else if (k == "small_sort") c->dbg_small_sort = value;   // 0: small MSMs take the packed two-level sort again
-    else if (k == "eval_split") c->dbg_eval_split = value;
-    else if (k == "pre_big") c->dbg_pre_big = value;
-#ifdef FB_TIMING
-    else if (k == "fb_mask") {
-        const uint32_t m = (uint32_t)value;
-        hipMemcpyToSymbol(HIP_SYMBOL(g_fb_mask), &m, 4);
-    }
-    else if (k == "fb_dump") {
-        unsigned long long h[64];
-        hipDeviceSynchronize();
-        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fb_dbg), sizeof(h));
-        for (int b = 0; b < 8; ++b) {
-            fprintf(stderr, "fb wg %d:", b);
-            for (int i = 1; i < 7; ++i) fprintf(stderr, " %6.2f", (double)(h[b * 8 + i] - h[b * 8 + i - 1]) / 100.0);
-            fprintf(stderr, " us\n");
-        }
-    }
-#endif   // 0: an evaluation's two multi_exps are two MSMs again
+    else if (k == "eval_split") c->dbg_eval_split = value;   // 0: an evaluation's two multi_exps are two MSMs again
+    else if (k == "lean_acc") c->dbg_lean_acc = value;       // 0: the bucket accumulation through the generic kernel (k_msm_accumulate) instead of the lean one
+    else if (k == "pre_big") c->dbg_pre_big = value;         // 1: h2agg_bases_precompute takes any explicit width (levels through the two-array sort)
     else return fail(c, H2AGG_ERR_INVALID, "h2agg_debug_configure: unknown key " + k);
     return H2AGG_OK;
 } catch (...) {

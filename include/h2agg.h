@@ -156,9 +156,11 @@ int h2agg_bases_upload(h2agg_ctx* ctx, const uint8_t* bases_aff, size_t n, uint6
  * (ceil(255 / c) x 64 B per point).  Every later MSM over this handle (h2agg_g1_msm_preloaded / _device / _device_async /
  * _device_batch_async, h2agg_instance_commitment) then drops all digits of a scalar into ONE bucket set: one bucket
  * reduction instead of one per window, no doubling chain, and a wider window.  window_bits: 0 = chosen from the table
- * size, else 4..20; ceil(255 / c) * n must be <= 2^22 (tables up to ~2^18 points), larger tables are refused
- * (H2AGG_ERR_INVALID) and keep the ordinary path.  Results are the same points (h2agg_msm_configure's explicit
- * window_bits disables the fast path). */
+ * size, else 4..20.  Tables up to ~2^18 points (ceil(255 / c) * n <= 2^22) take the width that minimises the work; larger
+ * ones, up to 2^22 points, take c = 20: 13 levels = 832 B per point beside the table — 3.25 GiB for a 2^22-point g_lagrange,
+ * built in ~80 ms — and a (level, point) sort of their own (csrc/fb_sort_kernels.hpp).  An explicit width other than 20 whose
+ * levels exceed 2^22 entries, and tables beyond 2^22 points, are refused (H2AGG_ERR_INVALID) and keep the ordinary path.
+ * Results are the same points (h2agg_msm_configure's explicit window_bits disables the fast path). */
 int h2agg_bases_precompute(h2agg_ctx* ctx, uint64_t bases_handle, int window_bits);
 /* bases[i] = k_i * G for n canonical Fr scalars held in DEVICE memory (workload generation: the
  * expected MSM is then (sum k_i * s_i) * G).  Arithmetic = scalar_mul_constant + to_affine. */

@@ -45,3 +45,17 @@ def test_product_does_not_import_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b|#include\s+[\"<].*oracle", txt, flags=re.M):
                     bad.append(f)
     assert not bad, bad
+
+
+def test_kernel_register_budgets_of_the_built_library():
+    """The lean bucket accumulation is built for four waves per SIMD: 128 VGPRs, no scratch.  If register pressure ever
+    exceeded that the compiler would spill silently, so the budgets are read off the code object that ships
+    (tools/kernel_resources.py --check), here as well as on the GPU box.  The single-chain lean variants are A/B builds only:
+    they must not be in the product library."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "kernel_resources.py")
+    r = subprocess.run([sys.executable, tool, "--check"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    table = subprocess.run([sys.executable, tool, "k_msm_accumulate_lean"], capture_output=True, text=True).stdout
+    assert "k_msm_accumulate_lean<0, true>" in table and ", false>" not in table, table
