@@ -49,8 +49,8 @@ constexpr uint32_t FB_NPART = FB_PPW + (FB_XB >> FB_XSUB_BITS);   // 2048 + 256 
 constexpr int FB_KEYS1 = FB_T * FB_W;          // keys of a tile (26 624)
 constexpr int FB_MAX_TILES = 2048;             // n <= 2^22
 constexpr int FB_TB2 = 1024;                   // level-2 threads
-constexpr int FB_PER2 = 30;                    // keys per thread staged in LDS by level 2
-constexpr int FB_STAGE = FB_PER2 * FB_TB2;     // 30 720 keys (120 KiB): the mean partition holds 13 n / 2048 <= 26 624
+constexpr int FB_PER2 = 28;                    // keys per thread staged in LDS by level 2
+constexpr int FB_STAGE = FB_PER2 * FB_TB2;     // 28 672 keys (112 KiB): a partition holds 12 n / 2048 <= 24 576 on average
 constexpr uint32_t FB_KEYS2 = FB_SB * FB_W;    // level-2 counters: (bucket, level)
 
 // exclusive scan of v[0 .. cnt) in LDS (cnt <= 4 * blockDim.x, blockDim.x = 1024), total -> v[cnt]; ws: 17 words of LDS
