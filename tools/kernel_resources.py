@@ -57,7 +57,7 @@ def main():
             if not hit:
                 bad.append("no kernel matches " + pat)
             for k in hit:
-                if k["vgpr_count"] > vmax or k["private_segment_fixed_size"] > smax or k.get("vgpr_spill_count", 0):
+                if k["vgpr_count"] > vmax or k["private_segment_fixed_size"] > smax or (smax == 0 and k.get("vgpr_spill_count", 0)):
                     bad.append("%s: %d VGPRs, %d B scratch" % (k["demangled"], k["vgpr_count"], k["private_segment_fixed_size"]))
         print("\n".join(bad) if bad else "kernel budgets hold (%d kernels in the code object)" % len(ks))
         sys.exit(1 if bad else 0)
