@@ -17,7 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libh2agg.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "h2agg.h")
 
-OK, ERR_INVALID, ERR_DIV_ZERO, ERR_EMPTY, ERR_HIP, ERR_NONCANONICAL, ERR_NOMEM, ERR_BAD_POINT = range(8)
+OK, ERR_INVALID, ERR_DIV_ZERO, ERR_EMPTY, ERR_HIP, ERR_NONCANONICAL, ERR_NOMEM, ERR_BAD_POINT, ERR_PEER = range(9)
 OP_ADD, OP_SUB, OP_MUL, OP_SQR, OP_INV, OP_DIV = range(6)
 
 IDENTITY_JAC = (0).to_bytes(32, "little") + (1).to_bytes(32, "little") + (0).to_bytes(32, "little")

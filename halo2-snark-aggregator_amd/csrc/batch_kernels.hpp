@@ -441,6 +441,19 @@ __global__ void __launch_bounds__(BLOCK) k_g1_sum(const uint8_t* __restrict__ in
     if (threadIdx.x == 0) jac_store_canonical(out, jac_from_xyzz(tot));
 }
 
+// y^2 = x^3 + 3 z^6 (or z = 0): partial accumulators arrive over a transport and are checked like every other input
+FP_INLINE bool jac_on_curve(const G1Jac& p) {
+    if (fp_is_zero_mod<2, FqParams>(p.z)) return true;
+    Fq three;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) three.l[k] = 0;
+    three.l[0] = 3;
+    const Fq z2 = FQ_SQR(p.z);
+    const Fq z6 = FQ_MUL(FQ_SQR(z2), z2);
+    const Fq rhs = FQ_ADD(FQ_MUL(FQ_SQR(p.x), p.x), FQ_MUL(z6, fp_to_mont<FqParams>(three)));   // [4]
+    return fp_is_zero_mod<8, FqParams>(FQ_SUB(4, FQ_SQR(p.y), rhs));
+}
+
 // out_aff[k] = to_affine( sum_r in[(r * npts + k)] ), r < world: the local fold after the all-gather of the ranks' partial
 // accumulators (one workgroup per output point; arithmetic = MockEccChip::add + to_value, mock/arith/ecc.rs:30-37,64-66)
 __global__ void __launch_bounds__(BLOCK) k_g1_sum_strided_affine(const uint8_t* __restrict__ in, size_t world, size_t npts,
@@ -451,7 +464,9 @@ __global__ void __launch_bounds__(BLOCK) k_g1_sum_strided_affine(const uint8_t* 
     for (size_t r = threadIdx.x; r < world; r += BLOCK) {
         const uint8_t* p = in + 96 * (r * npts + k);
         if (jac_noncanonical(p)) atomicOr(flags, FLAG_NONCANONICAL);
-        acc = xyzz_add(acc, xyzz_from_jac(jac_load_canonical(p)));
+        const G1Jac j = jac_load_canonical(p);
+        if (!jac_on_curve(j)) atomicOr(flags, FLAG_BAD_POINT);
+        acc = xyzz_add(acc, xyzz_from_jac(j));
     }
     G1XYZZ tot = block_sum_xyzz(acc, lds);
     if (threadIdx.x == 0) {

@@ -152,7 +152,7 @@ struct h2agg_ctx {
     int comm_rank = 0, comm_size = 0;
 
     // h2agg_debug_configure: test hooks read per call (chained host-buffer slices, comb route, plan cache)
-    int dbg_pcie_slices = 0, dbg_pcie_glv = 0, dbg_pcie_chain = 1, dbg_comb_msm = 1, dbg_plan_cache = 1, dbg_small_sort = 1, dbg_eval_split = 1, dbg_pre_big = 0, dbg_lean_acc = 1;
+    int dbg_pcie_slices = 0, dbg_pcie_glv = 0, dbg_pcie_chain = 1, dbg_comb_msm = 1, dbg_plan_cache = 1, dbg_small_sort = 1, dbg_eval_split = 1, dbg_pre_big = 0, dbg_lean_acc = 1, dbg_shard_fail = 0;
     // tuning
     int cfg_c = 0, cfg_seg = 0, cfg_big = 0, cfg_sub_bits = 0, cfg_tile = 0;
     int cfg_glv = 0;   // 0 = auto, 1 = on, -1 = off
@@ -914,7 +914,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     // of the CU — registers and LDS — to whatever else is in flight; see profiles/r03_sweeps.txt section 10)
     static const int acc_block = knob("H2AGG_ACC_BLOCK") ? atoi(knob("H2AGG_ACC_BLOCK")) : 64;
     // the generic kernel stays in the shipped library behind a debug key (lean_acc = 0) so that the lean one — inline-asm
-    // Montgomery blocks, fixed temporaries — can be checked against it bit for bit on any box (tests/test_gpu_parity.py)
+    // Montgomery blocks, fixed temporaries — can be checked against it, point for point, on any box (tests/test_gpu_parity.py)
     static const bool lean_env = !(knob("H2AGG_ACC") && !strcmp(knob("H2AGG_ACC"), "generic"));
     const bool lean = lean_env && c->dbg_lean_acc;
     uint32_t* fix_list = nullptr;
@@ -2235,6 +2235,7 @@ int h2agg_debug_configure(h2agg_ctx* c, const char* key, int value) try {
     else if (k == "plan_cache") c->dbg_plan_cache = value;
     else if (k == "small_sort") c->dbg_small_sort = value;   // 0: small MSMs take the packed two-level sort again
     else if (k == "eval_split") c->dbg_eval_split = value;   // 0: an evaluation's two multi_exps are two MSMs again
+    else if (k == "shard_fail") c->dbg_shard_fail = value;   // tests: this rank of a sharded aggregation fails before (1) / between (2) the exchanges
     else if (k == "lean_acc") c->dbg_lean_acc = value;       // 0: the bucket accumulation through the generic kernel (k_msm_accumulate) instead of the lean one
     else if (k == "pre_big") c->dbg_pre_big = value;         // 1: h2agg_bases_precompute takes any explicit width (levels through the two-array sort)
     else return fail(c, H2AGG_ERR_INVALID, "h2agg_debug_configure: unknown key " + k);

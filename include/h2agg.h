@@ -44,7 +44,9 @@ enum {
     H2AGG_ERR_HIP = 4,          /* HIP runtime / device failure */
     H2AGG_ERR_NONCANONICAL = 5, /* an input integer was >= its modulus */
     H2AGG_ERR_NOMEM = 6,
-    H2AGG_ERR_BAD_POINT = 7     /* a compressed point does not decode: "invalid point encoding in proof", transcript.rs:65-70 */
+    H2AGG_ERR_BAD_POINT = 7,    /* a compressed point does not decode: "invalid point encoding in proof", transcript.rs:65-70;
+                                   a partial accumulator received from a peer rank is not on the curve */
+    H2AGG_ERR_PEER = 8          /* sharded aggregation: another rank failed (its code is in the message); this rank's inputs were fine */
 };
 
 /* field ops of h2agg_fr_batch_op */
@@ -351,7 +353,15 @@ int h2agg_verify_aggregation_ex(h2agg_ctx* ctx, const h2agg_circuit_proofs* circ
  * [bytes] in rank order, returns 0) or, if NULL, the context's RCCL communicator over xGMI (h2agg_comm_init_rank with the same
  * rank / world).  Every rank returns the same pair, lambda and pairing verdict as h2agg_verify_aggregation on all N proofs in
  * one context, bit for bit.  advice_out: this rank's proofs only, local order.  Errors as h2agg_verify_aggregation; two ranks
- * claiming one position, or a position nobody holds -> H2AGG_ERR_INVALID on every rank. */
+ * claiming one position, or a position nobody holds -> H2AGG_ERR_INVALID on every rank.
+ * No rank waits for a rank that failed: once its shard description is accepted a rank enters BOTH exchanges whatever happens
+ * to it locally (a proof that does not decode, a non-canonical scalar, no memory, advice_cap too small) — each payload
+ * carries a status word — and every rank leaves the call at the same exchange: the failing rank with its own error, the
+ * others with H2AGG_ERR_PEER.  (A rank whose shard DESCRIPTION is refused — bad rank / world, repeated global_index, no
+ * transport — returns before any exchange: that is a caller's bug, the same on every rank of a correct launch.)  Trust: the
+ * squeezes and partial pairs of the other ranks arrive through the transport; partial pairs are checked to be canonical
+ * points of the curve (H2AGG_ERR_NONCANONICAL / H2AGG_ERR_BAD_POINT), but a rank that LIES within those bounds changes the
+ * result — ranks and transport are inside the verifier's trust boundary, as the threads of the reference's one process are. */
 typedef int (*h2agg_allgather_fn)(void* user, const void* send, size_t bytes, void* recv);
 typedef struct {
     uint32_t rank, world;

@@ -190,3 +190,88 @@ def test_sharded_over_the_contexts_rccl_communicator_world_1(pkg, eng):
     finally:
         e2.close()
     assert got == want
+
+
+def run_threads_collecting(pkg, setup, circuits, world, prepare=None, wrap_exchange=None):
+    """as run_threads, but every rank's outcome is kept: a result tuple, or the H2AggError it raised.  prepare(rank, eng):
+    per-rank set-up (debug keys); wrap_exchange(rank, allgather) -> allgather: a transport that misbehaves."""
+    ver = importlib.import_module(entry.PKG_NAME + ".verifier")
+    ex = BarrierExchange(world)
+    out = [None] * world
+
+    def rank_main(rank):
+        eng = pkg.H2Agg(0)
+        try:
+            if prepare:
+                prepare(rank, eng)
+            local, gidx, n_total = shard_batch(circuits, world, rank)
+            table, vks, arg = product_args(ver, eng, setup, local)
+            try:
+                ag = ex.for_rank(rank)
+                if wrap_exchange:
+                    ag = wrap_exchange(rank, ag)
+                out[rank] = ver.verify_aggregation_sharded(eng, arg, gidx, n_total, rank, world, ag, g2b(setup.s_g2), g2b(setup.g2))
+            finally:
+                for vk in vks:
+                    vk.close()
+                eng.bases_free(table)
+        except BaseException as e:   # noqa
+            out[rank] = e
+        finally:
+            eng.close()
+    ts = [threading.Thread(target=rank_main, args=(r,), daemon=True) for r in range(world)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(timeout=300)
+    assert not any(t.is_alive() for t in ts), "a rank is still waiting in an exchange another rank never entered"
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_a_rank_failing_before_the_lambda_exchange_hangs_nobody(eng, pkg, world):
+    """One malformed proof on one rank (a point that does not decode) used to leave the other ranks in an all-gather forever
+    (ADVICE r4): now the failing rank still enters exchange 1, with its error in the status word; it reports its own error and
+    every other rank H2AGG_ERR_PEER."""
+    setup, circuits = make_batch(0x6F1 + world, [SHAPES[0]], 3)
+    inst, data = circuits[0].proofs[1]          # round-robin: proof 1 sits on rank 1
+    bad = bytearray(data)
+    x = next(v for v in range(2, 60) if pow((v ** 3 + 3) % O.P, (O.P - 1) // 2, O.P) != 1)
+    bad[0:32] = x.to_bytes(32, "little")
+    circuits[0].proofs[1] = (inst, bytes(bad))
+    out = run_threads_collecting(pkg, setup, circuits, world)
+    for rank, res in enumerate(out):
+        assert isinstance(res, pkg.H2AggError), (rank, res)
+        assert res.code == (pkg.ERR_BAD_POINT if rank == 1 else pkg.ERR_PEER), (rank, res)
+
+
+@pytest.mark.parametrize("phase", [1, 2])
+def test_an_injected_failure_on_either_side_of_the_lambda_exchange(eng, pkg, phase):
+    """debug key shard_fail: rank 0 fails before (1) / between (2) the exchanges — exchange 2 must then carry the status"""
+    setup, circuits = make_batch(0x6F8, [SHAPES[1]], 2)
+    out = run_threads_collecting(pkg, setup, circuits, 2, prepare=lambda rank, e: e.debug_configure("shard_fail", phase if rank == 0 else 0))
+    assert isinstance(out[0], pkg.H2AggError) and out[0].code == pkg.ERR_INVALID, out[0]
+    assert isinstance(out[1], pkg.H2AggError) and out[1].code == pkg.ERR_PEER, out[1]
+    assert "rank 0" in str(out[1])
+    # and the contexts are fine afterwards: the same aggregation without the injection
+    want = run_product(pkg, eng, setup, circuits)
+    assert run_threads(pkg, setup, circuits, 2, "auto") == [want, want]
+
+
+def test_a_partial_pair_off_the_curve_is_refused(eng, pkg):
+    """what arrives in exchange 2 is checked like any input: canonical coordinates of a point ON the curve"""
+    setup, circuits = make_batch(0x6FB, [SHAPES[0]], 2)
+
+    def wrap(rank, ag):
+        def allgather(payload):
+            parts = ag(payload)
+            if len(payload) == 132:                       # exchange 2: rank 1's W_x partial with y + 1
+                p = bytearray(parts[1])
+                y = (int.from_bytes(p[32:64], "little") + 1) % O.P
+                p[32:64] = y.to_bytes(32, "little")
+                parts = [parts[0], bytes(p)]
+            return parts
+        return allgather
+    out = run_threads_collecting(pkg, setup, circuits, 2, wrap_exchange=wrap)
+    for rank, res in enumerate(out):
+        assert isinstance(res, pkg.H2AggError) and res.code == pkg.ERR_BAD_POINT, (rank, res)
