@@ -6,7 +6,8 @@ test:
 	python -m pytest tests -x -q -m "not gpu"
 # Pins the oracle against the REFERENCE ITSELF (needs Rust nightly-2022-08-23 and network for the reference's git
 # dependencies — neither exists in the build image, so this has never run here): AGG = a checkout of
-# scroll-tech/halo2-snark-aggregator.  Writes tests/golden/ref_*.json; tests/test_ref_golden.py then stops skipping.
+# scroll-tech/halo2-snark-aggregator.  Writes tests/golden/ref_*.json (the pipeline dumps and ref_chip_kats.json: MockEccChip over the
+# committed msm / point fixtures' inputs); tests/test_ref_golden.py then stops skipping.
 ref-golden:
 	test -n "$(AGG)" || (echo "usage: make ref-golden AGG=/path/to/halo2-snark-aggregator" && false)
 	cp -r tools/ref_dump $(AGG)/ref_dump && cp -r halo2-snark-aggregator_amd/rust-shim $(AGG)/h2agg-sys

@@ -18,6 +18,7 @@ Prints ONE JSON line on rank 0.
 from __future__ import annotations
 
 import argparse
+import math
 import json
 import os
 import sys
@@ -221,6 +222,34 @@ def check_pair_second_path(eng, pkg, agg, mo, syn, specs, lam, commits, pair):
     return (out[0], out[1]) == (pair[0], pair[1])
 
 
+def latency_stats(times):
+    """what a service would see of a leg's repetitions: p50 and p95 beside mean / min / max (a rate quoted from the median
+    alone hid a 68-ms repetition inside a "1.9 ms" figure in round 4)"""
+    ts = sorted(times)
+    n = len(ts)
+    return {"repetitions": n, "p50_s": ts[n // 2], "p95_s": ts[min(n - 1, int(math.ceil(0.95 * n)) - 1)],
+            "mean_s": sum(ts) / n, "min_s": ts[0], "max_s": ts[-1]}
+
+
+class quiet_gc:
+    """the timed repetitions of the host-driven legs run with the cyclic collector off and everything allocated so far moved
+    out of its reach (gc.freeze): a generation-2 collection over torch's and ctypes' object graphs is tens of milliseconds,
+    and it lands inside whichever repetition happens to cross the threshold (tools/pipeline_time.py, tools/stall_hunt.py)"""
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        gc.freeze()
+        gc.disable()
+        return self
+
+    def __exit__(self, *exc):
+        import gc
+        gc.enable()
+        gc.unfreeze()
+        return False
+
+
 def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
     """Secondary figure (BASELINE.json metric, second half): aggregated proofs/s through the full
     EvaluationQuerySchema::eval path.  `agg_proofs` synthetic proofs per GPU (shape: `agg_commitments`
@@ -329,20 +358,21 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
-    reps = 8
+    reps = 32
     times = []
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        t1 = time.perf_counter()
-        pair2 = agg.aggregate_sharded(backend, build, n_total, lam, dist=dist, device=coll_dev, comm=comm, rank_world=(rank, world))
-        times.append(time.perf_counter() - t1)
+    with quiet_gc():
+        for _ in range(reps):
+            t1 = time.perf_counter()
+            pair2 = agg.aggregate_sharded(backend, build, n_total, lam, dist=dist, device=coll_dev, comm=comm, rank_world=(rank, world))
+            times.append(time.perf_counter() - t1)
+            if pair2 != pair:
+                raise SystemExit("aggregate leg: a timed repetition does not reproduce the verified pair — refusing to report")
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize(dev)
-    mean_dt = (time.perf_counter() - t0) / reps
-    dt = sorted(times)[len(times) // 2]          # the median repetition: one stray 10-ms hiccup in 8 x 2.5 ms is not the rate
-    if pair2 != pair:
-        raise SystemExit("aggregate leg: the timed repetitions do not reproduce the verified pair — refusing to report")
+    lat = latency_stats(times)
+    mean_dt = lat["mean_s"]
+    dt = lat["p50_s"]                            # the rate is quoted from the median repetition; p95 / max stand beside it
     # ---- sharded run: the whole aggregation once more on ONE rank (rank 0's GPU, no collective, every proof local) must give
     # the pair the ranks agreed on — the first multi-GPU run checks itself
     one_rank = None
@@ -360,10 +390,11 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
         if int(flag.item()) != 1:
             raise SystemExit("aggregate leg: the %d-rank pair differs from the one-rank recomputation — refusing to report" % world)
         one_rank = "the %d proofs aggregated again on rank 0 alone (no collective) give the same pair" % n_total
-    t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+    t = torch.tensor([dt, lat["p95_s"], lat["max_s"]], dtype=torch.float64, device=coll_dev)
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
+    dt, lat["p95_s"], lat["max_s"] = float(t[0].item()), float(t[1].item()), float(t[2].item())
+    lat["p50_s"] = dt
     # the leg's dominant kernel against the HBM roofline: one more aggregation, untimed, with every MSM stage
     # bracketed by events; algorithmic bytes = 96 B per point of the instance-column MSMs (the two multi_exps of the
     # evaluation are ~10^3 points: noise beside them)
@@ -395,7 +426,9 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
         "proofs": n_total,
         "seconds_per_aggregation": dt,
         "seconds_per_aggregation_mean_min_max": [mean_dt, min(times), max(times)],
-        "timing": "median of the repetitions (max over ranks)",
+        "latency": lat,
+        "p95_over_p50": lat["p95_s"] / lat["p50_s"],
+        "timing": "median of %d repetitions with the cyclic garbage collector off (max over ranks); p95 / max in `latency`" % reps,
         "repetitions": reps,
         "commitments_per_proof": specs[0].nq,
         "instance_msm_points_per_proof": n_inst,
@@ -492,33 +525,33 @@ def full_pipeline_leg(pkg, eng, args, g_table):
         "aa7dfa6601cce64c7bd3430c69e7d1e38f40cb8d8071ab4aeb6d8cdba55ec8125b9722d1dcdaac55f38eb37033314bbc95330c69ad999eec75f05f58d0890609")
     s_g2 = g2                                                    # any valid G2 point: the check is expected to reject
 
-    def timed(k, reps=6):
-        """median seconds per aggregation of k proofs, alternating between two sets; every set's result must repeat"""
+    def timed(k, reps=32):
+        """seconds per aggregation of k proofs (latency_stats), alternating between two sets; every set's result must repeat"""
         sets = [[(vk, "syn", g_table, proofs_all[:k])], [(vk, "syn", g_table, proofs_all[k:2 * k])]]
         first = [ver.verify_aggregation(eng, a, s_g2, g2) for a in sets]      # warm-up (Poseidon constants, buffers, the recording)
         ts = []
-        for r in range(reps):
-            t0 = time.perf_counter()
-            got = ver.verify_aggregation(eng, sets[r & 1], s_g2, g2)
-            ts.append(time.perf_counter() - t0)
-            if got[:3] != first[r & 1][:3]:
-                raise SystemExit("full pipeline leg (%d proofs): repetitions disagree — refusing to report" % k)
+        with quiet_gc():
+            for r in range(reps):
+                t0 = time.perf_counter()
+                got = ver.verify_aggregation(eng, sets[r & 1], s_g2, g2)
+                ts.append(time.perf_counter() - t0)
+                if got[:3] != first[r & 1][:3]:
+                    raise SystemExit("full pipeline leg (%d proofs): repetitions disagree — refusing to report" % k)
         if first[0][:2] == first[1][:2]:
             raise SystemExit("full pipeline leg: two different sets of proofs gave the same pair — refusing to report")
-        ts.sort()
-        return ts[len(ts) // 2], first[0]
+        return latency_stats(ts), first[0]
 
     def both(k):
         eng.debug_configure("plan_cache", 1)
-        dt, res = timed(k)
+        lat, res = timed(k)
         eng.debug_configure("plan_cache", 0)                     # every call records its schema afresh
         try:
-            dt_rec, res_rec = timed(k)
+            lat_rec, res_rec = timed(k, reps=12)
         finally:
             eng.debug_configure("plan_cache", 1)
         if res_rec[:3] != res[:3]:
             raise SystemExit("full pipeline leg: a reused recording and a fresh one disagree — refusing to report")
-        return dt, dt_rec, res
+        return lat, lat_rec["p50_s"], res
 
     def concurrent(k, nthreads=4, secs=1.5):
         """aggregated proofs per second of this GPU when `nthreads` host threads drive it, each with its own context: one call's
@@ -569,11 +602,13 @@ def full_pipeline_leg(pkg, eng, args, g_table):
                 w.eng.close()
 
     try:
-        dt, dt_rec, (left, right, lam, ok) = both(args.agg_proofs)
+        lat, dt_rec, (left, right, lam, ok) = both(args.agg_proofs)
+        dt = lat["p50_s"]
         more = None
         if n_more:
-            dt16, dt16_rec, _ = both(n_more)
-            more = {"proofs_per_sec": n_more / dt16, "proofs": n_more, "seconds_per_aggregation": dt16,
+            lat16, dt16_rec, _ = both(n_more)
+            dt16 = lat16["p50_s"]
+            more = {"proofs_per_sec": n_more / dt16, "proofs": n_more, "seconds_per_aggregation": dt16, "latency": lat16,
                     "recording_every_call": {"proofs_per_sec": n_more / dt16_rec, "seconds_per_aggregation": dt16_rec}}
         plan_stats = eng.verify_plan_stats()
         conc = None
@@ -590,7 +625,8 @@ def full_pipeline_leg(pkg, eng, args, g_table):
     return {"proofs_per_sec": args.agg_proofs / dt, "proofs": args.agg_proofs, "seconds_per_aggregation": dt,
             "recording_every_call": {"proofs_per_sec": args.agg_proofs / dt_rec, "seconds_per_aggregation": dt_rec},
             "recorded_aggregations": {"hits": plan_stats[0], "misses": plan_stats[1]},
-            "timing": "median of 6 calls alternating between two disjoint sets of proofs",
+            "latency": lat, "p95_over_p50": lat["p95_s"] / lat["p50_s"],
+            "timing": "median of 32 calls alternating between two disjoint sets of proofs, cyclic garbage collector off; p95 / max in `latency`",
             "throughput_with_concurrent_contexts": conc,
             "transcript_items_per_proof": {"points": n_pts + n_w, "scalars": n_evals},
             "poseidon_permutations_per_proof": (2 * (n_pts + n_w + 1) + n_evals + 1 + 7) // 8 + 10,
@@ -607,9 +643,123 @@ def full_pipeline_leg(pkg, eng, args, g_table):
                     "without that (DESIGN.md section 5)"}
 
 
+def from_bytes_sharded_leg(pkg, eng, args, rank, world, dist, devs, g_table):
+    """BASELINE.json configs[3] from PROOF BYTES: h2agg_verify_aggregation_sharded with `agg_proofs` proofs per rank, round-robin
+    (rank r holds positions r, r + world, ...), both exchanges inside the C ABI — the lambda all-gather of verify.rs:909-913,
+    :924 and the all-gather + group-law sum of the partial pairs (verify.rs:926-938) — over the context's RCCL communicator
+    (shard->allgather NULL), one rank per GPU; at one GPU a one-rank communicator (`rccl_ranks: 1`).  Only under
+    H2AGG_DIST_BACKEND=gloo (ranks sharing a GPU: a control-flow mode, see main) the transport is torch.distributed.  Every
+    rank's (pair, lambda, verdict) must equal rank 0's ONE-context h2agg_verify_aggregation over all the proofs, or nothing is
+    reported."""
+    import hashlib
+    import importlib
+    dev, coll_dev = devs
+    syn = importlib.import_module(entry.PKG_NAME + ".synthetic")
+    ver = importlib.import_module(entry.PKG_NAME + ".verifier")
+    pool = syn.point_pool(eng, 0xA66)
+    comp = eng.g1_batch_compress(b"".join(pool))
+    pool_c = [comp[32 * i:32 * i + 32] for i in range(len(pool))]
+    shape = syn.CircuitShape(args.agg_instance_log2 or 17, args.agg_commitments, pool)
+    vk = ver.VerifyingKey(eng, ver.encode_vk(shape, lambda p: p))
+    n_inst = 64
+    n_total = args.agg_proofs * world
+    fr = syn.fr_stream(0xF00D)                                   # (seeded: the same proofs on every rank)
+    proofs_all = [([b"".join(fr() for _ in range(n_inst))], shape.random_transcript(pool_c, 300 + i)) for i in range(2 * n_total)]
+    g2 = bytes.fromhex(
+        "edf692d95cbdde46ddda5ef7d422436779445c5e66006a42761e1f12efde0018c212f3aeb785e49712e7a9353349aaf1255dfb31b7bf60723a480d9293938e19"
+        "aa7dfa6601cce64c7bd3430c69e7d1e38f40cb8d8071ab4aeb6d8cdba55ec8125b9722d1dcdaac55f38eb37033314bbc95330c69ad999eec75f05f58d0890609")
+    s_g2 = g2
+    try:
+        allgather, transport = None, None
+        if dist is not None and dist.get_backend() != "nccl":
+            allgather = ver.dist_allgather(dist)
+            transport = "torch.distributed (%s) through the C ABI's allgather callback — control-flow mode, not RCCL" % dist.get_backend()
+        else:
+            if eng.comm_size() == 0:                             # (the aggregation leg sets the communicator up when it can)
+                uid = torch.zeros(128, dtype=torch.uint8, device=coll_dev)
+                if rank == 0:
+                    uid = torch.frombuffer(bytearray(pkg.H2Agg.comm_unique_id()), dtype=torch.uint8).to(coll_dev)
+                if dist is not None:
+                    dist.broadcast(uid, src=0)
+                eng.comm_init_rank(bytes(uid.cpu().numpy().tobytes()), rank, world)
+            if eng.comm_size() != world or eng.comm_rank() != rank:
+                raise SystemExit("rank %d: h2agg communicator reports rank %d of %d, launch says %d of %d"
+                                 % (rank, eng.comm_rank(), eng.comm_size(), rank, world))
+            transport = "the context's RCCL communicator (ncclAllGather inside the C ABI: 4 + 36 N bytes and 132 bytes per rank)"
+        gidx = list(range(rank, n_total, world))
+        sets = [[(vk, "syn", g_table, [proofs_all[b * n_total + g] for g in gidx])] for b in range(2)]
+
+        def call(b):
+            return ver.verify_aggregation_sharded(eng, sets[b], gidx, n_total, rank, world, allgather, s_g2, g2)
+        first = [call(0), call(1)]                                # warm-up + the results every repetition must give
+        # rank 0 alone, ONE context, all N proofs: the sharded call must give exactly this
+        ok_flag = 1
+        if rank == 0:
+            for b in range(2):
+                one = ver.verify_aggregation(eng, [(vk, "syn", g_table, proofs_all[b * n_total:(b + 1) * n_total])], s_g2, g2)
+                if one != first[b]:
+                    ok_flag = 0
+        mine = hashlib.sha256(b"".join(first[b][0] + first[b][1] + first[b][2] for b in range(2))).digest()
+        if dist is not None:
+            t = torch.frombuffer(bytearray(mine), dtype=torch.uint8).to(coll_dev)
+            t0 = t.clone()
+            dist.broadcast(t0, src=0)
+            flag = torch.tensor([ok_flag if bool((t == t0).all().item()) else 0], dtype=torch.int32, device=coll_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok_flag = int(flag.item())
+        if ok_flag != 1:
+            raise SystemExit("from-bytes sharded leg: the ranks' result differs from rank 0's one-context aggregation — refusing to report")
+        if first[0][:2] == first[1][:2]:
+            raise SystemExit("from-bytes sharded leg: two different sets of proofs gave the same pair — refusing to report")
+        if dist is not None:
+            dist.barrier()
+        reps, ts = 32, []
+        with quiet_gc():
+            for r in range(reps):
+                t1 = time.perf_counter()
+                got = call(r & 1)
+                ts.append(time.perf_counter() - t1)
+                if got != first[r & 1]:
+                    raise SystemExit("from-bytes sharded leg: repetitions disagree — refusing to report")
+        lat = latency_stats(ts)
+        t = torch.tensor([lat["p50_s"], lat["p95_s"], lat["max_s"]], dtype=torch.float64, device=coll_dev)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        lat["p50_s"], lat["p95_s"], lat["max_s"] = float(t[0].item()), float(t[1].item()), float(t[2].item())
+        return {"proofs_per_sec": n_total / lat["p50_s"], "proofs": n_total, "proofs_per_gpu": args.agg_proofs,
+                "seconds_per_aggregation": lat["p50_s"], "latency": lat, "p95_over_p50": lat["p95_s"] / lat["p50_s"],
+                "rccl_ranks": eng.comm_size() if allgather is None else 0, "transport": transport,
+                "final_pair_sha": hashlib.sha256(first[0][0] + first[0][1]).hexdigest()[:16],
+                "lambda_sha": hashlib.sha256(first[0][2]).hexdigest()[:16],
+                "equals_one_context_call": "rank 0's h2agg_verify_aggregation over all %d proofs gives every rank's pair, lambda and verdict (both sets)" % n_total,
+                "exchanges": "1: every proof's last squeeze -> the same lambda on every rank (verify.rs:909-913, :924); "
+                             "2: partial (W_x, W_g) per rank, summed with the group law on every rank (verify.rs:926-938)",
+                "timing": "median of 32 calls alternating between two disjoint sets of proofs (max over ranks), cyclic garbage collector off"}
+    finally:
+        vk.close()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): become the launch the driver uses for N > 1, one rank
+    per GPU, instead of quietly measuring one GPU and printing n_gpus = 1"""
+    import socket
+    import subprocess
+    backend = os.environ.get("H2AGG_DIST_BACKEND", "nccl")
+    if backend == "nccl" and torch.cuda.is_available() and args.gpus > torch.cuda.device_count():
+        raise SystemExit("bench.py --gpus %d: this node shows %d GPU(s) — refusing to run (no line is printed for a GPU count "
+                         "that was not measured)" % (args.gpus, torch.cuda.device_count()))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: --gpus %d without a launcher: running %s" % (args.gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    raise SystemExit(subprocess.call(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1")))
+
+
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=None)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--spinup", type=int, default=40, help="untimed MSMs before the warm-up (GPU clock spin-up after the host-side self-check)")
@@ -643,9 +793,13 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and (args.gpus or 1) > 1:
+        self_launch(args)                                    # (does not return)
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
+    if args.gpus is None:
         args.gpus = world
+    if world != args.gpus:       # never a line whose n_gpus is not what was asked for
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s) — refusing to run" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path is the product; there is no CPU fallback)")
     # One rank per GPU over RCCL.  H2AGG_DIST_BACKEND=gloo (collectives through host tensors, ranks may share a
@@ -932,6 +1086,8 @@ def main():
                                                  "instance_msm_fixed_base_levels", "exchange", "verified")}
                 finally:
                     eng.bases_free(g4)
+            if agg_info is not None and g_table is not None and args.agg_instance_log2 <= 18:
+                agg_info["from_bytes_sharded"] = from_bytes_sharded_leg(pkg, eng, args, rank, world, dist, (dev, coll_dev), g_table)
             if agg_info is not None and world == 1 and g_table is not None and args.agg_instance_log2 <= 18:
                 agg_info["full_pipeline"] = full_pipeline_leg(pkg, eng, args, g_table)
             if cpu_ctx is not None and rank == 0 and not args.no_cpu_baseline:

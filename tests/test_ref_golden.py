@@ -133,6 +133,27 @@ def test_primitives_against_the_reference():
     assert O.fe_to_bytes(V.FR_ROOT_OF_UNITY).hex() == g["fr_root_of_unity"] and O.fe_to_bytes(V.FR_DELTA).hex() == g["fr_delta"]
 
 
+CHIP_KATS = os.path.join(GOLDEN, "ref_chip_kats.json")
+
+
+@pytest.mark.skipif(not os.path.exists(CHIP_KATS), reason=WHY)
+def test_chip_fixtures_against_the_reference():
+    """ref_chip_kats.json = the reference's own MockEccChip (multi_exp mock/arith/ecc.rs:106-129, scalar_mul, add, sub) over the
+    INPUTS of msm_kats.json / point_kats.json (tools/ref_dump dump_chip_kats).  Those fixtures' outputs — made by the oracle,
+    reproduced by the C restatement (tests/test_oracle.py) and by the HIP kernels (tests/test_gpu_golden.py) — must be the
+    reference's: one comparison pins rows a1-a8 for all three."""
+    with open(CHIP_KATS) as f:
+        ref = json.load(f)
+    with open(os.path.join(GOLDEN, "msm_kats.json")) as f:
+        msm = json.load(f)
+    with open(os.path.join(GOLDEN, "point_kats.json")) as f:
+        pk = json.load(f)
+    assert ref["multi_exp_out_aff"] == [k["out_aff"] for k in msm]
+    assert ref["scalar_mul_out_aff"] == [k["out_aff"] for k in pk["scalar_mul"]]
+    assert ref["add_sum_aff"] == [k["sum_aff"] for k in pk["add"]]
+    assert ref["sub_diff_aff"] == [k["diff_aff"] for k in pk["add"]]
+
+
 def _normalise(g):
     """files of the first ref_dump schema hold ONE circuit flat (circuit / vk_blob / vk_scalar / proofs at the top level); the
     current one holds `circuits`: [...] (several circuits in one aggregation: ref_multi_*.json)"""

@@ -23,6 +23,8 @@
 //!   poseidon            State::default() words, the first three permutation outputs of the T = 9 spec on a fixed input,
 //!                       mds[0][0..3], constants.start[0][0..3]  (the Grain generator and the absent MDS re-draw)
 //!   encodings           G1Affine::to_bytes / to_repr samples for k*G, k = 1, 2, r-1, and the identity
+//! and ref_chip_kats.json: MockEccChip::multi_exp / scalar_mul / add / sub over the inputs of the committed msm_kats.json and
+//! point_kats.json (dump_chip_kats).
 use std::{env, fs, marker::PhantomData, path::PathBuf};
 
 use halo2_proofs::arithmetic::{CurveAffine, Field, FieldExt};
@@ -202,10 +204,86 @@ fn dump_primitives(out_dir: &PathBuf) {
     fs::write(out_dir.join("ref_primitives.json"), o).unwrap();
 }
 
+/// every `"key": "<hex>"` of a JSON text, in order (the committed fixtures are flat lists of objects with hex-string fields;
+/// serde is not among the workspace's dependencies)
+fn hex_fields(text: &str, key: &str) -> Vec<Vec<u8>> {
+    let pat = format!("\"{}\": \"", key);
+    let mut out = vec![];
+    let mut at = 0;
+    while let Some(i) = text[at..].find(&pat) {
+        let start = at + i + pat.len();
+        let end = start + text[start..].find('"').unwrap();
+        out.push(hex::decode(&text[start..end]).unwrap());
+        at = end;
+    }
+    out
+}
+fn fq_from(b: &[u8]) -> halo2curves::bn256::Fq {
+    let mut r = [0u8; 32];
+    r.copy_from_slice(b);
+    Option::from(halo2curves::bn256::Fq::from_repr(r)).expect("canonical coordinate")
+}
+fn fr_from(b: &[u8]) -> Fr {
+    let mut r = [0u8; 32];
+    r.copy_from_slice(b);
+    Option::from(Fr::from_repr(r)).expect("canonical scalar")
+}
+/// the C ABI's affine encoding back into a point (64 zero bytes: the identity)
+fn g1_from_aff64(b: &[u8]) -> G1 {
+    if b.iter().all(|&x| x == 0) { return G1::identity(); }
+    let p: G1Affine = Option::from(G1Affine::from_xy(fq_from(&b[..32]), fq_from(&b[32..64]))).expect("point on the curve");
+    p.into()
+}
+
+/// Rows a1-a8 of SURVEY.md section 8 pinned in the same run as the pipeline: the reference's OWN MockEccChip (multi_exp =
+/// mock/arith/ecc.rs:106-129, scalar_mul :48-62, add / sub :30-46) over the INPUTS of the committed, oracle-made fixtures
+/// tests/golden/msm_kats.json and point_kats.json; the outputs go to ref_chip_kats.json, which tests/test_ref_golden.py holds
+/// against those fixtures' own outputs (the ones the oracle and the HIP kernels already reproduce).
+fn dump_chip_kats(golden: &PathBuf) {
+    type E = halo2_proofs::plonk::Error;
+    let pchip = MockEccChip::<G1Affine, E>::default();
+    let mut ctx = MockChipCtx::default();
+    let msm = fs::read_to_string(golden.join("msm_kats.json")).expect("tests/golden/msm_kats.json");
+    let (bases, scalars) = (hex_fields(&msm, "bases_aff"), hex_fields(&msm, "scalars"));
+    let mut msm_out = vec![];
+    for (b, sc) in bases.iter().zip(scalars.iter()) {
+        let pts: Vec<G1> = b.chunks(64).map(g1_from_aff64).collect();
+        let ss: Vec<Fr> = sc.chunks(32).map(fr_from).collect();
+        let r = pchip.multi_exp(&mut ctx, pts, ss).unwrap();
+        msm_out.push(aff64(&r.to_affine()));
+    }
+    let pk = fs::read_to_string(golden.join("point_kats.json")).expect("tests/golden/point_kats.json");
+    let mut mul_out = vec![];
+    for (b, sc) in hex_fields(&pk, "base_aff").iter().zip(hex_fields(&pk, "scalar").iter()) {
+        let r = pchip.scalar_mul(&mut ctx, &fr_from(sc), &g1_from_aff64(b)).unwrap();
+        mul_out.push(aff64(&r.to_affine()));
+    }
+    // (the add fixtures hold Jacobian triples x || y || z, 96 bytes: the reference's CurveExt has no such constructor in
+    // halo2curves 0.2.1, so they are rebuilt from their affine form x / z^2, y / z^3)
+    let jac = |b: &[u8]| -> G1 {
+        let (x, y, z) = (fq_from(&b[..32]), fq_from(&b[32..64]), fq_from(&b[64..96]));
+        if bool::from(z.is_zero()) { return G1::identity(); }
+        let zi = z.invert().unwrap();
+        let zi2 = zi.square();
+        let p: G1Affine = Option::from(G1Affine::from_xy(x * zi2, y * zi2 * zi)).expect("point on the curve");
+        p.into()
+    };
+    let (mut sum_out, mut diff_out) = (vec![], vec![]);
+    for (a, b) in hex_fields(&pk, "a_jac").iter().zip(hex_fields(&pk, "b_jac").iter()) {
+        let (pa, pb) = (jac(a), jac(b));
+        sum_out.push(aff64(&pchip.add(&mut ctx, &pa, &pb).unwrap().to_affine()));
+        diff_out.push(aff64(&pchip.sub(&mut ctx, &pa, &pb).unwrap().to_affine()));
+    }
+    let o = format!("{{\n  \"multi_exp_out_aff\": {},\n  \"scalar_mul_out_aff\": {},\n  \"add_sum_aff\": {},\n  \"sub_diff_aff\": {}\n}}\n",
+                    json_list(&msm_out), json_list(&mul_out), json_list(&sum_out), json_list(&diff_out));
+    fs::write(golden.join("ref_chip_kats.json"), o).unwrap();
+}
+
 fn main() {
     let out_dir = PathBuf::from(env::args().nth(1).expect("usage: ref_dump <tests/golden directory>"));
     fs::create_dir_all(&out_dir).unwrap();
     dump_primitives(&out_dir);
+    dump_chip_kats(&out_dir);
     // add_mul: c = 7 a^2 b^2 (verify_aggregation.rs:75-82), fixed witnesses instead of the clock-seeded ones
     let add_mul = |rng: &mut XorShiftRng| -> Vec<_> {
         (0..NPROOFS).map(|_| {
