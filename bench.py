@@ -192,7 +192,8 @@ def pmc_evidence_for(stage_name: str, log2n: int, batch: int):
         if got.get("log2n") == log2n and got.get("batch") == batch:
             if got.get("csrc_sha") != csrc_sha():
                 return {"stale": "kernel sources changed since %s was collected" % os.path.relpath(cand, ROOT)}
-            return {"file": os.path.relpath(cand, ROOT), "bytes_per_aggregation": got.get("bytes_per_launch"),
+            return {"file": os.path.relpath(cand, ROOT), "bytes_per_launch": got.get("bytes_per_launch"),
+                    "bytes_per_aggregation": got.get("bytes_per_aggregation"),
                     "traffic_over_algorithmic": got.get("traffic_over_algorithmic"), "csrc_sha": got.get("csrc_sha")}
     return None
 

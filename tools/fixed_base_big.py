@@ -7,7 +7,8 @@ import torch
 import __graft_entry__ as entry
 pkg = entry.load_package(); eng = pkg.H2Agg(0)
 dev = torch.device("cuda:0")
-ORD_ONLY = "--ordinary-only" in sys.argv      # (for counter passes: only the path BASELINE.json configs[4]'s share runs on)
+ORD_ONLY = "--ordinary-only" in sys.argv      # (for counter passes: one path only)
+FIX_ONLY = "--fixed-only" in sys.argv          # ... the path BASELINE.json configs[4]'s share runs on since round 5
 for lg in [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [20, 22]:
     n = (1 << lg) - 6
     B = 16
@@ -18,7 +19,7 @@ for lg in [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [20, 22]:
     out = torch.zeros((2, B, 96), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
     res = {}
-    for m, mode in enumerate(("ordinary",) if ORD_ONLY else ("ordinary", "fixed-base")):
+    for m, mode in enumerate(("ordinary",) if ORD_ONLY else ("fixed-base",) if FIX_ONLY else ("ordinary", "fixed-base")):
         tp = 0.0
         if mode == "fixed-base":
             t0 = time.perf_counter(); eng.bases_precompute(table, 0); tp = time.perf_counter() - t0
@@ -28,8 +29,9 @@ for lg in [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [20, 22]:
             eng.g1_msm_device_batch_async(table, d.data_ptr(), n, B, out[m].data_ptr())
         eng.synchronize()
         res[mode] = ((time.perf_counter() - t0) / 3 * 1e3, tp * 1e3)
-    if ORD_ONLY:
-        print("2^%d - 6 points x %d: ordinary %.2f ms" % (lg, B, res["ordinary"][0]), flush=True)
+    if ORD_ONLY or FIX_ONLY:
+        mode = "ordinary" if ORD_ONLY else "fixed-base"
+        print("2^%d - 6 points x %d: %s %.2f ms" % (lg, B, mode, res[mode][0]), flush=True)
         eng.bases_free(table)
         continue
     same = eng.g1_batch_to_affine(bytes(out[0].cpu().numpy().tobytes())) == eng.g1_batch_to_affine(bytes(out[1].cpu().numpy().tobytes()))

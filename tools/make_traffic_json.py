@@ -66,7 +66,8 @@ def main(prefix):
 
 def batch(prefix, log2n=22, nbatch=16):
     """counter evidence for BASELINE.json configs[4]'s per-GPU share: 16 instance-column MSMs of 2^22 - 6 points over one table
-    (tools/fixed_base_big.py 22 --ordinary-only under rocprofv3 --pmc): bytes of the accumulation kernel per AGGREGATION"""
+    with fixed-base levels (tools/fixed_base_big.py 22 --fixed-only under rocprofv3 --pmc: the path bench.py's
+    aggregate.config4_share runs on): bytes of the accumulation kernel per launch and per AGGREGATION"""
     import bench
     k = "h2agg::k_msm_accumulate_lean<0, true>"
     fetch = counters(prefix + "_pmc_batch_fetch.txt", k)["FETCH_SIZE"]
@@ -75,10 +76,12 @@ def batch(prefix, log2n=22, nbatch=16):
     algo = 96.0 * ((1 << log2n) - 6)
     print(json.dumps({
         "kernel": "k_msm_accumulate_lean", "log2n": log2n, "batch": nbatch,
-        "workload": "16 MSMs of 2^22 - 6 points over one 2^22-point table (tools/fixed_base_big.py 22 --ordinary-only), one launch per MSM",
+        "workload": "16 MSMs of 2^22 - 6 points over one 2^22-point table with fixed-base levels, c = 20 (tools/fixed_base_big.py 22 "
+                    "--fixed-only), one launch per MSM: 13 insertions per point, every (level, point) gathered once from 3.25 GiB of levels",
         "csrc_sha": bench.csrc_sha(),
         "fetch_kb_per_launch": fetch[0], "write_kb_per_launch": write[0], "avg_launch_us": fetch[1],
-        "bytes_per_launch": int(per_launch * nbatch),
+        "bytes_per_launch": int(per_launch),
+        "bytes_per_aggregation": int(per_launch * nbatch),
         "traffic_over_algorithmic": per_launch / algo,
         "source": "%s_pmc_batch_{fetch,write}.txt (rocprofv3 --pmc, separate passes, per-dispatch average, summed over the 8 XCDs)"
                   % os.path.basename(prefix),

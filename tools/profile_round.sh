@@ -3,7 +3,7 @@
 # never combined with other traces) for the dominant kernel.  Run on the GPU box from the repo root:
 #   tools/profile_round.sh r01_final      -> gpurun_out/<tag>_*.txt  (copy the ones to keep into profiles/)
 set -u
-tag=${1:-r04_final}
+tag=${1:-r05_final}
 root=$(pwd)
 out=$root/gpurun_out
 mkdir -p $out
@@ -25,7 +25,7 @@ python tools/make_traffic_json.py $out/${tag} > $out/${tag}_traffic.json 2>> $ou
 cd /tmp
 for pair in "FETCH_SIZE fetch" "WRITE_SIZE write"; do
   set -- $pair
-  rm -rf /tmp/prof_pmcb && rocprofv3 --kernel-trace --pmc $1 -d /tmp/prof_pmcb -o pmc -- python $root/tools/fixed_base_big.py 22 --ordinary-only > /dev/null 2>&1
+  rm -rf /tmp/prof_pmcb && rocprofv3 --kernel-trace --pmc $1 -d /tmp/prof_pmcb -o pmc -- python $root/tools/fixed_base_big.py 22 --fixed-only > /dev/null 2>&1
   python $root/tools/rocpd_summary.py /tmp/prof_pmcb/pmc_results.db > $out/${tag}_pmc_batch_$2.txt 2>&1
 done
 cd $root
