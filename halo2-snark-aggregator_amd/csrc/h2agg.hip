@@ -28,6 +28,17 @@
 #include "scalar_mul_kernels.hpp"
 #include "lp_kernels.hpp"
 #include "pairing.hpp"
+#if !defined(__HIP_DEVICE_COMPILE__) && defined(__x86_64__)
+// the same pairing once more, compiled for BMI2 + ADX (csrc/pairing.hpp's header): taken when the CPU has both
+#define H2AGG_PAIRING_ADX_BUILD 1
+#define PAIRING_NS pairing_adx
+#define PAIRING_ADX 1
+#pragma clang attribute push(__attribute__((target("bmi2,adx"))), apply_to = function)
+#include "pairing.hpp"
+#pragma clang attribute pop
+#undef PAIRING_NS
+#undef PAIRING_ADX
+#endif
 #include "poseidon_host.hpp"
 #include "poseidon_sponge_host.hpp"
 #include "poseidon_ifma_host.hpp"
@@ -2302,39 +2313,83 @@ int h2agg_profile_stage_get(h2agg_ctx* c, int i, double* total_ms, uint64_t* lau
 }
 
 // ---------------------------------------------------------------- pairing check (host)
+extern "C++" {
 namespace {
-int pairing_load(h2agg_ctx* c, const uint8_t* g1_aff, const uint8_t* g2_aff, size_t n,
-                 std::vector<pairing::G1Affine>& ps, std::vector<pairing::G2Affine>& qs) {
+bool pairing_adx_ok() {
+#ifdef H2AGG_PAIRING_ADX_BUILD
+    static const bool ok = __builtin_cpu_supports("bmi2") && __builtin_cpu_supports("adx") && !getenv("H2AGG_PAIRING_PORTABLE");
+    return ok;
+#else
+    return false;
+#endif
+}
+template <class P>
+int pairing_load(h2agg_ctx* c, const uint8_t* g1_aff, const uint8_t* g2_aff, size_t n, std::vector<typename P::G1>& ps,
+                 std::vector<typename P::G2>& qs) {
     if (n && (!g1_aff || !g2_aff)) return fail(c, H2AGG_ERR_INVALID, "null buffer");
     ps.resize(n);
     qs.resize(n);
     for (size_t i = 0; i < n; ++i) {
-        const int r1 = pairing::load_g1(g1_aff + 64 * i, ps[i]);
+        const int r1 = P::load1(g1_aff + 64 * i, ps[i]);
         if (r1 == 1) return fail(c, H2AGG_ERR_NONCANONICAL, "pairing: G1 coordinate >= p");
         if (r1) return fail(c, H2AGG_ERR_BAD_POINT, "pairing: G1 point not on the curve");
-        const int r2 = pairing::load_g2(g2_aff + 128 * i, qs[i]);
+        const int r2 = P::load2(g2_aff + 128 * i, qs[i]);
         if (r2 == 1) return fail(c, H2AGG_ERR_NONCANONICAL, "pairing: G2 coordinate >= p");
         if (r2 == 2) return fail(c, H2AGG_ERR_BAD_POINT, "pairing: G2 point not on the twist");
         if (r2) return fail(c, H2AGG_ERR_BAD_POINT, "pairing: G2 point outside the order-r subgroup");
     }
     return H2AGG_OK;
 }
+template <class P>
+int pairing_product_t(h2agg_ctx* c, const uint8_t* g1_aff, const uint8_t* g2_aff, size_t n, uint8_t out_gt[384]) {
+    std::vector<typename P::G1> ps;
+    std::vector<typename P::G2> qs;
+    TRY(pairing_load<P>(c, g1_aff, g2_aff, n, ps, qs));
+    // (prepared lines: a G2 point that comes back — [s]_2, [1]_2 of one ParamsKZG — pays its doubling / addition steps once)
+    std::vector<std::shared_ptr<const typename P::Prepared>> keep(n);
+    std::vector<const typename P::Prepared*> preps(n);
+    for (size_t i = 0; i < n; ++i) {
+        keep[i] = P::prepared(g2_aff + 128 * i, false, qs[i]);
+        preps[i] = keep[i].get();
+    }
+    P::product_prepared(ps, preps, out_gt);
+    return H2AGG_OK;
+}
+template <class P>
+int pairing_check_t(h2agg_ctx* c, const uint8_t* g1_aff, const uint8_t* g2_aff, size_t n, int* ok) {
+    std::vector<typename P::G1> ps;
+    std::vector<typename P::G2> qs;
+    TRY(pairing_load<P>(c, g1_aff, g2_aff, n, ps, qs));
+    *ok = P::check(ps, qs) ? 1 : 0;
+    return H2AGG_OK;
+}
+// e(left, [s]_2) * e(right, -[1]_2) == 1 ?   (verify.rs:733-739: `n_g2_prepared = -params.g2()`)
+template <class P>
+int final_pair_check_t(h2agg_ctx* c, const uint8_t left_aff[64], const uint8_t right_aff[64], const uint8_t s_g2[128], const uint8_t g2[128],
+                       int* ok) {
+    uint8_t g1s[128], g2s[256];
+    memcpy(g1s, left_aff, 64);
+    memcpy(g1s + 64, right_aff, 64);
+    memcpy(g2s, s_g2, 128);
+    memcpy(g2s + 128, g2, 128);
+    std::vector<typename P::G1> ps;
+    std::vector<typename P::G2> qs;
+    TRY(pairing_load<P>(c, g1s, g2s, 2, ps, qs));
+    P::negate(qs[1]);
+    const std::shared_ptr<const typename P::Prepared> keep[2] = {P::prepared(s_g2, false, qs[0]), P::prepared(g2, true, qs[1])};
+    const std::vector<const typename P::Prepared*> preps = {keep[0].get(), keep[1].get()};
+    *ok = P::check_prepared(ps, preps) ? 1 : 0;
+    return H2AGG_OK;
+}
 }  // namespace
+}  // extern "C++"
 
 int h2agg_pairing_product(h2agg_ctx* c, const uint8_t* g1_aff, const uint8_t* g2_aff, size_t n, uint8_t out_gt[384]) try {
     if (!out_gt) return fail(c, H2AGG_ERR_INVALID, "null buffer");
-    std::vector<pairing::G1Affine> ps;
-    std::vector<pairing::G2Affine> qs;
-    TRY(pairing_load(c, g1_aff, g2_aff, n, ps, qs));
-    // (prepared lines: a G2 point that comes back — [s]_2, [1]_2 of one ParamsKZG — pays its doubling / addition steps once)
-    std::vector<std::shared_ptr<const pairing::G2Prepared>> keep(n);
-    std::vector<const pairing::G2Prepared*> preps(n);
-    for (size_t i = 0; i < n; ++i) {
-        keep[i] = pairing::g2_prepared_cached(g2_aff + 128 * i, false, qs[i]);
-        preps[i] = keep[i].get();
-    }
-    pairing::f12_to_bytes(pairing::final_exponentiation(pairing::multi_miller_loop_prepared(ps, preps)), out_gt);
-    return H2AGG_OK;
+#ifdef H2AGG_PAIRING_ADX_BUILD
+    if (pairing_adx_ok()) return pairing_product_t<pairing_adx::Api>(c, g1_aff, g2_aff, n, out_gt);
+#endif
+    return pairing_product_t<pairing::Api>(c, g1_aff, g2_aff, n, out_gt);
 } catch (const std::bad_alloc&) {
     return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
 } catch (...) {
@@ -2344,11 +2399,10 @@ int h2agg_pairing_product(h2agg_ctx* c, const uint8_t* g1_aff, const uint8_t* g2
 int h2agg_pairing_check(h2agg_ctx* c, const uint8_t* g1_aff, const uint8_t* g2_aff, size_t n, int* ok) try {
     if (!ok) return fail(c, H2AGG_ERR_INVALID, "null buffer");
     *ok = 0;
-    std::vector<pairing::G1Affine> ps;
-    std::vector<pairing::G2Affine> qs;
-    TRY(pairing_load(c, g1_aff, g2_aff, n, ps, qs));
-    *ok = pairing::f12_is_one(pairing::final_exponentiation(pairing::multi_miller_loop(ps, qs))) ? 1 : 0;
-    return H2AGG_OK;
+#ifdef H2AGG_PAIRING_ADX_BUILD
+    if (pairing_adx_ok()) return pairing_check_t<pairing_adx::Api>(c, g1_aff, g2_aff, n, ok);
+#endif
+    return pairing_check_t<pairing::Api>(c, g1_aff, g2_aff, n, ok);
 } catch (const std::bad_alloc&) {
     return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
 } catch (...) {
@@ -2373,25 +2427,14 @@ int h2agg_g2_batch_decompress(h2agg_ctx* c, const uint8_t* in, size_t n, uint8_t
     return H2AGG_ERR_INVALID;
 }
 
-// e(left, [s]_2) * e(right, -[1]_2) == 1 ?   (verify.rs:733-739: `n_g2_prepared = -params.g2()`)
 int h2agg_final_pair_check(h2agg_ctx* c, const uint8_t left_aff[64], const uint8_t right_aff[64], const uint8_t s_g2[128],
                            const uint8_t g2[128], int* ok) try {
     if (!ok || !left_aff || !right_aff || !s_g2 || !g2) return fail(c, H2AGG_ERR_INVALID, "null buffer");
     *ok = 0;
-    uint8_t g1s[128], g2s[256];
-    memcpy(g1s, left_aff, 64);
-    memcpy(g1s + 64, right_aff, 64);
-    memcpy(g2s, s_g2, 128);
-    memcpy(g2s + 128, g2, 128);
-    std::vector<pairing::G1Affine> ps;
-    std::vector<pairing::G2Affine> qs;
-    TRY(pairing_load(c, g1s, g2s, 2, ps, qs));
-    if (!qs[1].inf) qs[1].y = pairing::f2_neg(qs[1].y);
-    const std::shared_ptr<const pairing::G2Prepared> keep[2] = {pairing::g2_prepared_cached(s_g2, false, qs[0]),
-                                                                pairing::g2_prepared_cached(g2, true, qs[1])};
-    const std::vector<const pairing::G2Prepared*> preps = {keep[0].get(), keep[1].get()};
-    *ok = pairing::f12_is_one(pairing::final_exponentiation(pairing::multi_miller_loop_prepared(ps, preps))) ? 1 : 0;
-    return H2AGG_OK;
+#ifdef H2AGG_PAIRING_ADX_BUILD
+    if (pairing_adx_ok()) return final_pair_check_t<pairing_adx::Api>(c, left_aff, right_aff, s_g2, g2, ok);
+#endif
+    return final_pair_check_t<pairing::Api>(c, left_aff, right_aff, s_g2, g2, ok);
 } catch (const std::bad_alloc&) {
     return H2AGG_ERR_NOMEM;   // no C++ exception crosses the C ABI
 } catch (...) {
