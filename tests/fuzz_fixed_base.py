@@ -14,8 +14,9 @@ rng = O.SplitMix64(int(sys.argv[2]) if len(sys.argv) > 2 else 11)
 t_end = time.time() + (float(sys.argv[1]) if len(sys.argv) > 1 else 60)
 cases = 0
 while time.time() < t_end:
-    n = 1 + rng.next() % (1 << (1 + rng.next() % 12))
-    cw = 0 if rng.next() % 3 == 0 else 4 + rng.next() % 17
+    big = rng.next() % 6 == 0                                  # now and then a table whose levels take the (level, point) sort (c = 20)
+    n = (1 << 18) + 1 + rng.next() % (1 << 17) if big else 1 + rng.next() % (1 << (1 + rng.next() % 12))
+    cw = (0 if rng.next() % 2 else 20) if big else (0 if rng.next() % 3 == 0 else 4 + rng.next() % 17)
     ks = b"".join(O.fe_to_bytes(rng.fr()) for _ in range(n))
     d_k = torch.frombuffer(bytearray(ks), dtype=torch.uint8).to(dev)
     table = eng.bases_generate(d_k.data_ptr(), n)

@@ -330,3 +330,66 @@ def test_fixed_base_levels(eng, n, cw):
         assert eng.g1_batch_to_affine(eng.g1_msm_preloaded(table, bytes(arr[2].tobytes()))) == want_full[2]
     finally:
         eng.bases_free(table)
+
+
+@pytest.mark.parametrize("kind", ["all_equal", "two_values", "small", "top_digit_only", "half_zero"])
+def test_fixed_base_levels_c20_skewed_scalars(eng, kind):
+    """the (level, point) sort of the big-table levels (csrc/fb_sort_kernels.hpp) under scalars that are not uniform: every key
+    of a level in ONE bucket (level 2's over-long-partition path with wave-aggregated counters, level 1's one-counter tiles,
+    the accumulation's over-long-bucket chunks), only the top digit's own slots in use, half the digits zero — against the
+    ordinary path over the same table."""
+    dev = torch.device("cuda", 0)
+    n = (1 << 18) + 5
+    ks, k_np = _workload(n, 181)
+    d_k = torch.from_numpy(k_np.copy()).to(dev)
+    table = eng.bases_generate(d_k.data_ptr(), n)
+    try:
+        rng = np.random.Generator(np.random.PCG64(77))
+        if kind == "all_equal":
+            vals = [0x1234567 << 100 | 0xabcdef] * n
+        elif kind == "two_values":
+            vals = [(O.R - 1) if i & 1 else (1 << 240) + 12345 for i in range(n)]
+        elif kind == "small":
+            vals = [int(v) for v in rng.integers(0, 1000, size=n)]
+        elif kind == "top_digit_only":
+            vals = [int(v) << 240 for v in rng.integers(1, 1 << 13, size=n)]
+        else:
+            vals = [0 if i % 2 else int.from_bytes(rng.bytes(31), "little") for i in range(n)]
+        arr = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals), dtype=np.uint8).reshape(n, 32).copy()
+        d_s = torch.from_numpy(arr).to(dev)
+        want = eng.g1_batch_to_affine(eng.g1_msm_device(table, d_s.data_ptr(), n))
+        tot = sum(k * s for k, s in zip(ks, vals)) % O.R
+        assert want == O.aff_to_bytes(O.scalar_mul(tot, O.G1))
+        eng.bases_precompute(table, 20)
+        assert eng.g1_batch_to_affine(eng.g1_msm_device(table, d_s.data_ptr(), n)) == want
+        assert eng.g1_batch_to_affine(eng.g1_msm_device(table, d_s.data_ptr(), n - 70001)) == \
+            O.aff_to_bytes(O.scalar_mul(sum(k * s for k, s in zip(ks[:n - 70001], vals)) % O.R, O.G1))
+    finally:
+        eng.bases_free(table)
+
+
+def test_fixed_base_levels_refusals(eng, pkg):
+    """h2agg_bases_precompute: an explicit width whose levels outgrow the packed sort item is refused unless it is 20 (the
+    (level, point) sort's width); debug key pre_big lifts that for A/B runs through the two-array sort"""
+    dev = torch.device("cuda", 0)
+    n = (1 << 19) + 3
+    _ks, k_np = _workload(n, 191)
+    d_k = torch.from_numpy(k_np.copy()).to(dev)
+    table = eng.bases_generate(d_k.data_ptr(), n)
+    try:
+        with pytest.raises(pkg.H2AggError) as ei:
+            eng.bases_precompute(table, 16)
+        assert ei.value.code == pkg.ERR_INVALID
+        _v, s_np = _workload(n, 192)
+        d_s = torch.from_numpy(s_np.copy()).to(dev)
+        want = eng.g1_batch_to_affine(eng.g1_msm_device(table, d_s.data_ptr(), n))
+        eng.bases_precompute(table, 0)                       # auto: c = 20 here
+        assert eng.g1_batch_to_affine(eng.g1_msm_device(table, d_s.data_ptr(), n)) == want
+        eng.debug_configure("pre_big", 1)
+        try:
+            eng.bases_precompute(table, 19)                  # 14 levels through the two-array sort
+            assert eng.g1_batch_to_affine(eng.g1_msm_device(table, d_s.data_ptr(), n)) == want
+        finally:
+            eng.debug_configure("pre_big", 0)
+    finally:
+        eng.bases_free(table)
