@@ -9,15 +9,18 @@
 //
 //   level 1   k_fb_partition: a workgroup takes a tile of 2048 SCALARS (not keys of one window: all levels share the bucket
 //             space, so nothing separates them), recodes each into 13 digits in registers and orders the tile's 26 624 keys by
-//             partition (top 11 bits of the bucket) in 104 KiB of LDS: one returning LDS atomic per key; the tile goes back
-//             coalesced with its table of 2049 partition offsets.  item = low slot bits : 8 (10) | sign | level : 4 | scalar : 11
-//   level 2   k_fb_bucket_sort: one workgroup per partition (256 buckets) collects its ~13-key run from every tile and orders
-//             it by (bucket, LEVEL) in LDS — 3 328 counters, one atomic per key — then writes entries[] / hist[] / offs[] of its
-//             buckets.  entry = sign << 31 | level * n_level + point.
+//             partition in 104 KiB of LDS: one returning LDS atomic per key; the tile goes back coalesced with its table of
+//             2305 partition offsets.  item = low slot bits : 8 (10) | sign | level : 4 | scalar : 11          (0.12 ms at 2^22)
+//   level 2   k_fb_bucket_sort: one workgroup per partition (256 buckets) collects its ~12-key run from every tile and orders
+//             it by (bucket, level) in LDS — 3 328 counters, one atomic per key — then writes entries[] / hist[] / offs[] of its
+//             buckets.  entry = sign << 31 | level * n_level + point.                                          (0.39-0.42 ms)
 //
-// Level order inside a bucket is deliberate: the lanes of the accumulation start together and walk their ~104-entry runs at
-// the same pace, so at any moment most of the chip gathers from the same one or two levels (256 MiB each at 2^22 points: what
-// the Infinity Cache holds) instead of from all 3.5 GiB at random.
+// What bounds level 2 (profiles/r05_sweeps.txt section 1): 2 048 runs of ~50 bytes per workgroup, each its own memory
+// request; with every key's load in flight at once (LDS-DMA, below) a workgroup still waits ~14 us for them — the CU's
+// outstanding-request budget at HBM latency — and a 154-KiB workgroup has the CU to itself, so nothing hides it.
+// Entries of a bucket come out in level order; that was meant to keep the accumulation's gathers inside one or two levels at
+// a time, and measured as no gain (3.95 ms either way: every (level, point) is read exactly once per MSM, there is nothing
+// for a cache to keep) — it is simply the order the counters give.
 #pragma once
 #include "sort_kernels.hpp"
 
@@ -32,12 +35,11 @@ constexpr int FB_SUB_BITS = 8;                 // low bucket bits resolved in le
 constexpr uint32_t FB_SB = 1u << FB_SUB_BITS;
 constexpr uint32_t FB_PPW = FB_NB >> FB_SUB_BITS;   // 2048 partitions
 // The top digit has 14 bits (254 = 12 * 20 + 14): dropped into the same buckets it would put n / 2^14 extra entries into each
-// of the lowest 2^14 — 3.7 x the mean run, on lanes that then outlast the launch.  It gets bucket slots of its own instead:
-// value m of the top digit, scalar i -> slot FB_NB + 16 (m - 1) + (i & 15); k_fb_fold (msm_kernels.hpp) adds the sixteen parts
-// of value m into bucket m - 1 in front of the reduction (same weight).  Sixteen, because the slot count then is 3 x 2^18: the
-// accumulation runs one lane per slot, longest runs first, on 4 096 wave slots (256 CUs x 4 SIMDs x 4 waves of 128 VGPRs) of
-// 64 lanes — three full rounds, and a slot's three waves (long, medium, short) add up alike.  With 2^19 + 2^16 slots (2.25
-// rounds) the last quarter round ran on a quarter-full chip: 70.6 instead of 64.5 ns per million insertions.
+// of the lowest 2^14 — 3.7 x the mean run, on lanes that then outlast the launch (single 2^22-point MSM: accumulation 4.69 ms;
+// with the slots below 3.95).  It gets bucket slots of its own instead: value m of the top digit, scalar i -> slot
+// FB_NB + 16 (m - 1) + (i & 15); k_fb_fold (msm_kernels.hpp) adds the sixteen parts of value m into bucket m - 1 in front of
+// the reduction (same weight).  Sixteen parts make 3 x 2^18 slots = three full rounds of the chip's 4 096 wave slots; four
+// parts (2.25 rounds) measured the same within a box's noise — longest-first order already puts the shortest runs last.
 constexpr int FB_XPARTS_LOG = 4;
 constexpr uint32_t FB_XB = (1u << 14) << FB_XPARTS_LOG;          // extra slots (2^18)
 constexpr uint32_t FB_NBT = FB_NB + FB_XB;                        // bucket slots the accumulation walks

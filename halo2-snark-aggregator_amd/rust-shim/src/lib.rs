@@ -175,30 +175,55 @@ where
     C::ScalarExt: Sync,
 {
     let n = points.len().min(scalars.len());
+    // Small multi_exps — the ~350- and ~1 400-pair ones of an evaluation, every MockEccChip::multi_exp under the h2agg feature
+    // comes through here — stay on the calling thread: spawning and joining a thread per core costs tens of microseconds
+    // each, more than marshalling and formatting a few thousand points.
+    const INLINE_BELOW: usize = 1 << 14;
+    if points.len() < INLINE_BELOW {
+        let result = with_gpu(|g| {
+            g.reserve(n.max(1));
+            marshal_range::<C>(points, scalars, 0, n, SendPtr(g.points), SendPtr(g.scalars));
+            run_msm::<C>(g, n)
+        });
+        point_list.clear();
+        point_list.extend(points.iter().map(|x| format!("{:?}", x)));
+        return result;
+    }
     let workers = std::thread::available_parallelism().map(|v| v.get()).unwrap_or(1).saturating_sub(1).max(1);
     let chunk = ((points.len() + workers - 1) / workers).max(1);
     let nchunks = (points.len() + chunk - 1) / chunk;
-    let marshalled = std::sync::Barrier::new(nchunks + 1);
     let mut parts: Vec<Vec<String>> = Vec::new();
     let result = with_gpu(|g| {
         g.reserve(n.max(1));
         let (pb, sb) = (SendPtr(g.points), SendPtr(g.scalars));
         std::thread::scope(|s| {
+            // one channel message per marshalled chunk instead of a Barrier: a worker that panics before it reports (out of
+            // memory inside marshal_range, say) drops its sender, `recv` then fails on this thread and the panic is
+            // re-raised by the scope's join — with a Barrier this thread would have waited for it forever
+            let (tx, rx) = std::sync::mpsc::channel::<()>();
             let handles: Vec<_> = (0..nchunks)
                 .map(|w| {
-                    let marshalled = &marshalled;
+                    let tx = tx.clone();
                     s.spawn(move || {
                         let (lo, hi) = (w * chunk, ((w + 1) * chunk).min(points.len()));
                         marshal_range::<C>(points, scalars, lo.min(n), hi.min(n), pb, sb);
-                        marshalled.wait();
+                        let _ = tx.send(());
+                        drop(tx);
                         points[lo..hi].iter().map(|x| format!("{:?}", x)).collect::<Vec<String>>()
                     })
                 })
                 .collect();
-            marshalled.wait();
-            let r = run_msm::<C>(g, n); // the GPU call, under the formatting
-            parts = handles.into_iter().map(|h| h.join().expect("point_list worker")).collect();
-            r
+            drop(tx);
+            let mut marshalled = 0;
+            while marshalled < nchunks {
+                match rx.recv() {
+                    Ok(()) => marshalled += 1,
+                    Err(_) => break, // every sender is gone and a chunk is missing: a worker panicked; the joins below re-raise it
+                }
+            }
+            let r = if marshalled == nchunks { Some(run_msm::<C>(g, n)) } else { None }; // the GPU call, under the formatting
+            parts = handles.into_iter().map(|h| h.join().unwrap_or_else(|e| std::panic::resume_unwind(e))).collect();
+            r.expect("every chunk marshalled")
         })
     });
     point_list.clear();
