@@ -1088,7 +1088,12 @@ def main():
                 finally:
                     eng.bases_free(g4)
             if agg_info is not None and g_table is not None and args.agg_instance_log2 <= 18:
-                agg_info["from_bytes_sharded"] = from_bytes_sharded_leg(pkg, eng, args, rank, world, dist, (dev, coll_dev), g_table)
+                try:
+                    agg_info["from_bytes_sharded"] = from_bytes_sharded_leg(pkg, eng, args, rank, world, dist, (dev, coll_dev), g_table)
+                except Exception as ex:      # noqa: BLE001 - this leg must not cost the legs already measured
+                    import traceback
+                    traceback.print_exc()
+                    agg_info["from_bytes_sharded"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}
             if agg_info is not None and world == 1 and g_table is not None and args.agg_instance_log2 <= 18:
                 agg_info["full_pipeline"] = full_pipeline_leg(pkg, eng, args, g_table)
             if cpu_ctx is not None and rank == 0 and not args.no_cpu_baseline:

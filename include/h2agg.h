@@ -469,13 +469,18 @@ int h2agg_msm_configure_sort(h2agg_ctx* ctx, int sub_bits, int tile);
  *   H2AGG_NO_PLACE            skip the stream-placement probe of h2agg_create / h2agg_set_stream (needed when the caller's
  *                             stream is being graph-captured: the probe launches and synchronises)
  *   H2AGG_TRACE, H2AGG_TRACE_PHASES   diagnostics on stderr (schema evaluation / phases of h2agg_verify_aggregation)
+ *   H2AGG_PAIRING_PORTABLE    (any value) the host pairing in its portable build even on a CPU with BMI2 + ADX (A/B of the two
+ *                             instantiations of csrc/pairing.hpp; the pairing entry points take ctx = NULL, so this is not a key)
  * Test hooks, per context and per call (tests/ exercise code paths a production call reaches only by size):
  *   key "pcie_slices" n   cut h2agg_g1_msm's host buffers into n slices (0 = automatic)
  *       "pcie_glv" -1|0|1 GLV for those slices (0 = automatic)       "pcie_chain" 0|1  slices share one bucket set (default 1)
  *       "comb_msm" 0|1    small MSMs over tables with fixed-base levels take the comb (default 1)
  *       "plan_cache" 0|1  h2agg_verify_aggregation keeps the recording of a call shape (default 1)
  *       "small_sort" 0|1  MSMs of <= 16384 scalars sort in one launch (default 1; 0 = the packed two-level sort)
- *       "eval_split" 0|1  the two multi_exps of an evaluation run as one set of launches (default 1) */
+ *       "eval_split" 0|1  the two multi_exps of an evaluation run as one set of launches (default 1)
+ *       "lean_acc" 0|1    bucket accumulation through k_msm_accumulate_lean (default 1; 0 = the generic kernel: A/B on any box)
+ *       "pre_big" 0|1     h2agg_bases_precompute takes any explicit width (1: levels through the two-array sort, A/B only)
+ *       "shard_fail" 0|1|2  this rank of h2agg_verify_aggregation_sharded fails before (1) / between (2) its exchanges */
 int h2agg_debug_configure(h2agg_ctx* ctx, const char* key, int value);
 /* Overlap the latency-shaped tail of one MSM (enable = 1: the Horner kernel, one wave; 2: bucket reduction + window
  * sums + Horner; 3: as 2, and the bucket accumulation itself leaves the context's stream, so that the NEXT MSM's sort runs

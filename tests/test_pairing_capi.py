@@ -129,3 +129,24 @@ def _f2_sqrt(a):
             if E.f2_mul((x0, x1), (x0, x1)) == (a0 % p, a1 % p):
                 return (x0, x1)
     return None
+
+
+def test_adx_and_portable_builds_give_the_same_gt_element(lib, pkg):
+    """csrc/pairing.hpp is compiled twice (portable; BMI2 + ADX: another Montgomery product under every Fq12 operation) and
+    the process picks one from the CPU's feature bits — H2AGG_PAIRING_PORTABLE forces the portable one.  Same GT element,
+    byte for byte, from a child process running the other build."""
+    import subprocess
+    import sys
+    rng = O.SplitMix64(0xADC5)
+    a, b = rng.fr(), rng.fr()
+    pairs = [(O.scalar_mul(a, O.G1), E.g2_mul(b, E.G2)), (O.G1, E.G2)]
+    g1, g2 = enc(pairs)
+    out = C.create_string_buffer(384)
+    assert lib.h2agg_pairing_product(None, g1, g2, 2, out) == 0
+    code = ("import ctypes as C, sys, os; sys.path.insert(0, %r); import __graft_entry__ as e; lib = e.load_package().load_library(); "
+            "o = C.create_string_buffer(384); assert lib.h2agg_pairing_product(None, bytes.fromhex(%r), bytes.fromhex(%r), 2, o) == 0; "
+            "print(o.raw.hex())") % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), g1.hex(), g2.hex())
+    child = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, H2AGG_PAIRING_PORTABLE="1"), capture_output=True, text=True,
+                           timeout=300)
+    assert child.returncode == 0, child.stderr[-2000:]
+    assert child.stdout.strip().splitlines()[-1] == out.raw.hex()
