@@ -1148,7 +1148,10 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     static const bool defer_env_off = knob("H2AGG_DEFER_TAILS") && !strcmp(knob("H2AGG_DEFER_TAILS"), "0");
     // (and it only pays from 2^20 points on — measured, profiles/r02_sweeps.txt: below that the tail is a large share of the
     // MSM and wants to start at once; the two multi_exps of an evaluation in particular)
-    if (tails_off_stream && !defer_env_off && !(c->profiling && c->prof_only < 0) && n >= ((size_t)1 << 20)) {
+    // (not for the fixed-base levels of big tables: their sort's whole-CU workgroups collide with a tail either way — a tail always
+    // ends up beside some later MSM's sort, profiles/r05_sweeps.txt section 1(g) — and the batch of 16 x 2^22 measures 71.6 ms with
+    // the tail launched at once against 72.5 deferred)
+    if (tails_off_stream && !defer_env_off && !(c->profiling && c->prof_only < 0) && n >= ((size_t)1 << 20) && !fbdm) {
         c->deferred_tail = tail_fn;
     } else {
         TRY(tail_fn(false));
