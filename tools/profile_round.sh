@@ -30,6 +30,11 @@ for pair in "FETCH_SIZE fetch" "WRITE_SIZE write"; do
 done
 cd $root
 python tools/make_traffic_json.py $out/${tag} batch > $out/${tag}_batch_traffic.json 2>> $out/${tag}_traffic.err
+# the same batch's kernels (the levels' sort: k_fb_partition / k_fb_bucket_sort; accumulation; the 16-grid tail), and the ordinary path beside it
+cd /tmp && rm -rf /tmp/prof_fb && rocprofv3 --kernel-trace --stats -d /tmp/prof_fb -o fb -- python $root/tools/fixed_base_big.py 22 --fixed-only > $out/${tag}_fb_batch.txt 2>/dev/null
+python $root/tools/rocpd_summary.py /tmp/prof_fb/fb_results.db > $out/${tag}_fb_kernel_stats.txt 2>&1
+python $root/tools/r05_batch.py 22 16 > $out/${tag}_fb_vs_ordinary.txt 2>/dev/null
+cd $root
 # batch kernels at n = 2^22 (HBM roofline rows)
 cd /tmp && rm -rf /tmp/prof_b && rocprofv3 --kernel-trace --stats -d /tmp/prof_b -o b -- python $root/tools/batch_roofline.py run > /dev/null 2>&1
 python $root/tools/rocpd_summary.py /tmp/prof_b/b_results.db > $out/${tag}_batch_kernel_stats.txt 2>&1
