@@ -16,6 +16,17 @@
 // needs a broadcast.  Partial rounds run in the scaled form of Spec::scale_partial_rounds (csrc/poseidon_host.hpp), like the
 // device kernel: per round  z = w^5;  shat += A_k z;  w <- z + D_k + sum_i R_{k,i} shat_i  (the sum uses the shat of BEFORE the
 // update and is off the w -> z -> w chain).
+//
+// Round 5: the chain of the partial rounds leaves the vectors.  A permutation's latency is its 63 partial rounds' w -> w^5 -> w
+// chain, three dependent products per round, and a vector product here is ~90 cycles deep (25 + 25 multiply-adds into ten
+// accumulators, a word-serial reduction, carries) however wide it is.  The chain is ONE element: it now runs on the scalar
+// unit — 4 x 64-bit "no-carry" CIOS over mulx with two carry chains (BMI2 + ADX; the arithmetic of csrc/pairing.hpp's second
+// build), values kept below 2 r without any conditional subtraction inside w^5 (r / 2^256 = 0.19: inputs < 2 r give
+// < (4 x 0.19 + 1) r) — while everything that is eight wide (shat += A_k z; D_k + sum_i R_{k,i} shat_i) stays on IFMA beside
+// it, off the chain.  The two Montgomery radices (2^256 there, 2^260 here) meet in the constants: R_k and D_k are stored
+// divided by 16, so the sum comes out of the vector reduction in the scalar side's form; A_k and beta_63 multiplied by 16, so
+// the scalar z goes into the vector products as it is.  Same integers at the end (tests/test_host_sponge.py: both kernels
+// against each other and against the oracle).  17.5 -> ~8 us per permutation on the build container's Xeon.
 #pragma once
 #if !defined(__HIP_DEVICE_COMPILE__) && (defined(__x86_64__) || defined(_M_X64))
 #define H2AGG_HAVE_IFMA_BUILD 1
@@ -27,8 +38,8 @@ namespace h2agg {
 namespace poseidon_host {
 namespace ifma {
 
-#define IFMA_FN __attribute__((target("avx512f,avx512ifma,avx512vl,avx512dq,avx512bw"), always_inline)) static inline
-#define IFMA_BIG __attribute__((target("avx512f,avx512ifma,avx512vl,avx512dq,avx512bw"), noinline)) static
+#define IFMA_FN __attribute__((target("avx512f,avx512ifma,avx512vl,avx512dq,avx512bw,bmi2,adx"), always_inline)) static inline
+#define IFMA_BIG __attribute__((target("avx512f,avx512ifma,avx512vl,avx512dq,avx512bw,bmi2,adx"), noinline)) static
 
 struct V5 {
     __m512i l[5];
@@ -75,8 +86,12 @@ struct Consts {
         uint64_t col[9][5][8], row0[5][8], m00[5][8];
     } mds, pre;
     // scaled partial rounds
-    std::vector<std::array<uint64_t, 40>> R, A, D;   // [k][5][8]: R_k lanes, A_k lanes, D_k replicated
-    uint64_t finBeta[5][8], finCum[5][8];
+    // [k][5][8]: R_k / 16 lanes, 16 A_k lanes, D_k / 16 replicated — the factors of 16 = 2^260 / 2^256 that let the scalar chain
+    // (Montgomery radix 2^256) and the vectors (2^260) exchange values without a conversion product (header)
+    std::vector<std::array<uint64_t, 40>> R, A;   // [k][5][8]: 2^56 R_k lanes (see dot_words), 16 A_k lanes
+    std::vector<HFr> Dk, Ck;                      // D_k; 2^64 <R_k, A_{k-1}> (C_0 = 0): scalar side's Montgomery form
+    uint64_t finBeta[5][8], finCum[5][8];    // 16 beta_63 replicated; cum lanes
+    HFr two252;                              // the integer 2^252 in plain words: (w 2^260)(2^252) / 2^256 = w 2^256
     int h = 0, r_p = 0;
     bool ok = false;
 
@@ -129,18 +144,23 @@ struct Consts {
         };
         dense(s.mds, mds);
         dense(s.pre_sparse, pre);
+        const uint64_t w16[4] = {16, 0, 0, 0}, w56[4] = {(uint64_t)1 << 56, 0, 0, 0}, w64[4] = {0, 1, 0, 0};
+        const HFr f16 = from_words(w16), f56 = from_words(w56), f64 = from_words(w64);
         for (int k = 0; k < r_p; ++k) {
-            std::array<uint64_t, 40> r{}, a{}, d{};
+            std::array<uint64_t, 40> r{}, a{};
+            HFr ck = zero();
             for (int i = 0; i < 8; ++i) {
-                put_lane((uint64_t(*)[8])r.data(), i, s.ps_r[k][i]);
-                put_lane((uint64_t(*)[8])a.data(), i, s.ps_a[k][i]);
+                put_lane((uint64_t(*)[8])r.data(), i, mul(s.ps_r[k][i], f56));
+                put_lane((uint64_t(*)[8])a.data(), i, mul(s.ps_a[k][i], f16));
+                if (k) ck = add(ck, mul(s.ps_r[k][i], s.ps_a[k - 1][i]));
             }
-            put_all((uint64_t(*)[8])d.data(), s.ps_d[k]);
             R.push_back(r);
             A.push_back(a);
-            D.push_back(d);
+            Dk.push_back(s.ps_d[k]);
+            Ck.push_back(mul(ck, f64));
         }
-        put_all(finBeta, s.ps_fin[0]);
+        put_all(finBeta, mul(s.ps_fin[0], f16));
+        two252 = HFr{{0, 0, 0, (uint64_t)1 << 60}};
         for (int i = 0; i < 8; ++i) put_lane(finCum, i, s.ps_fin[i + 1]);
         ok = true;
     }
@@ -290,6 +310,140 @@ IFMA_BIG void dense(const Consts::Dense& M, V5& W, V5& V, const Consts& C) {
     W = Wn;
 }
 
+// ---- the scalar side of the partial rounds: 4 x 64-bit Montgomery (radix 2^256), values < 4 r, no final subtraction -----
+// a * b / 2^256 mod r for a, b < 4 r < 2^256: result < a b / 2^256 + r  (the running sum stays below b + r < 2^256)
+IFMA_FN HFr smul_lazy(const HFr& a, const HFr& b) {
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, A, Cw, hi, lo, m;
+    unsigned char c1, c2;
+#pragma GCC unroll 4
+    for (int i = 0; i < 4; ++i) {
+        lo = _mulx_u64(a.l[i], b.l[0], &hi); c1 = _addcarry_u64(0, lo, t0, &t0); A = hi;
+        lo = _mulx_u64(a.l[i], b.l[1], &hi); c2 = _addcarry_u64(0, lo, A, &lo); A = hi; c1 = _addcarry_u64(c1, lo, t1, &t1);
+        lo = _mulx_u64(a.l[i], b.l[2], &hi); c2 = _addcarry_u64(c2, lo, A, &lo); A = hi; c1 = _addcarry_u64(c1, lo, t2, &t2);
+        lo = _mulx_u64(a.l[i], b.l[3], &hi); c2 = _addcarry_u64(c2, lo, A, &lo); A = hi; c1 = _addcarry_u64(c1, lo, t3, &t3);
+        _addcarry_u64(c2, A, 0, &A);
+        _addcarry_u64(c1, A, 0, &A);
+        m = t0 * R_INV;
+        lo = _mulx_u64(m, R_MOD[0], &hi); c2 = _addcarry_u64(0, lo, t0, &lo); Cw = hi;
+        lo = _mulx_u64(m, R_MOD[1], &hi); c2 = _addcarry_u64(c2, Cw, lo, &lo); Cw = hi; c1 = _addcarry_u64(0, lo, t1, &t0);
+        lo = _mulx_u64(m, R_MOD[2], &hi); c2 = _addcarry_u64(c2, Cw, lo, &lo); Cw = hi; c1 = _addcarry_u64(c1, lo, t2, &t1);
+        lo = _mulx_u64(m, R_MOD[3], &hi); c2 = _addcarry_u64(c2, Cw, lo, &lo); Cw = hi; c1 = _addcarry_u64(c1, lo, t3, &t2);
+        _addcarry_u64(c2, Cw, 0, &Cw);
+        _addcarry_u64(c1, Cw, A, &t3);
+    }
+    return HFr{{t0, t1, t2, t3}};
+}
+// a + b (no overflow by the callers' bounds), then - 2 r if that does not go negative: a + b < 4 r -> result < 2 r
+IFMA_FN HFr sadd_csub2r(const HFr& a, const HFr& b) {
+    static const uint64_t R2[4] = {0x87c3eb27e0000002ull, 0x5067d090f372e122ull, 0x70a08b6d0302b0baull, 0x60c89ce5c2634053ull};   // 2 r
+    unsigned long long s0, s1, s2, s3, d0, d1, d2, d3;
+    unsigned char c = _addcarry_u64(0, a.l[0], b.l[0], &s0);
+    c = _addcarry_u64(c, a.l[1], b.l[1], &s1);
+    c = _addcarry_u64(c, a.l[2], b.l[2], &s2);
+    (void)_addcarry_u64(c, a.l[3], b.l[3], &s3);
+    unsigned char bw = _subborrow_u64(0, s0, R2[0], &d0);
+    bw = _subborrow_u64(bw, s1, R2[1], &d1);
+    bw = _subborrow_u64(bw, s2, R2[2], &d2);
+    bw = _subborrow_u64(bw, s3, R2[3], &d3);
+    const uint64_t keep = (uint64_t)0 - (uint64_t)bw;   // borrowed: the sum was below 2 r, keep it
+    return HFr{{(s0 & keep) | (d0 & ~keep), (s1 & keep) | (d1 & ~keep), (s2 & keep) | (d2 & ~keep), (s3 & keep) | (d3 & ~keep)}};
+}
+// The dot product <R_k, shat> of a partial round leaves the vectors UNREDUCED: ten 64-bit accumulators per lane, summed over
+// the lanes (hsum), lane 0 read out and packed into nine 64-bit words here; the scalar side adds its own share to it and
+// reduces once, by 2^320 (five word steps: the vectors' lazily reduced inputs make the sum up to ~2^515, and 2^-320 brings any
+// of that below 1.01 r).  The powers of two are in the constants: R_k x 2^56 in the vectors (2^56 R'^2 = R 2^320), C_k x 2^64.
+IFMA_FN void acc10_lane0_words(const A10& a, uint64_t T[9]) {
+    unsigned __int128 carry = 0;
+    uint64_t t[10];
+    for (int i = 0; i < 10; ++i) t[i] = (uint64_t)_mm_cvtsi128_si64(_mm512_castsi512_si128(a.t[i]));
+    // word j collects the bits [64 j, 64 j + 64) of sum_i t[i] 2^(52 i)
+#pragma GCC unroll 9
+    for (int j = 0; j < 9; ++j) {
+        unsigned __int128 v = carry;
+#pragma GCC unroll 10
+        for (int i = 0; i < 10; ++i) {
+            const int lo = 52 * i - 64 * j;          // position of t[i]'s bit 0 relative to word j
+            if (lo >= 64 || lo <= -64) continue;
+            if (lo >= 0) v += (uint64_t)(t[i] << lo);   // (its bits above the word are the next word's `>>` share)
+            else v += (unsigned __int128)(t[i] >> (-lo));
+        }
+        T[j] = (uint64_t)v;
+        carry = v >> 64;
+    }
+}
+// T += a * b  (4 x 4 words into nine)
+IFMA_FN void wide_mul_add(uint64_t T[9], const HFr& a, const HFr& b) {
+#pragma GCC unroll 4
+    for (int i = 0; i < 4; ++i) {
+        unsigned long long hi, lo, c = 0;
+        unsigned char cy;
+#pragma GCC unroll 4
+        for (int j = 0; j < 4; ++j) {
+            lo = _mulx_u64(a.l[i], b.l[j], &hi);
+            cy = _addcarry_u64(0, lo, c, &lo);
+            hi += cy;                                   // (hi <= 2^64 - 2: no overflow)
+            unsigned long long tt;
+            cy = _addcarry_u64(0, T[i + j], lo, &tt);
+            T[i + j] = tt;
+            c = hi + cy;
+        }
+        unsigned long long tt;
+        cy = _addcarry_u64(0, T[i + 4], c, &tt);
+        T[i + 4] = tt;
+        for (int k = i + 5; cy && k < 9; ++k) {
+            cy = _addcarry_u64(cy, T[k], 0, &tt);
+            T[k] = tt;
+        }
+    }
+}
+// T / 2^320 mod r for T < 2^520: < T / 2^320 + r < 1.01 r
+IFMA_FN HFr redc5(uint64_t T[9]) {
+#pragma GCC unroll 5
+    for (int i = 0; i < 5; ++i) {
+        const unsigned long long m = T[i] * R_INV;
+        unsigned long long hi, lo, c = 0, tt;
+        unsigned char cy;
+#pragma GCC unroll 4
+        for (int j = 0; j < 4; ++j) {
+            lo = _mulx_u64(m, R_MOD[j], &hi);
+            cy = _addcarry_u64(0, lo, c, &lo);
+            hi += cy;
+            cy = _addcarry_u64(0, T[i + j], lo, &tt);
+            T[i + j] = tt;
+            c = hi + cy;
+        }
+        cy = _addcarry_u64(0, T[i + 4], c, &tt);
+        T[i + 4] = tt;
+        for (int k = i + 5; k < 9; ++k) {
+            cy = _addcarry_u64(cy, T[k], 0, &tt);
+            T[k] = tt;
+        }
+    }
+    return HFr{{T[5], T[6], T[7], T[8]}};
+}
+IFMA_FN HFr sadd(const HFr& a, const HFr& b) {   // no overflow by the callers' bounds
+    unsigned long long s0, s1, s2, s3;
+    unsigned char c = _addcarry_u64(0, a.l[0], b.l[0], &s0);
+    c = _addcarry_u64(c, a.l[1], b.l[1], &s1);
+    c = _addcarry_u64(c, a.l[2], b.l[2], &s2);
+    (void)_addcarry_u64(c, a.l[3], b.l[3], &s3);
+    return HFr{{s0, s1, s2, s3}};
+}
+// lane 0 of a vector value (< 2^256) as 4 x 64-bit words / a 4-word value (< 2^256) replicated into every lane's five limbs
+IFMA_FN HFr lane0_words(const V5& v) {
+    uint64_t l[5], w[4];
+    for (int i = 0; i < 5; ++i) l[i] = (uint64_t)_mm_cvtsi128_si64(_mm512_castsi512_si128(v.l[i]));
+    limbs_to_words(l, w);
+    return HFr{{w[0], w[1], w[2], w[3]}};
+}
+IFMA_FN V5 bcast_words(const HFr& a) {
+    uint64_t l[5];
+    words_to_limbs(a.l, l);
+    V5 r;
+    for (int i = 0; i < 5; ++i) r.l[i] = _mm512_set1_epi64((long long)l[i]);
+    return r;
+}
+
 struct State {
     V5 W, V;
 };
@@ -314,25 +468,44 @@ IFMA_BIG void permute(const Consts& C, State& S, const V5& IN, int n_in) {
         V = pow5_plus(V, load5((const uint64_t(*)[8])C.startV[k - 1].data()), C);
         dense(k < C.h ? C.mds : C.pre, W, V, C);
     }
-    // partial rounds, scaled: W = w (s0 = beta_k w), V = shat
+    // partial rounds, scaled: w (s0 = beta_k w) on the scalar unit in radix-2^256 Montgomery form, < 2 r; V = shat
+    // (w arrives from a vector reduction: < 2 r < 2^256; times 2^252 / 2^256 takes the 16 out of its radix)
+    HFr w = smul_lazy(lane0_words(W), C.two252);
+    // With S_k = shat before round k:  e_k = D_k + <R_k, S_k> = D_k + <R_k, S_{k-1}> + <R_k, A_{k-1}> z_{k-1}: the vectors' share
+    // of e_k only needs S_{k-1}, a whole round earlier than z_{k-1} exists (pre, carried from the previous iteration); the
+    // last-minute share is ONE scalar product with a constant.  So the vectors never sit on the w -> w^5 -> w chain.
+    uint64_t pre[9];
+    {
+        A10 d = zero10();
+        mul_acc(d, load5((const uint64_t(*)[8])C.R[0].data()), V);
+        hsum(d);
+        acc10_lane0_words(d, pre);
+    }
+    HFr zprev = HFr{{0, 0, 0, 0}};
 #pragma GCC unroll 1
     for (int k = 0; k < C.r_p; ++k) {
-        A10 d = zero10();
-        mul_acc(d, load5((const uint64_t(*)[8])C.R[k].data()), V);
-        hsum(d);
-        add_shifted(d, load5((const uint64_t(*)[8])C.D[k].data()));
-        const V5 e = redc(d, C);                   // D_k + sum_i R_{k,i} shat_i   (off the chain)
-        const V5 z = pow5(W, C);
-        W = vadd(z, e);
+        wide_mul_add(pre, C.Ck[k], zprev);         // + 2^64 <R_k, A_{k-1}> z_{k-1}   (C_0 = 0)
+        const HFr e = sadd(redc5(pre), C.Dk[k]);   // D_k + <R_k, S_k>, < 2.01 r
+        if (k + 1 < C.r_p) {                       // the vectors' share of e_{k+1}: from S_k, before z_k is known
+            A10 d = zero10();
+            mul_acc(d, load5((const uint64_t(*)[8])C.R[k + 1].data()), V);
+            hsum(d);
+            acc10_lane0_words(d, pre);
+        }
+        const HFr w2 = smul_lazy(w, w);            // < 1.76 r
+        const HFr w4 = smul_lazy(w2, w2);          // < 1.6 r
+        const HFr z = smul_lazy(w4, w);            // w^5 < 1.6 r
+        w = sadd_csub2r(z, e);                     // < 3.7 r before, < 2 r after
+        zprev = z;
         A10 u = zero10();
-        mul_acc(u, load5((const uint64_t(*)[8])C.A[k].data()), z);
+        mul_acc(u, load5((const uint64_t(*)[8])C.A[k].data()), bcast_words(z));
         add_shifted(u, V);
-        V = redc(u, C);                            // shat_i + A_{k,i} z
+        V = redc(u, C);                            // S_{k+1} = S_k + A_k z_k
         // a reduction only promises "< exact + r": with shat folded into the product the slack would add up round after
         // round (65 r < 2^260 at the end, too close); a multiplication by one every 16 rounds resets it
         if ((k & 15) == 15) V = vmul(V, load5(C.oneV), C);
     }
-    W = vmul(W, load5(C.finBeta), C);              // s0 = beta_63 w
+    W = vmul(bcast_words(w), load5(C.finBeta), C); // s0 = beta_63 w, back in the vectors' form
     V = vadd(V, load5(C.finCum));                  // s_i = shat_i + cum_i
     for (size_t k = 0; k < C.endV.size(); ++k) {
         W = pow5_plus(W, load5((const uint64_t(*)[8])C.endW[k].data()), C);
@@ -347,7 +520,7 @@ IFMA_BIG void permute(const Consts& C, State& S, const V5& IN, int n_in) {
 }
 
 // the sponge over one element stream (see sponge_run in poseidon_sponge_host.hpp)
-__attribute__((target("avx512f,avx512ifma,avx512vl,avx512dq,avx512bw"))) static bool sponge_run(
+__attribute__((target("avx512f,avx512ifma,avx512vl,avx512dq,avx512bw,bmi2,adx"))) static bool sponge_run(
     const Consts& C, const uint8_t* elems, const uint32_t* upto, uint32_t nsq, uint8_t* out) {
     State S;
     {
@@ -413,7 +586,8 @@ __attribute__((target("avx512f,avx512ifma,avx512vl,avx512dq,avx512bw"))) static 
 
 static inline bool cpu_has_ifma() {
     return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512ifma") && __builtin_cpu_supports("avx512vl") &&
-           __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512bw");
+           __builtin_cpu_supports("avx512dq") && __builtin_cpu_supports("avx512bw") && __builtin_cpu_supports("bmi2") &&
+           __builtin_cpu_supports("adx");
 }
 
 }  // namespace ifma
