@@ -19,7 +19,7 @@ def main(path):
     # traced duration is mostly waiting for wave slots / issue cycles, not work.  They are marked '*' and left out of the
     # percentage column; `min_us` is what they take when they get the machine (DESIGN.md section 5 has the alone figures).
     waiting = ("k_msm_accumulate_big", "k_msm_accumulate_fix", "k_msm_big_combine", "k_msm_final", "k_msm_final_lp", "k_msm_reduce2d_parts", "k_msm_reduce2d_window",
-               "k_msm_reduce_segments", "k_msm_window_sum", "k_msm_bucket_combine")
+               "k_msm_reduce_segments", "k_msm_window_sum", "k_msm_bucket_combine", "k_fb_fold", "k_fb_wsum")
     def waits(name):
         base = name.split("(")[0].replace("void ", "").replace("h2agg::", "").split("<")[0]
         return base in waiting
