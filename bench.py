@@ -672,21 +672,29 @@ def from_bytes_sharded_leg(pkg, eng, args, rank, world, dist, devs, g_table):
     s_g2 = g2
     try:
         allgather, transport = None, None
+        rccl_how = "the context's RCCL communicator (ncclAllGather inside the C ABI: 4 + 36 N bytes and 132 bytes per rank)"
         if dist is not None and dist.get_backend() != "nccl":
             allgather = ver.dist_allgather(dist)
             transport = "torch.distributed (%s) through the C ABI's allgather callback — control-flow mode, not RCCL" % dist.get_backend()
+        elif dist is None:
+            if eng.comm_size() == 0:                             # one GPU: a one-rank communicator
+                eng.comm_init_rank(pkg.H2Agg.comm_unique_id(), 0, 1)
+            transport = rccl_how
         else:
-            if eng.comm_size() == 0:                             # (the aggregation leg sets the communicator up when it can)
-                uid = torch.zeros(128, dtype=torch.uint8, device=coll_dev)
-                if rank == 0:
-                    uid = torch.frombuffer(bytearray(pkg.H2Agg.comm_unique_id()), dtype=torch.uint8).to(coll_dev)
-                if dist is not None:
-                    dist.broadcast(uid, src=0)
-                eng.comm_init_rank(bytes(uid.cpu().numpy().tobytes()), rank, world)
-            if eng.comm_size() != world or eng.comm_rank() != rank:
-                raise SystemExit("rank %d: h2agg communicator reports rank %d of %d, launch says %d of %d"
-                                 % (rank, eng.comm_rank(), eng.comm_size(), rank, world))
-            transport = "the context's RCCL communicator (ncclAllGather inside the C ABI: 4 + 36 N bytes and 132 bytes per rank)"
+            # the aggregation leg set the library's communicator up when it could; whether THIS leg uses it is decided by all
+            # ranks together (a rank without one must not be left alone in a collective)
+            have = 1 if (eng.comm_size() == world and eng.comm_rank() == rank) else 0
+            flag = torch.tensor([have], dtype=torch.int32, device=coll_dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                transport = rccl_how
+            else:
+                allgather = ver.dist_allgather(dist, device=coll_dev)
+                transport = ("torch.distributed (nccl = RCCL) through the C ABI's allgather callback: the library's own communicator "
+                             "was not available on every rank")
+        if allgather is None and (eng.comm_size() != world or eng.comm_rank() != rank):
+            raise SystemExit("rank %d: h2agg communicator reports rank %d of %d, launch says %d of %d"
+                             % (rank, eng.comm_rank(), eng.comm_size(), rank, world))
         gidx = list(range(rank, n_total, world))
         sets = [[(vk, "syn", g_table, [proofs_all[b * n_total + g] for g in gidx])] for b in range(2)]
 
