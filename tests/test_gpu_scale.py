@@ -362,6 +362,11 @@ def test_fixed_base_levels_c20_skewed_scalars(eng, kind):
         assert want == O.aff_to_bytes(O.scalar_mul(tot, O.G1))
         eng.bases_precompute(table, 20)
         assert eng.g1_batch_to_affine(eng.g1_msm_device(table, d_s.data_ptr(), n)) == want
+        eng.msm_configure_lanes_per_bucket(2)            # every slot's run on two lanes + the slice combine, then the fold
+        try:
+            assert eng.g1_batch_to_affine(eng.g1_msm_device(table, d_s.data_ptr(), n)) == want
+        finally:
+            eng.msm_configure_lanes_per_bucket(0)
         assert eng.g1_batch_to_affine(eng.g1_msm_device(table, d_s.data_ptr(), n - 70001)) == \
             O.aff_to_bytes(O.scalar_mul(sum(k * s for k, s in zip(ks[:n - 70001], vals)) % O.R, O.G1))
     finally:
