@@ -275,3 +275,21 @@ def test_a_partial_pair_off_the_curve_is_refused(eng, pkg):
     out = run_threads_collecting(pkg, setup, circuits, 2, wrap_exchange=wrap)
     for rank, res in enumerate(out):
         assert isinstance(res, pkg.H2AggError) and res.code == pkg.ERR_BAD_POINT, (rank, res)
+
+
+@pytest.mark.parametrize("world,mode", [(2, "ok"), (3, "ok"), (2, "fail1"), (3, "fail2")])
+def test_sharded_over_rccl_transport_with_threads_as_ranks(tmp_path, world, mode):
+    """shard->allgather = NULL at world > 1 on one GPU: the library's own transport (h2agg_comm_init_rank + ncclAllGather inside
+    the C ABI, csrc/verifier.inc shard_allgather) with threads as ranks and tests/cpp/rccl_stub.cpp standing in for RCCL (the
+    real one refuses two ranks on one device) — see tests/rccl_stub_ranks.py, which runs in a child process that never loads
+    torch's RCCL."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hipcc = "/opt/rocm/bin/hipcc" if os.path.exists("/opt/rocm/bin/hipcc") else "hipcc"
+    stub = str(tmp_path / "librccl.so.1")
+    subprocess.run([hipcc, "-O1", "-shared", "-fPIC", "-Wl,-soname,librccl.so.1", os.path.join(root, "tests", "cpp", "rccl_stub.cpp"), "-o", stub],
+                   check=True, capture_output=True, text=True)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "rccl_stub_ranks.py"), stub, str(world), mode], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0 and "RCCL-STUB-RANKS-OK" in r.stdout, r.stdout[-3000:] + r.stderr[-3000:]
