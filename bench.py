@@ -269,7 +269,9 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
     comm, exchange_how = None, "none (1 rank)"
     if dist is not None:
         exchange_how = "torch.distributed all_gather of 128 B per rank + local EC adds (h2agg_g1_sum)"
-        if dist.get_backend() == "nccl":
+        if dist.get_backend() == "nccl" or os.environ.get("H2AGG_RCCL_LIB"):
+            # (H2AGG_RCCL_LIB under gloo: the one-GPU rehearsal — the library's communicator over tests/cpp/rccl_stub.cpp,
+            # ranks as processes sharing the device; `transport` / `exchange` carry the library's path, `rccl_ranks` = world)
             ok = 1
             try:
                 if eng.comm_size() == 0:
@@ -437,6 +439,7 @@ def aggregation_leg(pkg, eng, args, rank, world, dist, devs, g_table):
         "final_pair_sha": __import__("hashlib").sha256(pair[0] + pair[1]).hexdigest()[:16],
         "exchange": exchange_how,
         "rccl_ranks": eng.comm_size() if comm is not None else 0,   # ranks of the C-ABI communicator the exchange ran on (0 = not used)
+        "rccl_library": os.environ.get("H2AGG_RCCL_LIB") or "librccl.so.1 (the process's own)",
         "one_rank_recomputation": one_rank,
         "roofline": hbm,
         "proofs_per_gpu": args.agg_proofs,
@@ -673,7 +676,7 @@ def from_bytes_sharded_leg(pkg, eng, args, rank, world, dist, devs, g_table):
     try:
         allgather, transport = None, None
         rccl_how = "the context's RCCL communicator (ncclAllGather inside the C ABI: 4 + 36 N bytes and 132 bytes per rank)"
-        if dist is not None and dist.get_backend() != "nccl":
+        if dist is not None and dist.get_backend() != "nccl" and not os.environ.get("H2AGG_RCCL_LIB"):
             allgather = ver.dist_allgather(dist)
             transport = "torch.distributed (%s) through the C ABI's allgather callback — control-flow mode, not RCCL" % dist.get_backend()
         elif dist is None:
@@ -738,6 +741,7 @@ def from_bytes_sharded_leg(pkg, eng, args, rank, world, dist, devs, g_table):
         return {"proofs_per_sec": n_total / lat["p50_s"], "proofs": n_total, "proofs_per_gpu": args.agg_proofs,
                 "seconds_per_aggregation": lat["p50_s"], "latency": lat, "p95_over_p50": lat["p95_s"] / lat["p50_s"],
                 "rccl_ranks": eng.comm_size() if allgather is None else 0, "transport": transport,
+                "rccl_library": os.environ.get("H2AGG_RCCL_LIB") or "librccl.so.1 (the process's own)",
                 "final_pair_sha": hashlib.sha256(first[0][0] + first[0][1]).hexdigest()[:16],
                 "lambda_sha": hashlib.sha256(first[0][2]).hexdigest()[:16],
                 "equals_one_context_call": "rank 0's h2agg_verify_aggregation over all %d proofs gives every rank's pair, lambda and verdict (both sets)" % n_total,
@@ -1065,7 +1069,7 @@ def main():
             if agg_info is not None and more is not None:
                 # BASELINE.json configs[3]: 4 proofs per GPU (32 at 8 GPUs) — this leg under the config's name
                 agg_info["config3"] = {k: agg_info.get(k) for k in ("proofs", "proofs_per_gpu", "proofs_per_sec", "seconds_per_aggregation",
-                                                                   "rccl_ranks", "final_pair_sha", "one_rank_recomputation", "roofline",
+                                                                   "rccl_ranks", "rccl_library", "final_pair_sha", "one_rank_recomputation", "roofline",
                                                                    "instance_msm_points_per_proof", "exchange")}
             if agg_info is not None and args.agg_config4 and args.agg_instance_log2 < 20:
                 # BASELINE.json configs[4]: 16 proofs per GPU of a k = 22 circuit's shape (2^22 - 6 instance scalars per proof,
@@ -1099,6 +1103,9 @@ def main():
                 try:
                     agg_info["from_bytes_sharded"] = from_bytes_sharded_leg(pkg, eng, args, rank, world, dist, (dev, coll_dev), g_table)
                 except Exception as ex:      # noqa: BLE001 - this leg must not cost the legs already measured
+                    # (the LAST leg with collectives: nothing after it can pair up with a collective a peer is still in.  A
+                    # failure inside the library reaches every rank — the exchanges' status words — so the ranks leave
+                    # together; a Python error on one rank alone leaves its peers to the watchdog above.)
                     import traceback
                     traceback.print_exc()
                     agg_info["from_bytes_sharded"] = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:300])}

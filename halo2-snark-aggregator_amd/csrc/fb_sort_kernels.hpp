@@ -131,7 +131,12 @@ __global__ void __launch_bounds__(FB_TB1) k_fb_partition(const uint8_t* __restri
     uint32_t pr[SPT * FB_W];   // partition << 16 | rank inside (tile, partition); 0xffffffff: no key
 #pragma unroll
     for (int j = 0; j < SPT; ++j) {
-        if (live[j]) bad |= !u256_is_canonical_fr(s[j]);
+        // a scalar >= r is refused by the call (FLAG_NONCANONICAL) and must not reach the digit loops: with bits 254 / 255
+        // set its top digit exceeds 2^14 and names a partition past FB_NPART — LDS counters out of bounds
+        if (live[j] && !u256_is_canonical_fr(s[j])) {
+            bad = 1;
+            live[j] = false;
+        }
         if (!live[j]) {
 #pragma unroll
             for (int w = 0; w < FB_W; ++w) pr[j * FB_W + w] = 0xffffffffu;

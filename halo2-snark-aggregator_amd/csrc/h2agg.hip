@@ -163,7 +163,7 @@ struct h2agg_ctx {
     int comm_rank = 0, comm_size = 0;
 
     // h2agg_debug_configure: test hooks read per call (chained host-buffer slices, comb route, plan cache)
-    int dbg_pcie_slices = 0, dbg_pcie_glv = 0, dbg_pcie_chain = 1, dbg_comb_msm = 1, dbg_plan_cache = 1, dbg_small_sort = 1, dbg_eval_split = 1, dbg_pre_big = 0, dbg_lean_acc = 1, dbg_shard_fail = 0;
+    int dbg_pcie_slices = 0, dbg_pcie_glv = 0, dbg_pcie_chain = 1, dbg_comb_msm = 1, dbg_plan_cache = 1, dbg_small_sort = 1, dbg_eval_split = 1, dbg_pre_big = 0, dbg_lean_acc = 1, dbg_shard_fail = 0, dbg_shard_calls = 0;
     // tuning
     int cfg_c = 0, cfg_seg = 0, cfg_big = 0, cfg_sub_bits = 0, cfg_tile = 0;
     int cfg_glv = 0;   // 0 = auto, 1 = on, -1 = off
@@ -568,6 +568,12 @@ bool msm_split_ok(const h2agg_ctx* c, size_t n_total) {
 // one-launch sort takes (msm_split_ok): the evaluation's two multi_exps.  When the plan (make_plan(c, n_base, 2)) uses GLV,
 // d_scalars are glv_decompose() words and d_endo_x is given (k_eval_prep wrote both); the tail stays on the context's
 // stream — nothing follows that it could hide under, and a stream hand-over costs 10-20 us each way.
+// the (level, point) sort of fb_sort_kernels.hpp has no sort / segment knobs: a context configured with any
+// (h2agg_msm_configure_sort, reduce_segment) does not take it
+bool fb_sort_knobs_clear(const h2agg_ctx* c) {
+    return !c->cfg_no_dm && !c->cfg_no_stage && !c->cfg_stage_l1 && !c->cfg_sub_bits && !c->cfg_tile && !c->cfg_seg;
+}
+
 int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size_t n_base, uint8_t* d_out_jac,
             uint32_t batch = 1, const uint8_t* d_endo_x = nullptr, const PreTable* pre = nullptr, uint32_t split = 0) {
     if (split) batch = 2;
@@ -585,7 +591,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     int Wd = p.W;                             // digit positions per scalar (what the recoding loops over)
     // fixed-base levels at c = 20 (tables of 2^18 .. 2^22 points): the (level, point) sort of fb_sort_kernels.hpp
     const bool fbdm = pre && batch == 1 && pre->c == FB_C && pre->W == FB_W && pre->n_level <= ((size_t)FB_MAX_TILES * FB_T) &&
-                      !c->cfg_no_dm && !c->cfg_no_stage && !c->cfg_stage_l1 && !c->cfg_sub_bits && !c->cfg_tile && !c->cfg_seg;
+                      fb_sort_knobs_clear(c);
     const uint32_t fb_ntile = (uint32_t)((n + FB_T - 1) / FB_T);
     if (pre) {
         p.glv = false;
@@ -924,10 +930,14 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     // (experiment knob: 256-thread workgroups + H2AGG_ACC_LDS pin the accumulation at exactly N waves per SIMD and leave the rest
     // of the CU — registers and LDS — to whatever else is in flight; see profiles/r03_sweeps.txt section 10)
     static const int acc_block = knob("H2AGG_ACC_BLOCK") ? atoi(knob("H2AGG_ACC_BLOCK")) : 64;
-    // the generic kernel stays in the shipped library behind a debug key (lean_acc = 0) so that the lean one — inline-asm
-    // Montgomery blocks, fixed temporaries — can be checked against it, point for point, on any box (tests/test_gpu_parity.py)
+    // the generic kernel (compiler-scheduled formulas, 166 VGPRs) lives in the measure build only, behind the debug key
+    // lean_acc = 0 / H2AGG_ACC=generic, for A/B runs; the shipped library carries the lean one alone
+#ifdef H2AGG_MEASURE_KNOBS
     static const bool lean_env = !(knob("H2AGG_ACC") && !strcmp(knob("H2AGG_ACC"), "generic"));
     const bool lean = lean_env && c->dbg_lean_acc;
+#else
+    const bool lean = true;
+#endif
     uint32_t* fix_list = nullptr;
     if (lean) {
         TRY(ensure(c, c->fix_list[sq], (size_t)p.NBT * lpb * 8));
@@ -952,10 +962,12 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
                                st, d_bases, d_endo_x, entries, offs, hist, ordered ? order : (uint32_t*)nullptr, p.NBT, p.big, lpb, acc_out,
                                big_list, big_keys, big_count, fix_list);
         } else {
+#ifdef H2AGG_MEASURE_KNOBS
         auto kacc = chain == CHAIN_FIRST ? k_msm_accumulate<1> : (chain == CHAIN_MID || chain == CHAIN_LAST) ? k_msm_accumulate<2> : k_msm_accumulate<0>;
         hipLaunchKernelGGL(kacc, dim3((unsigned)(((size_t)p.NBT * lpb + acc_block - 1) / acc_block)), dim3(acc_block), (size_t)acc_lds,
                            st, d_bases, d_endo_x, entries, offs, hist, ordered ? order : (uint32_t*)nullptr, p.NBT, p.big, lpb, acc_out,
                            big_list, big_keys, big_count);
+#endif
         }
     }
     // Buckets longer than `big` (skewed scalars; none for uniform ones, where the two launches below only find empty lists):
@@ -1771,6 +1783,14 @@ int h2agg_bases_precompute(h2agg_ctx* c, uint64_t handle, int window_bits) try {
     // sort).  debug key "pre_big" lifts the limit for A/B runs of exactly that.
     if (cc != FB_C && (size_t)W * t.n > ((size_t)1 << 22) && !c->dbg_pre_big)
         return fail(c, H2AGG_ERR_INVALID, "table too large for fixed-base levels (ceil(255 / c) * n must be <= 2^22)");
+    if (!window_bits) {
+        // auto mode is the opportunistic call: it does not take a large share of what is left of the device for levels
+        // (832 B per point at c = 20: 3.25 GiB for a 2^22-point table) — the caller who wants them regardless names the width
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(c, hipMemGetInfo(&free_b, &total_b));
+        if ((size_t)W * t.n * 64 > free_b / 4)
+            return fail(c, H2AGG_ERR_NOMEM, "fixed-base levels (auto) would take more than a quarter of the free device memory; pass window_bits to insist");
+    }
     TRY(join_tails(c));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (t.pre) {
@@ -1904,7 +1924,12 @@ int h2agg_g1_msm_device_batch_async(h2agg_ctx* c, uint64_t handle, const void* d
     }
     // MSMs per set of launches: the level-1 sort partitions (batch * W * NB >> sub_bits, sub_bits <= 11) must fit its
     // LDS counters, and the entry count its 32-bit offsets
-    const bool use_pre = it->second.pre && !c->cfg_c;   // fixed-base levels (h2agg_bases_precompute)
+    // fixed-base levels (h2agg_bases_precompute).  Levels at c = 20 pay only through their own sort, which takes one MSM at
+    // a time and no sort knobs: where it does not apply (a configured context; a batch of short columns over a big table, which
+    // would also want batch x 2^19 buckets) the levels are left alone and the ordinary path runs over the table — the two-array
+    // sort over c = 20 levels measured 113 ms against the ordinary path's 74 (16 MSMs, 2^22 points).
+    const bool fb_table = it->second.pre && it->second.pre_c == FB_C && !c->dbg_pre_big;
+    const bool use_pre = it->second.pre && !c->cfg_c && (!fb_table || (fb_sort_knobs_clear(c) && (batch == 1 || n >= ((size_t)1 << 18))));
     const PreTable pt{it->second.pre, it->second.n, it->second.pre_c, it->second.pre_W};
     const MsmPlan p1 = make_plan(c, n, 1);
     const uint32_t nb1 = use_pre ? (1u << (pt.c - 1)) : p1.NB;
@@ -2249,8 +2274,14 @@ int h2agg_debug_configure(h2agg_ctx* c, const char* key, int value) try {
     else if (k == "plan_cache") c->dbg_plan_cache = value;
     else if (k == "small_sort") c->dbg_small_sort = value;   // 0: small MSMs take the packed two-level sort again
     else if (k == "eval_split") c->dbg_eval_split = value;   // 0: an evaluation's two multi_exps are two MSMs again
-    else if (k == "shard_fail") c->dbg_shard_fail = value;   // tests: this rank of a sharded aggregation fails before (1) / between (2) the exchanges
-    else if (k == "lean_acc") c->dbg_lean_acc = value;       // 0: the bucket accumulation through the generic kernel (k_msm_accumulate) instead of the lean one
+    else if (k == "shard_fail") c->dbg_shard_fail = value;   // tests: this rank of a sharded aggregation fails before (1) / between (2) the exchanges, or inside exchange 1 (3) / 2 (4) before its all-gather
+    else if (k == "lean_acc") {   // 0: the bucket accumulation through the generic kernel (k_msm_accumulate) instead of the lean one
+#ifdef H2AGG_MEASURE_KNOBS
+        c->dbg_lean_acc = value;
+#else
+        if (value != 1) return fail(c, H2AGG_ERR_INVALID, "h2agg_debug_configure: the generic accumulation kernel is in the measure build only (build_ext.py --measure)");
+#endif
+    }
     else if (k == "pre_big") c->dbg_pre_big = value;         // 1: h2agg_bases_precompute takes any explicit width (levels through the two-array sort)
     else return fail(c, H2AGG_ERR_INVALID, "h2agg_debug_configure: unknown key " + k);
     return H2AGG_OK;

@@ -162,7 +162,11 @@ int h2agg_bases_upload(h2agg_ctx* ctx, const uint8_t* bases_aff, size_t n, uint6
  * ones, up to 2^22 points, take c = 20: 13 levels = 832 B per point beside the table — 3.25 GiB for a 2^22-point g_lagrange,
  * built in ~80 ms — and a (level, point) sort of their own (csrc/fb_sort_kernels.hpp).  An explicit width other than 20 whose
  * levels exceed 2^22 entries, and tables beyond 2^22 points, are refused (H2AGG_ERR_INVALID) and keep the ordinary path.
- * Results are the same points (h2agg_msm_configure's explicit window_bits disables the fast path). */
+ * window_bits = 0 is the opportunistic call: it returns H2AGG_ERR_NOMEM (table untouched, ordinary path kept) when the
+ * levels would take more than a quarter of the device memory that is free; an explicit width allocates regardless.
+ * Results are the same points (h2agg_msm_configure's explicit window_bits disables the fast path).  The c = 20 levels are
+ * used by MSMs their own sort takes — one MSM at a time (batches of >= 2^18 scalars run one after another), no sort /
+ * segment knobs configured; any other call over such a table runs the ordinary path and ignores the levels. */
 int h2agg_bases_precompute(h2agg_ctx* ctx, uint64_t bases_handle, int window_bits);
 /* bases[i] = k_i * G for n canonical Fr scalars held in DEVICE memory (workload generation: the
  * expected MSM is then (sum k_i * s_i) * G).  Arithmetic = scalar_mul_constant + to_affine. */
@@ -478,7 +482,8 @@ int h2agg_msm_configure_sort(h2agg_ctx* ctx, int sub_bits, int tile);
  *       "plan_cache" 0|1  h2agg_verify_aggregation keeps the recording of a call shape (default 1)
  *       "small_sort" 0|1  MSMs of <= 16384 scalars sort in one launch (default 1; 0 = the packed two-level sort)
  *       "eval_split" 0|1  the two multi_exps of an evaluation run as one set of launches (default 1)
- *       "lean_acc" 0|1    bucket accumulation through k_msm_accumulate_lean (default 1; 0 = the generic kernel: A/B on any box)
+ *       "lean_acc" 0|1    bucket accumulation through k_msm_accumulate_lean (default 1; 0 = the generic kernel, which only the
+ *                         measure build carries: the shipped library answers H2AGG_ERR_INVALID)
  *       "pre_big" 0|1     h2agg_bases_precompute takes any explicit width (1: levels through the two-array sort, A/B only)
  *       "shard_fail" 0|1|2  this rank of h2agg_verify_aggregation_sharded fails before (1) / between (2) its exchanges */
 int h2agg_debug_configure(h2agg_ctx* ctx, const char* key, int value);

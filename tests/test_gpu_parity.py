@@ -240,21 +240,16 @@ def test_msm_skewed_buckets(eng, kind, glv):
 
 @pytest.mark.parametrize("kind", ["random", "edges", "equal_scalars"])
 @pytest.mark.parametrize("n", [600, 20000])
-def test_msm_lean_accumulation_equals_the_generic_kernel(eng, n, kind):
+def test_msm_lean_accumulation(eng, pkg, n, kind):
     """The shipped library's bucket accumulation is k_msm_accumulate_lean (inline-asm Montgomery blocks with fixed temporaries,
-    exceptional cases through a fix-up list); debug key lean_acc = 0 sends the same MSM through the generic kernel
-    (compiler-scheduled C++ formulas).  Both must give the same point (their Jacobian triples may differ: the two kernels
-    meet a bucket's first entries through different formulas, so the bucket sums carry different Z)."""
+    exceptional cases through a fix-up list) and nothing else: the generic kernel (compiler-scheduled C++ formulas, 166 VGPRs)
+    is in the measure build only, and the shipped library refuses the debug key that would select it."""
     rng = O.SplitMix64(3050 + n)
     bases, sb, want = _msm_case(rng, n, kind)
-    try:
-        lean = eng.g1_msm(bases, sb)
+    assert norm(eng, eng.g1_msm(bases, sb)) == want
+    with pytest.raises(pkg.H2AggError):
         eng.debug_configure("lean_acc", 0)
-        generic = eng.g1_msm(bases, sb)
-    finally:
-        eng.debug_configure("lean_acc", 1)
-    assert norm(eng, lean) == want
-    assert norm(eng, generic) == want
+    eng.debug_configure("lean_acc", 1)
 
 
 def test_msm_all_zero_scalars_and_identity_bases(eng):

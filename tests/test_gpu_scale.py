@@ -373,6 +373,35 @@ def test_fixed_base_levels_c20_skewed_scalars(eng, kind):
         eng.bases_free(table)
 
 
+@pytest.mark.parametrize("bad", [1 << 254, 1 << 255, (1 << 256) - 1, None])
+def test_fixed_base_levels_c20_refuse_a_scalar_above_the_modulus(eng, pkg, bad):
+    """a scalar >= r in a caller's device buffer over a table with c = 20 levels: H2AGG_ERR_NONCANONICAL, cleanly — with bits
+    254 / 255 set its top digit names a partition past the level-1 sort's counters (LDS out of bounds, then gathers
+    outside the level table); None: r itself, the smallest one.  The context and the table work afterwards."""
+    dev = torch.device("cuda", 0)
+    n = (1 << 18) + 77
+    ks, k_np = _workload(n, 201)
+    d_k = torch.from_numpy(k_np.copy()).to(dev)
+    table = eng.bases_generate(d_k.data_ptr(), n)
+    try:
+        vals, s_np = _workload(n, 202)
+        eng.bases_precompute(table, 20)
+        good = torch.from_numpy(s_np.copy()).to(dev)
+        want = O.aff_to_bytes(O.scalar_mul(sum(k * s for k, s in zip(ks, vals)) % O.R, O.G1))
+        assert eng.g1_batch_to_affine(eng.g1_msm_device(table, good.data_ptr(), n)) == want
+        arr = s_np.copy()
+        for at in (0, 2047, 2048, n - 1, n // 2):            # first / last of a tile, the ragged last tile
+            arr[at] = np.frombuffer((O.R if bad is None else bad).to_bytes(32, "little"), dtype=np.uint8)
+        d_s = torch.from_numpy(arr).to(dev)
+        for _ in range(3):
+            with pytest.raises(pkg.H2AggError) as ei:
+                eng.g1_msm_device(table, d_s.data_ptr(), n)
+            assert ei.value.code == pkg.ERR_NONCANONICAL
+        assert eng.g1_batch_to_affine(eng.g1_msm_device(table, good.data_ptr(), n)) == want
+    finally:
+        eng.bases_free(table)
+
+
 def test_fixed_base_levels_refusals(eng, pkg):
     """h2agg_bases_precompute: an explicit width whose levels outgrow the packed sort item is refused unless it is 20 (the
     (level, point) sort's width); debug key pre_big lifts that for A/B runs through the two-array sort"""
