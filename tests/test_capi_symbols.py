@@ -50,8 +50,10 @@ def test_product_does_not_import_the_oracle():
 def test_kernel_register_budgets_of_the_built_library():
     """The lean bucket accumulation is built for four waves per SIMD: 128 VGPRs, no scratch.  If register pressure ever
     exceeded that the compiler would spill silently, so the budgets are read off the code object that ships
-    (tools/kernel_resources.py --check), here as well as on the GPU box.  The single-chain lean variants are A/B builds only:
-    they must not be in the product library."""
+    (tools/kernel_resources.py --check), here as well as on the GPU box.  The check walks EVERY kernel of the code object: one
+    with a scratch segment or spilled VGPRs that is not on the tool's allow-list (name, bytes, spills, reason) fails, so a new
+    kernel cannot pick up spills unseen.  The single-chain lean variants and the generic accumulation kernel are A/B builds
+    only: they must not be in the product library."""
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     tool = os.path.join(root, "tools", "kernel_resources.py")
@@ -59,3 +61,5 @@ def test_kernel_register_budgets_of_the_built_library():
     assert r.returncode == 0, r.stdout + r.stderr
     table = subprocess.run([sys.executable, tool, "k_msm_accumulate_lean"], capture_output=True, text=True).stdout
     assert "k_msm_accumulate_lean<0, true>" in table and ", false>" not in table, table
+    every = subprocess.run([sys.executable, tool, "k_msm_accumulate"], capture_output=True, text=True).stdout
+    assert "k_msm_accumulate<" not in every, every
