@@ -232,6 +232,48 @@ def latency_stats(times):
             "mean_s": sum(ts) / n, "min_s": ts[0], "max_s": ts[-1]}
 
 
+def host_noise():
+    """what the HOST did to this process, as counters to difference around a leg: the cgroup's CPU-quota throttling (periods in
+    which the container was stopped for having used its quota, and for how long) and this thread's context switches"""
+    import resource
+    out = {}
+    try:
+        with open("/sys/fs/cgroup/cpu.stat") as f:
+            for ln in f:
+                k, v = ln.split()
+                if k in ("nr_periods", "nr_throttled", "throttled_usec"):
+                    out[k] = int(v)
+    except (OSError, ValueError):
+        pass
+    ru = resource.getrusage(resource.RUSAGE_THREAD)
+    out["caller_involuntary_switches"] = ru.ru_nivcsw
+    return out
+
+
+def phase_report(ts, phases, noise0):
+    """`latency` extras of a from-bytes leg: the library's own wall-clock split (h2agg_last_phases) of the
+    SLOWEST repetition beside the median one's, the phase that grew most between the two, and what the host did meanwhile"""
+    order = sorted(range(len(ts)), key=lambda i: ts[i])
+    med, worst = order[len(order) // 2], order[-1]
+
+    def parse(line):
+        d = {}
+        for tok in line.split(" [")[0].split():
+            if "=" in tok:
+                k, v = tok.split("=")
+                d[k] = d.get(k, 0.0) + float(v)
+        return d
+    pm, pw = parse(phases[med]), parse(phases[worst])
+    grew = sorted(((pw.get(k, 0.0) - pm.get(k, 0.0), k) for k in pw), reverse=True)[:3]
+    n1 = host_noise()
+    return {"worst_phases": {"seconds": ts[worst], "repetition": worst, "line": phases[worst].strip()},
+            "median_phases": {"seconds": ts[med], "line": phases[med].strip()},
+            "worst_minus_median_ms_by_phase": [{"phase": k, "ms": round(d, 3)} for d, k in grew],
+            "host_during_leg": {k: n1[k] - noise0.get(k, 0) for k in n1},
+            "phases_are": "the library's wall-clock split of that call (h2agg_last_phases): milliseconds per phase in order, the "
+                          "calling thread's CPU and preemptions, every host sponge chain's start offset + run time (us) @ CPU"}
+
+
 class quiet_gc:
     """the timed repetitions of the host-driven legs run with the cyclic collector off and everything allocated so far moved
     out of its reach (gc.freeze): a generation-2 collection over torch's and ctypes' object graphs is tens of milliseconds,
@@ -533,17 +575,21 @@ def full_pipeline_leg(pkg, eng, args, g_table):
         """seconds per aggregation of k proofs (latency_stats), alternating between two sets; every set's result must repeat"""
         sets = [[(vk, "syn", g_table, proofs_all[:k])], [(vk, "syn", g_table, proofs_all[k:2 * k])]]
         first = [ver.verify_aggregation(eng, a, s_g2, g2) for a in sets]      # warm-up (Poseidon constants, buffers, the recording)
-        ts = []
+        ts, phases = [], []
+        noise0 = host_noise()
         with quiet_gc():
             for r in range(reps):
                 t0 = time.perf_counter()
                 got = ver.verify_aggregation(eng, sets[r & 1], s_g2, g2)
                 ts.append(time.perf_counter() - t0)
+                phases.append(eng.last_phases())
                 if got[:3] != first[r & 1][:3]:
                     raise SystemExit("full pipeline leg (%d proofs): repetitions disagree — refusing to report" % k)
         if first[0][:2] == first[1][:2]:
             raise SystemExit("full pipeline leg: two different sets of proofs gave the same pair — refusing to report")
-        return latency_stats(ts), first[0]
+        lat = latency_stats(ts)
+        lat.update(phase_report(ts, phases, noise0))
+        return lat, first[0]
 
     def both(k):
         eng.debug_configure("plan_cache", 1)
@@ -605,6 +651,7 @@ def full_pipeline_leg(pkg, eng, args, g_table):
                 w.vk.close()
                 w.eng.close()
 
+    eng.debug_configure("phases", 1)
     try:
         lat, dt_rec, (left, right, lam, ok) = both(args.agg_proofs)
         dt = lat["p50_s"]
@@ -624,6 +671,7 @@ def full_pipeline_leg(pkg, eng, args, g_table):
         except Exception as ex:      # noqa: BLE001 - a throughput extra must never cost the latency figures
             conc = {"error": "%s: %s" % (type(ex).__name__, str(ex)[:200])}
     finally:
+        eng.debug_configure("phases", 0)
         vk.close()
     n_pts, n_evals, n_w = shape.proof_items()
     return {"proofs_per_sec": args.agg_proofs / dt, "proofs": args.agg_proofs, "seconds_per_aggregation": dt,
@@ -725,15 +773,22 @@ def from_bytes_sharded_leg(pkg, eng, args, rank, world, dist, devs, g_table):
             raise SystemExit("from-bytes sharded leg: two different sets of proofs gave the same pair — refusing to report")
         if dist is not None:
             dist.barrier()
-        reps, ts = 32, []
-        with quiet_gc():
-            for r in range(reps):
-                t1 = time.perf_counter()
-                got = call(r & 1)
-                ts.append(time.perf_counter() - t1)
-                if got != first[r & 1]:
-                    raise SystemExit("from-bytes sharded leg: repetitions disagree — refusing to report")
+        reps, ts, phases = 32, [], []
+        noise0 = host_noise()
+        eng.debug_configure("phases", 1)
+        try:
+            with quiet_gc():
+                for r in range(reps):
+                    t1 = time.perf_counter()
+                    got = call(r & 1)
+                    ts.append(time.perf_counter() - t1)
+                    phases.append(eng.last_phases())
+                    if got != first[r & 1]:
+                        raise SystemExit("from-bytes sharded leg: repetitions disagree — refusing to report")
+        finally:
+            eng.debug_configure("phases", 0)
         lat = latency_stats(ts)
+        lat.update(phase_report(ts, phases, noise0))             # (this rank's own repetitions; p50 / p95 / max below: max over ranks)
         t = torch.tensor([lat["p50_s"], lat["p95_s"], lat["max_s"]], dtype=torch.float64, device=coll_dev)
         if dist is not None:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)

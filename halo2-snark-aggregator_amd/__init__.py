@@ -127,6 +127,7 @@ def load_library():
         "h2agg_verify_aggregation_sharded": (i32, [ctxp, vp, sz, vp, u8p, u8p, vp, vp, vp, C.POINTER(i32), vp, sz]),   # see verifier.py
         "h2agg_debug_configure": (i32, [ctxp, C.c_char_p, i32]),
         "h2agg_verify_plan_stats": (i32, [ctxp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+        "h2agg_last_phases": (C.c_char_p, [ctxp]),
         "h2agg_transcript_configure": (i32, [ctxp, i32]),
         "h2agg_poseidon_squeeze_batch_host": (i32, [u8p, sz, sz, C.POINTER(C.c_uint32), sz, vp, i32]),
         "h2agg_host_threads": (i32, []),
@@ -428,6 +429,10 @@ class H2Agg:
         h, m, k = C.c_uint64(), C.c_uint64(), C.c_uint64()
         self._check(self._lib.h2agg_verify_plan_stats(self._ctx, C.byref(h), C.byref(m), C.byref(k)))
         return h.value, m.value, k.value
+
+    def last_phases(self) -> str:
+        """wall-clock split of the last verify_aggregation call (after debug_configure("phases", 1)): h2agg_last_phases"""
+        return (self._lib.h2agg_last_phases(self._ctx) or b"").decode()
 
     def transcript_configure(self, backend: str = "auto"):
         """which backend runs the Poseidon sponges of this context: "auto" (by batch size), "device", "host" (worker threads)"""

@@ -129,6 +129,87 @@ __global__ void __launch_bounds__(TAPE_THREADS) k_tape_run(const TapeOp* __restr
     }
 }
 
+// The same walk with the register file in LDS.  A level of k_tape_run is a dependent round trip through
+// L2 — results stored, barrier, the next level's operands loaded: ~0.8 us of the ~2.4 us a level takes.  Here every value the
+// tape itself reads again lives in an LDS slot for as long as it is live (the host's liveness allocator below hands the slots
+// out level by level and reuses them: an aggregation's tape has ~9 500 values, ~150 KiB of LDS hold 4 096), so a level's
+// operands are an LDS read behind an LDS-only barrier; constants are converted and placed by this same launch (no separate
+// k_tape_load_consts).  Every result still goes to the global register file as well — fire and forget, nothing in here waits
+// for those stores — because the consumers behind the tape (k_eval_prep, k_tape_gather) read it from there.
+//   op.a / op.b:  bit 31 set: LDS slot (low bits); clear: never happens for a register operand (constants have slots too)
+//   op.op:        opcode | (LDS slot of the result, or TAPE_NOSLOT when nothing in the tape reads it) << 8
+// A tape whose live values do not fit runs through k_tape_run.
+constexpr uint32_t TAPE_LDS_SLOTS = 4096;          // x 36 B = 144 KiB of the CU's 160
+constexpr uint32_t TAPE_NOSLOT = 0xffffffu;
+constexpr uint32_t TAPE_SLOTBIT = 0x80000000u;
+FP_INLINE Fr slot_load(const uint32_t* file, uint32_t s) {
+    Fr r;
+#pragma unroll
+    for (int k = 0; k < NL; ++k) r.l[k] = file[s * NL + k];
+    return r;
+}
+FP_INLINE void slot_store(uint32_t* file, uint32_t s, const Fr& v) {
+#pragma unroll
+    for (int k = 0; k < NL; ++k) file[s * NL + k] = v.l[k];
+}
+FP_INLINE void tape_lds_barrier() {
+    // LDS traffic only: the global stores of the results are not waited for (their consumers are later kernels)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+FP_INLINE void tape_exec_lds(const TapeOp& op, uint32_t* file, uint32_t* regs, uint32_t* flags) {
+    const uint32_t code = op.op & 0xffu, dslot = op.op >> 8;
+    const Fr a = slot_load(file, op.a & ~TAPE_SLOTBIT);
+    Fr r;
+    if (code == TAPE_INV) {
+        if (fp_is_zero_mod<2, FrParams>(a)) atomicOr(flags, FLAG_DIV_ZERO);
+        r = fp_inv<FrParams>(a);
+    } else if (code == TAPE_SQRN) {
+        r = a;
+#pragma unroll 1
+        for (uint32_t i = 0; i < op.b; ++i) r = fp_sqr<FrParams>(r);
+    } else {
+        const Fr b = slot_load(file, op.b & ~TAPE_SLOTBIT);
+        if (code == TAPE_MUL) r = fp_mul<FrParams>(a, b);
+        else if (code == TAPE_ADD) r = fr_fold_2r(fp_add<FrParams>(a, b));
+        else r = fr_fold_2r(fp_sub<2, FrParams>(a, b));
+    }
+    if (dslot != TAPE_NOSLOT) slot_store(file, dslot, r);
+    reg_store(regs, op.dst, r);
+}
+__global__ void __launch_bounds__(TAPE_THREADS) k_tape_run_lds(const uint8_t* __restrict__ consts, const uint32_t* __restrict__ cslot,
+                                                               uint32_t nconst, const TapeOp* __restrict__ ops,
+                                                               const uint32_t* __restrict__ level_start, uint32_t nlevels,
+                                                               uint32_t* __restrict__ regs, uint32_t* flags) {
+    __shared__ uint32_t file[TAPE_LDS_SLOTS * NL];
+    uint32_t lo = nlevels ? level_start[0] : 0, hi = nlevels ? level_start[1] : 0;
+    TapeOp nxt = {0, 0, 0, 0};
+    if (lo + threadIdx.x < hi) nxt = ops[lo + threadIdx.x];
+    uint32_t bad = 0;
+#pragma unroll 1
+    for (uint32_t i = threadIdx.x; i < nconst; i += TAPE_THREADS) {
+        const Fr x = fp_load<FrParams>(consts + 32 * (size_t)i);
+        bad |= !fp_is_canonical<FrParams>(x);
+        const Fr m = fp_to_mont<FrParams>(x);
+        const uint32_t s = cslot[i];
+        if (s != TAPE_NOSLOT) slot_store(file, s, m);
+        reg_store(regs, i, m);
+    }
+    if (bad) atomicOr(flags, FLAG_NONCANONICAL);
+    tape_lds_barrier();
+#pragma unroll 1
+    for (uint32_t l = 0; l < nlevels; ++l) {
+        const TapeOp first = nxt;
+        const uint32_t lo_n = hi, hi_n = l + 1 < nlevels ? level_start[l + 2] : hi;
+        if (l + 1 < nlevels && lo_n + threadIdx.x < hi_n) nxt = ops[lo_n + threadIdx.x];
+        if (lo + threadIdx.x < hi) tape_exec_lds(first, file, regs, flags);
+#pragma unroll 1
+        for (uint32_t i = lo + threadIdx.x + TAPE_THREADS; i < hi; i += TAPE_THREADS) tape_exec_lds(ops[i], file, regs, flags);
+        tape_lds_barrier();
+        lo = lo_n;
+        hi = hi_n;
+    }
+}
+
 // registers -> canonical 32-byte scalars (MSM scalar buffer / results)
 __global__ void __launch_bounds__(BLOCK) k_tape_gather(const uint32_t* __restrict__ regs,
                                                        const uint32_t* __restrict__ idx, uint32_t n,

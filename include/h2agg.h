@@ -385,6 +385,11 @@ int h2agg_verify_aggregation_sharded(h2agg_ctx* ctx, const h2agg_circuit_proofs*
  * This reports how often that happened; any pointer may be NULL.  h2agg_debug_configure(ctx, "plan_cache", 0) records every
  * call afresh. */
 int h2agg_verify_plan_stats(h2agg_ctx* ctx, uint64_t* hits, uint64_t* misses, uint64_t* plans_kept);
+/* After h2agg_debug_configure(ctx, "phases", 1): the wall-clock split of the context's last h2agg_verify_aggregation* call as
+ * one line — " name=milliseconds" per phase in order, then the CPU the calling thread started and ended on and how often it was
+ * preempted, then every host sponge chain's start offset, run time (microseconds) and CPU.  For latency reports (which phase a
+ * slow call spent its time in); costs a few clock reads per call.  Owned by the context, valid until its next call. */
+const char* h2agg_last_phases(h2agg_ctx* ctx);
 
 /* ---- multi-GPU exchange -----------------------------------------------------------
  * The one collective of a sharded aggregation: every rank holds partial accumulators (the sharded form of the fold
@@ -473,6 +478,8 @@ int h2agg_msm_configure_sort(h2agg_ctx* ctx, int sub_bits, int tile);
  *   H2AGG_NO_PLACE            skip the stream-placement probe of h2agg_create / h2agg_set_stream (needed when the caller's
  *                             stream is being graph-captured: the probe launches and synchronises)
  *   H2AGG_TRACE, H2AGG_TRACE_PHASES   diagnostics on stderr (schema evaluation / phases of h2agg_verify_aggregation)
+ *   H2AGG_RCCL_LIB=path       the RCCL build to dlopen for the comm entry points instead of the librccl.so.1 already in the
+ *                             process / on the loader path (an operator's own build; tests point it at their stand-in)
  *   H2AGG_PAIRING_PORTABLE    (any value) the host pairing in its portable build even on a CPU with BMI2 + ADX (A/B of the two
  *                             instantiations of csrc/pairing.hpp; the pairing entry points take ctx = NULL, so this is not a key)
  * Test hooks, per context and per call (tests/ exercise code paths a production call reaches only by size):
@@ -484,6 +491,8 @@ int h2agg_msm_configure_sort(h2agg_ctx* ctx, int sub_bits, int tile);
  *       "eval_split" 0|1  the two multi_exps of an evaluation run as one set of launches (default 1)
  *       "lean_acc" 0|1    bucket accumulation through k_msm_accumulate_lean (default 1; 0 = the generic kernel, which only the
  *                         measure build carries: the shipped library answers H2AGG_ERR_INVALID)
+ *       "tape_lds" 0|1    Fr tapes whose live values fit run with the register file in LDS (default 1; 0 = through L2)
+ *       "phases" 0|1      keep every aggregation call's wall-clock split for h2agg_last_phases
  *       "pre_big" 0|1     h2agg_bases_precompute takes any explicit width (1: levels through the two-array sort, A/B only)
  *       "shard_fail" 0|1|2  this rank of h2agg_verify_aggregation_sharded fails before (1) / between (2) its exchanges */
 int h2agg_debug_configure(h2agg_ctx* ctx, const char* key, int value);

@@ -396,6 +396,57 @@ def test_fr_tape_eval(eng, pkg):
         eng.fr_tape_eval(O.R.to_bytes(32, "little"), [], [0])              # non-canonical input
 
 
+@pytest.mark.parametrize("kind", ["mixed", "wide_levels", "recycled_chain", "too_many_live", "consts_kept_to_the_end"])
+def test_fr_tape_register_file_in_lds(eng, pkg, kind):
+    """k_tape_run_lds (csrc/schema.hpp): the tape's values live in LDS slots handed out by the host's liveness allocator.
+    Programs that stress it — levels wider than the workgroup, a long chain whose dead values' slots are reused thousands of
+    times, more live values than slots (must fall back to the L2 register file), constants read for the first time at the very
+    end, inversions — against exact big-integer evaluation and against the same program with debug key tape_lds = 0."""
+    rng = O.SplitMix64(0x7D5 + len(kind))
+    if kind == "mixed":
+        nconst, nops = 300, 6000
+    elif kind == "wide_levels":
+        nconst, nops = 3000, 3500          # every op reads two constants: ONE level of 3500 operations (strip-mined by 1024 lanes)
+    elif kind == "recycled_chain":
+        nconst, nops = 5, 9000
+    elif kind == "too_many_live":
+        nconst, nops = 5000, 5001          # all 5000 constants stay live until the last operations
+    else:
+        nconst, nops = 3900, 3900
+    vals = [rng.fr() or 1 for _ in range(nconst)]
+    regs, ops = list(vals), []
+    for k in range(nops):
+        hi = nconst + k
+        op = rng.next() % 3
+        if kind == "mixed":
+            a = hi - 1 if (k % 3 == 0 and k) else rng.next() % hi
+            b = rng.next() % hi
+            if k % 977 == 5:
+                op, b = 3, a                # an inversion (b unused)
+        elif kind == "wide_levels":
+            a, b = rng.next() % nconst, rng.next() % nconst
+        elif kind == "recycled_chain":
+            a, b = hi - 1, (hi - 2 if k > 1 else rng.next() % nconst)
+            op = 0 if k % 2 else 1
+        elif kind == "too_many_live":
+            a, b = (hi - 1 if k else 0), k % nconst
+        else:
+            a, b = (hi - 1 if k else 0), nconst - 1 - (k % nconst)
+        ops.append((op, a, b))
+        if op == 3:
+            regs.append(pow(regs[a], O.R - 2, O.R) if regs[a] else 0)
+        else:
+            regs.append((regs[a] * regs[b], regs[a] + regs[b], regs[a] - regs[b])[op] % O.R)
+    outs = sorted({rng.next() % len(regs) for _ in range(200)} | {len(regs) - 1, 0, nconst - 1, nconst})
+    want = fr_bytes([regs[i] for i in outs])
+    assert eng.fr_tape_eval(fr_bytes(vals), ops, outs) == want
+    eng.debug_configure("tape_lds", 0)
+    try:
+        assert eng.fr_tape_eval(fr_bytes(vals), ops, outs) == want
+    finally:
+        eng.debug_configure("tape_lds", 1)
+
+
 def test_msm_over_projective_points(eng):
     """h2agg_g1_msm_jac: the points as `Vec<C::CurveExt>` (projective, arbitrary z, some identities) normalised on the
     device; same bytes as normalising first and calling h2agg_g1_msm, and as the oracle's naive multi_exp"""

@@ -55,6 +55,7 @@ SCRATCH_ALLOWED = {
     "k_small_sort": (36, 0, "stack"),
     "k_tape_level": (48, 0, "stack"),
     "k_tape_run": (48, 0, "stack"),
+    "k_tape_run_lds": (48, 0, "stack"),
 }
 
 
