@@ -164,7 +164,7 @@ struct h2agg_ctx {
     int comm_rank = 0, comm_size = 0;
 
     // h2agg_debug_configure: test hooks read per call (chained host-buffer slices, comb route, plan cache)
-    int dbg_pcie_slices = 0, dbg_pcie_glv = 0, dbg_pcie_chain = 1, dbg_comb_msm = 1, dbg_plan_cache = 1, dbg_small_sort = 1, dbg_eval_split = 1, dbg_pre_big = 0, dbg_lean_acc = 1, dbg_shard_fail = 0, dbg_shard_calls = 0, dbg_phases = 0, dbg_tape_lds = 1;
+    int dbg_pcie_slices = 0, dbg_pcie_glv = 0, dbg_pcie_chain = 1, dbg_comb_msm = 1, dbg_plan_cache = 1, dbg_small_sort = 1, dbg_eval_split = 1, dbg_pre_big = 0, dbg_lean_acc = 1, dbg_shard_fail = 0, dbg_shard_calls = 0, dbg_phases = 0, dbg_tape_lds = 1, dbg_prewake = 1;
     std::string last_phases;   // debug key phases: the last h2agg_verify_aggregation's wall-clock split (h2agg_last_phases)
     // tuning
     int cfg_c = 0, cfg_seg = 0, cfg_big = 0, cfg_sub_bits = 0, cfg_tile = 0;
@@ -2284,7 +2284,11 @@ int h2agg_debug_configure(h2agg_ctx* c, const char* key, int value) try {
         if (value != 1) return fail(c, H2AGG_ERR_INVALID, "h2agg_debug_configure: the generic accumulation kernel is in the measure build only (build_ext.py --measure)");
 #endif
     }
-    else if (k == "tape_lds") c->dbg_tape_lds = value;       // 0: every Fr tape through k_tape_run (register file in L2) instead of the LDS one
+    else if (k == "tape_lds") {
+        if (c->dbg_tape_lds != value) agg_plans_release(c);   // (kept recordings carry their tape in one encoding or the other)
+        c->dbg_tape_lds = value;
+    }       // 0: every Fr tape through k_tape_run (register file in L2) instead of the LDS one
+    else if (k == "prewake") c->dbg_prewake = value;         // 0: the sponge workers sleep until their chains are posted (A/B of the pre-wake)
     else if (k == "phases") c->dbg_phases = value;           // 1: every h2agg_verify_aggregation* call keeps its wall-clock split for h2agg_last_phases
     else if (k == "pre_big") c->dbg_pre_big = value;         // 1: h2agg_bases_precompute takes any explicit width (levels through the two-array sort)
     else return fail(c, H2AGG_ERR_INVALID, "h2agg_debug_configure: unknown key " + k);

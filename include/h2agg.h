@@ -492,6 +492,7 @@ int h2agg_msm_configure_sort(h2agg_ctx* ctx, int sub_bits, int tile);
  *       "lean_acc" 0|1    bucket accumulation through k_msm_accumulate_lean (default 1; 0 = the generic kernel, which only the
  *                         measure build carries: the shipped library answers H2AGG_ERR_INVALID)
  *       "tape_lds" 0|1    Fr tapes whose live values fit run with the register file in LDS (default 1; 0 = through L2)
+ *       "prewake" 0|1     a from-bytes call wakes its sponge workers at entry; they spin until the chains are posted (default 1)
  *       "phases" 0|1      keep every aggregation call's wall-clock split for h2agg_last_phases
  *       "pre_big" 0|1     h2agg_bases_precompute takes any explicit width (1: levels through the two-array sort, A/B only)
  *       "shard_fail" 0|1|2  this rank of h2agg_verify_aggregation_sharded fails before (1) / between (2) its exchanges */
