@@ -16,7 +16,7 @@ i1 = max(i for i, r in enumerate(rows) if r[2].startswith(end_marker))
 if "--last" in sys.argv:    # the N launches in front of the last evaluation's end (a whole h2agg_verify_aggregation call)
     i0 = max(0, i1 - int(sys.argv[sys.argv.index("--last") + 1]))
 else:
-    i0 = max(i for i, r in enumerate(rows[:i1]) if r[2].startswith("k_tape_load_consts"))
+    i0 = max(i for i, r in enumerate(rows[:i1]) if r[2].startswith("k_tape_load_consts") or r[2].startswith("k_tape_run_lds"))
 t0 = rows[i0][0]
 busy_end, idle = t0, 0
 for s, e, n, q in rows[i0:i1 + 1]:
