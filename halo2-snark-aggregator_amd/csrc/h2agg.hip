@@ -134,7 +134,7 @@ struct h2agg_ctx {
     DevBuf fix_list[2];                                        // buckets the lean accumulation left to the general formulas
     bool meta_clean[2] = {};                                   // pmeta[q] was zeroed behind its last use (tail stream)
     DevBuf item_idx, item_sub,
-        glv_buf, parts, small, endo_buf, tile_counts;  // MSM (bulk side: main stream only)
+        glv_buf, parts, small, endo_buf, tile_counts, fb_long;  // MSM (bulk side: main stream only)
     uint32_t* d_flags = nullptr;      // in `small`: [0] status flags, [1] big_count
     uint8_t* d_res_xyzz = nullptr;    // in `small` + 1024 + 144 * slot of the LAST msm_run (see msm_run)
     uint8_t* d_res_jac = nullptr;     // in `small` + 256
@@ -703,6 +703,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
         dp.idx_bits = 31 - dp.sub_bits;
     }
     TRY(ensure(c, c->item_idx, fbdm ? (size_t)fb_ntile * FB_KEYS1 * 4 : dm ? (size_t)dm_nwin * dp.n_row * 4 : nent * 4));
+    if (fbdm) TRY(ensure(c, c->fb_long, FB_LONG_WORDS * 4));   // very long partitions across workgroups (fb_sort_kernels.hpp)
     TRY(ensure(c, c->item_sub, fbdm ? 0 : dm ? (size_t)dm_nwin * dp.n_pad * 2 + (dm17 ? (size_t)2 * dm_nwin * (dp.n_pad / 8) : 0) : nent * 2));
     TRY(ensure(c, c->entries[sq], nent * 4));
     // buckets / segsum / wsum exist once per tail slot: in overlap mode the reduction of MSM k (tail stream)
@@ -730,6 +731,7 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
     uint32_t* order = (uint32_t*)c->order[sq].p;
     uint32_t* item_idx = (uint32_t*)c->item_idx.p;
     uint16_t* item_sub = (uint16_t*)c->item_sub.p;
+    uint32_t* fb_long = (uint32_t*)c->fb_long.p;
     uint32_t* entries = (uint32_t*)c->entries[sq].p;
     c->d_res_xyzz = (uint8_t*)c->small.p + 1024 + 144 * par;   // each tail slot has its own XYZZ result
     if (split) c->d_res_xyzz = (uint8_t*)c->small.p + 2048 + 2 * 144 * par;   // ... or its own two
@@ -798,12 +800,22 @@ int msm_run(h2agg_ctx* c, const uint8_t* d_bases, const uint8_t* d_scalars, size
             if (!meta_was_clean) HIP_TRY(c, hipMemsetAsync(meta, 0, M_WORDS * 4, st));
             hipLaunchKernelGGL(k_fb_partition, dim3(fb_ntile), dim3(FB_TB1), 0, st, d_scalars, (uint32_t)n, pcount, tile_counts, item_idx,
                                c->d_flags);
-            hipLaunchKernelGGL(k_dm_scan, dim3(1), dim3(1024), 0, st, (const uint32_t*)pcount, FB_NPART, pstart);
+            hipLaunchKernelGGL(k_fb_scan_list, dim3(1), dim3(1024), 0, st, (const uint32_t*)pcount, pstart, fb_ntile, fb_long);
         }
         {
             StageTimer t(c, ST_BUCKET_SORT);
             hipLaunchKernelGGL(k_fb_bucket_sort, dim3(FB_NPART), dim3(FB_TB2), 0, st, (const uint32_t*)pstart, (const uint32_t*)tile_counts,
                                (const uint32_t*)item_idx, (uint32_t)pre->n_level, fb_ntile, hist, offs, entries);
+            // partitions too long for the stage (skewed / small scalars): the very long ones split over workgroups, the rest one
+            // workgroup each; with uniform scalars every workgroup of the three launches leaves at once
+            hipLaunchKernelGGL(k_fb_long_count, dim3(FB_LONG_CAP, FB_LONG_S), dim3(FB_TB2), 0, st, (const uint32_t*)pstart,
+                               (const uint32_t*)tile_counts, (const uint32_t*)item_idx, (uint32_t)pre->n_level, fb_ntile, fb_long, hist, offs);
+            hipLaunchKernelGGL(k_fb_long_place, dim3(FB_LONG_CAP, FB_LONG_S), dim3(FB_TB2), 0, st, (const uint32_t*)pstart,
+                               (const uint32_t*)tile_counts, (const uint32_t*)item_idx, (uint32_t)pre->n_level, fb_ntile,
+                               (const uint32_t*)fb_long, entries);
+            hipLaunchKernelGGL(k_fb_bucket_sort_long, dim3(FB_NPART), dim3(FB_TB2), 0, st, (const uint32_t*)pstart,
+                               (const uint32_t*)tile_counts, (const uint32_t*)item_idx, (uint32_t)pre->n_level, fb_ntile,
+                               (const uint32_t*)fb_long, hist, offs, entries);
         }
     } else if (dm) {
         const uint32_t PW = dm_nwin * dp.ppw;
@@ -1312,7 +1324,7 @@ void h2agg_destroy(h2agg_ctx* c) {
     DevBuf* bufs[] = {&c->in_a,  &c->in_b,     &c->in_c,     &c->out,   &c->tmp_bases, &c->comb, &c->psd_spec, &c->tr_in, &c->tr_points, &c->tr_elems, &c->tr_chal, &c->inst_vals, &c->inst_jac, &c->inst_aff, &c->agg_elems, &c->hist[0], &c->hist[1],
                       &c->offs[0], &c->offs[1], &c->pmeta[0], &c->pmeta[1], &c->item_idx, &c->item_sub, &c->order[0], &c->order[1], &c->entries[0], &c->entries[1],
                       &c->r2d_ticket[0], &c->r2d_ticket[1], &c->r2d_ticket[2], &c->buckets[0], &c->buckets[1], &c->buckets[2], &c->segsum[0], &c->segsum[1], &c->segsum[2],
-                      &c->wsum[0], &c->wsum[1], &c->wsum[2], &c->big_list[0], &c->big_list[1], &c->big_keys[0], &c->big_keys[1], &c->big_part[0], &c->big_part[1], &c->fix_list[0], &c->fix_list[1], &c->glv_buf, &c->parts, &c->small, &c->endo_buf, &c->tile_counts,
+                      &c->wsum[0], &c->wsum[1], &c->wsum[2], &c->big_list[0], &c->big_list[1], &c->big_keys[0], &c->big_keys[1], &c->big_part[0], &c->big_part[1], &c->fix_list[0], &c->fix_list[1], &c->glv_buf, &c->parts, &c->small, &c->endo_buf, &c->tile_counts, &c->fb_long,
                       &c->sch_regs, &c->sch_in, &c->sch_scalars[0], &c->sch_scalars[1], &c->sch_bases[0], &c->sch_bases[1], &c->sch_endo};
     for (DevBuf* b : bufs)
         if (b->p) hipFree(b->p);

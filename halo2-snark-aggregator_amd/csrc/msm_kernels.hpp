@@ -757,14 +757,14 @@ __global__ void __launch_bounds__(R2D_TB) k_msm_reduce2d_window(const uint8_t* _
 // the two-dimensional reduction above over 16 pseudo-windows (k_msm_reduce2d_window also hands out T_q), then
 // k_fb_wsum: out[0] = sum_q V_q, out[1] = sum_q q T_q, and k_msm_final_lp over those two "windows" of 15 bits.
 constexpr int FB_R2D_WINDOWS = (int)(FB_NB / (uint32_t)(R2D_ROWS * R2D<7>::COLS));   // 16
-// buckets[m - 1] += the sixteen parts of value m of the top digit (slots FB_NB + 16 (m - 1) + part), in front of the reduction
+// buckets[m - 1] += the sixteen parts of value m of the top digit (slots FB_NB + fb_xslot(m - 1, part)), in front of the reduction
 __global__ void __launch_bounds__(64) k_fb_fold(uint8_t* __restrict__ buckets) {
     const uint32_t b = blockIdx.x * 64 + threadIdx.x;
     if (b >= (FB_XB >> FB_XPARTS_LOG)) return;
     G1XYZZ acc = xyzz_load(buckets + XYZZ_BYTES * (size_t)b);
 #pragma unroll 1
     for (uint32_t j = 0; j < (1u << FB_XPARTS_LOG); ++j)
-        acc = xyzz_add(acc, xyzz_load(buckets + XYZZ_BYTES * ((size_t)FB_NB + (b << FB_XPARTS_LOG) + j)));
+        acc = xyzz_add(acc, xyzz_load(buckets + XYZZ_BYTES * ((size_t)FB_NB + fb_xslot(b, j))));
     xyzz_store(buckets + XYZZ_BYTES * (size_t)b, acc);
 }
 __global__ void __launch_bounds__(64) k_fb_wsum(const uint8_t* __restrict__ vsum, const uint8_t* __restrict__ tsum,

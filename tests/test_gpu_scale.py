@@ -332,14 +332,15 @@ def test_fixed_base_levels(eng, n, cw):
         eng.bases_free(table)
 
 
-@pytest.mark.parametrize("kind", ["all_equal", "two_values", "small", "top_digit_only", "half_zero"])
+@pytest.mark.parametrize("kind", ["all_equal", "two_values", "small", "top_digit_only", "half_zero", "u64", "u128", "sixty_long_partitions",
+                                  "a_little_over_the_stage"])
 def test_fixed_base_levels_c20_skewed_scalars(eng, kind):
     """the (level, point) sort of the big-table levels (csrc/fb_sort_kernels.hpp) under scalars that are not uniform: every key
     of a level in ONE bucket (level 2's over-long-partition path with wave-aggregated counters, level 1's one-counter tiles,
     the accumulation's over-long-bucket chunks), only the top digit's own slots in use, half the digits zero — against the
     ordinary path over the same table."""
     dev = torch.device("cuda", 0)
-    n = (1 << 18) + 5
+    n = (1 << 21) + 9 if kind == "a_little_over_the_stage" else (1 << 18) + 5
     ks, k_np = _workload(n, 181)
     d_k = torch.from_numpy(k_np.copy()).to(dev)
     table = eng.bases_generate(d_k.data_ptr(), n)
@@ -353,6 +354,18 @@ def test_fixed_base_levels_c20_skewed_scalars(eng, kind):
             vals = [int(v) for v in rng.integers(0, 1000, size=n)]
         elif kind == "top_digit_only":
             vals = [int(v) << 240 for v in rng.integers(1, 1 << 13, size=n)]
+        elif kind == "u64":        # what instance columns hold: digit 3 has four bits -> its keys fill sixteen buckets of partition 0,
+            vals = [int.from_bytes(rng.bytes(8), "little") for _ in range(n)]      # split over workgroups (k_fb_long_count / _place)
+        elif kind == "u128":
+            vals = [int.from_bytes(rng.bytes(16), "little") for _ in range(n)]
+        elif kind == "sixty_long_partitions":
+            # twelve equal digits per scalar, drawn from 90 partitions: 12 n / 90 = 35 k keys each in runs of ~290 — more very
+            # long partitions than the list holds (64): the others go one workgroup each, tile-major
+            vals = [sum(((int(v) % 90) * 256 + 1 + ((int(v) >> 8) % 7)) << (20 * w) for w in range(12)) for v in rng.integers(0, 1 << 30, size=n)]
+        elif kind == "a_little_over_the_stage":
+            # (n = 2^21 + 9) twelve equal digits from 768 partitions: 32 k keys each — over the level-2 stage's 28 k — in runs of
+            # 32 per tile: the key-major shape of k_fb_bucket_sort_long
+            vals = [sum(((int(v) % 768) * 256 + 1 + ((int(v) >> 10) % 256)) << (20 * w) for w in range(12)) for v in rng.integers(0, 1 << 30, size=n)]
         else:
             vals = [0 if i % 2 else int.from_bytes(rng.bytes(31), "little") for i in range(n)]
         arr = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in vals), dtype=np.uint8).reshape(n, 32).copy()

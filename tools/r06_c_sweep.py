@@ -22,15 +22,21 @@ eng.bases_precompute(table, 0)
 out = torch.zeros((B, 96), dtype=torch.uint8, device=dev)
 names = None
 res = {}
-for bits in (254, 240, 220):
+import numpy as np
+for ndig in (13, 12, 11):
     d = torch.randint(0, 256, (B, n, 32), dtype=torch.uint8, device=dev)
-    full, rem = bits // 8, bits % 8
-    if full < 32:
-        d[:, :, full + (1 if rem else 0):] = 0
-        if rem:
-            d[:, :, full] &= (1 << rem) - 1
-    if bits == 254:
-        d[:, :, 31] &= 0x1f          # < 2^253 < r
+    if ndig == 13:
+        d[:, :, 31] &= 0x1f          # uniform below 2^253 < r: the headline workload
+    else:
+        # ndig non-zero digits, none of them above 2^19 (bit 19 of every 20-bit digit clear): no carries, so the dropped top
+        # digits stay empty instead of collecting a carry from half the scalars (which lands 2^21 keys on sixteen slots —
+        # measured beside this sweep: 172 ms per batch)
+        mask = np.zeros(32, dtype=np.uint8)
+        for bit in range(20 * ndig):
+            if bit % 20 != 19:
+                mask[bit // 8] |= 1 << (bit % 8)
+        d &= torch.from_numpy(mask).to(dev)
+    bits = ndig
     torch.cuda.synchronize()
     def batch():
         eng.g1_msm_device_batch_async(table, d.data_ptr(), n, B, out.data_ptr())
@@ -47,9 +53,9 @@ for bits in (254, 240, 220):
         if v[1]:
             stages[names[st]] = v[0] / v[1]
         eng.profile_enable(False)
-    res[bits] = (min(ts), stages)
-    print("%3d-bit scalars (%2d digits): batch of %d %.2f ms (%.3f per MSM; runs %s) | per MSM, one stage bracketed at a time: %s" % (
-        bits, (bits + 19) // 20, B, min(ts), min(ts) / B, " ".join("%.1f" % t for t in ts),
+    res[ndig] = (min(ts), stages)
+    print("%2d digits per scalar: batch of %d %.2f ms (%.3f per MSM; runs %s) | per MSM, one stage bracketed at a time: %s" % (
+        ndig, B, min(ts), min(ts) / B, " ".join("%.1f" % t for t in ts),
         " ".join("%s=%.3f" % (a.replace("msm_", ""), b) for a, b in stages.items())), flush=True)
     del d
 # one MSM alone with its tail in-stream: the reduction behind the accumulation, timed stage by stage
@@ -65,3 +71,35 @@ eng.synchronize()
 st = eng.profile_stages()
 eng.profile_enable(False)
 print("one MSM, tails in-stream, every stage bracketed (ms per MSM):", " ".join("%s=%.3f" % (a.replace("msm_", ""), v[0] / v[1]) for a, v in st.items() if v[1]))
+
+# small scalars (what instance columns of real circuits hold): few distinct top digits, so a handful of bucket slots take
+# most of the keys — levels + their sort against the ordinary path, one batch each
+eng.msm_set_tail_overlap(2)
+plain = eng.bases_generate(k.to(dev).data_ptr(), 1 << lg)      # the same table without levels
+for nbits in (64, 128, 253):
+    d = torch.randint(0, 256, (B, n, 32), dtype=torch.uint8, device=dev)
+    if nbits < 253:
+        d[:, :, nbits // 8:] = 0
+    else:
+        d[:, :, 31] &= 0x1f
+    torch.cuda.synchronize()
+    line = "%3d-bit scalars:" % nbits
+    for mode in ("levels", "ordinary"):
+        tb = table if mode == "levels" else plain
+        eng.g1_msm_device_batch_async(tb, d.data_ptr(), n, B, out.data_ptr()); eng.synchronize()
+        ts = []
+        for _ in range(3):
+            t0 = time.perf_counter(); eng.g1_msm_device_batch_async(tb, d.data_ptr(), n, B, out.data_ptr()); eng.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        line += "  %s %.1f ms per batch of %d" % (mode, min(ts), B)
+        stg = {}
+        for st_i in range(len(names)):
+            eng.profile_enable(True, only_stage=st_i); eng.profile_reset()
+            eng.g1_msm_device_batch_async(tb, d.data_ptr(), n, B, out.data_ptr()); eng.synchronize()
+            v = eng.profile_stages()[names[st_i]]
+            if v[1] and v[0] / v[1] > 0.03:
+                stg[names[st_i].replace("msm_", "")] = v[0] / v[1]
+            eng.profile_enable(False)
+        line += " (" + " ".join("%s=%.2f" % kv for kv in stg.items()) + ")"
+    print(line, flush=True)
+    del d
