@@ -278,3 +278,47 @@ def test_recorded_aggregation_is_reused_for_new_proofs_of_the_same_shape(eng, pk
         for vk in vks:
             vk.close()
         eng.bases_free(table)
+
+
+def test_phase_split_prewake_and_tape_keys_do_not_change_the_result(eng, pkg):
+    """round 6's latency items are switches over the SAME computation: h2agg_last_phases (debug key phases) reports the call's
+    wall-clock split and per-chain stamps; prewake = 0 keeps the sponge workers asleep until their chains are posted and the
+    pairing's two Miller loops on one thread; tape_lds = 0 runs the Fr tape through the L2 register file.  Every combination
+    must return the oracle's pair, lambda and an accepted pairing; a tampered proof must still be rejected under each."""
+    setup, circuits = make_batch(0xA7, [SHAPES[0], SHAPES[1]], 2)
+    want_l, want_r, _plain, _c, want_lam = V.verify_aggregation_proofs_in_chip(S.OracleEccChip(), circuits)
+    want = (S.final_pair_bytes(want_l, want_r), O.fe_to_bytes(want_lam))
+    eng.transcript_configure("host")
+    try:
+        assert eng.last_phases() == "" or "=" in eng.last_phases()
+        eng.debug_configure("phases", 1)
+        for prewake in (1, 0):
+            for tape_lds in (1, 0):
+                eng.debug_configure("prewake", prewake)
+                eng.debug_configure("tape_lds", tape_lds)
+                for _ in range(3):                               # recorded, then reused twice
+                    left, right, lam, ok = run_product(pkg, eng, setup, circuits)
+                    assert (left + right, lam) == want and ok is True, (prewake, tape_lds)
+                    line = eng.last_phases()
+                    for name in ("inst_upload=", "sponge_wait=", "evaluate=", "pairing=", "sponge chains posted at", "caller cpu"):
+                        assert name in line, (name, line)
+                    assert ("register file in LDS" in line) == bool(tape_lds) or "tape:" not in line
+        # a one-bit change of a proof under the default switches: rejected, and the phase split is that call's
+        eng.debug_configure("prewake", 1)
+        eng.debug_configure("tape_lds", 1)
+        import copy
+        c2 = copy.copy(circuits[0])
+        inst, data = c2.proofs[0]
+        pos = len(data) - 40                                     # inside the last scalars: decodes, verifies to a different pair
+        c2.proofs = [(inst, data[:pos] + bytes([data[pos] ^ 1]) + data[pos + 1:])] + list(c2.proofs[1:])
+        try:
+            _l, _r, _lam, ok = run_product(pkg, eng, setup, [c2, circuits[1]])
+            assert ok is False
+        except pkg.H2AggError:
+            pass                                                 # (a non-canonical scalar is refused outright)
+    finally:
+        eng.debug_configure("phases", 0)
+        eng.debug_configure("prewake", 1)
+        eng.debug_configure("tape_lds", 1)
+        eng.transcript_configure("auto")
+    assert eng.last_phases() != ""

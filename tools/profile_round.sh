@@ -3,7 +3,7 @@
 # never combined with other traces) for the dominant kernel.  Run on the GPU box from the repo root:
 #   tools/profile_round.sh r01_final      -> gpurun_out/<tag>_*.txt  (copy the ones to keep into profiles/)
 set -u
-tag=${1:-r05_final}
+tag=${1:-r06_final}
 root=$(pwd)
 out=$root/gpurun_out
 mkdir -p $out
@@ -34,6 +34,7 @@ python tools/make_traffic_json.py $out/${tag} batch > $out/${tag}_batch_traffic.
 cd /tmp && rm -rf /tmp/prof_fb && rocprofv3 --kernel-trace --stats -d /tmp/prof_fb -o fb -- python $root/tools/fixed_base_big.py 22 --fixed-only > $out/${tag}_fb_batch.txt 2>/dev/null
 python $root/tools/rocpd_summary.py /tmp/prof_fb/fb_results.db > $out/${tag}_fb_kernel_stats.txt 2>&1
 python $root/tools/r05_batch.py 22 16 > $out/${tag}_fb_vs_ordinary.txt 2>/dev/null
+python $root/tools/r06_c_sweep.py > $out/${tag}_c_sweep.txt 2>/dev/null
 cd $root
 # batch kernels at n = 2^22 (HBM roofline rows)
 cd /tmp && rm -rf /tmp/prof_b && rocprofv3 --kernel-trace --stats -d /tmp/prof_b -o b -- python $root/tools/batch_roofline.py run > /dev/null 2>&1
@@ -49,6 +50,8 @@ python tools/pipeline_time.py 4 16 64 > $out/${tag}_pipeline_time.txt 2>&1
 H2AGG_TRACE_PHASES=1 H2AGG_TRANSCRIPT=host python tools/pipeline_time.py 4 16 64 2>&1 | grep "phases" | awk 'NR%9==3' > $out/${tag}_pipeline_phases.txt
 # kernel timeline of one evaluation (limb-parallel Horner chain)
 bash tools/eval_trace.sh > /dev/null 2>&1; cp $out/eval_trace/eval_timeline.txt $out/${tag}_eval_timeline.txt 2>/dev/null
+# kernel + copy timeline of one whole h2agg_verify_aggregation call (4 proofs) with its host phases
+bash tools/pipeline_trace.sh > /dev/null 2>&1; (cat $out/pipeline_trace/timeline.txt; grep "h2agg phases" $out/pipeline_trace/phases.txt | tail -2 | cut -c1-900) > $out/${tag}_pipeline_trace.txt 2>/dev/null
 # host-side phases of bench.py's aggregate leg (instance-column MSMs under the schema build, then the evaluation)
 (python tools/agg_leg_phases.py --proofs 4; python tools/agg_leg_phases.py --proofs 16) > $out/${tag}_agg_leg_phases.txt 2>/dev/null
 # the default bench line itself (no profiler attached); it reads the PMC evidence just collected from profiles/
