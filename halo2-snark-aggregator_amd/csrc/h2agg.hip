@@ -145,6 +145,8 @@ struct h2agg_ctx {
     DevBuf sch_regs, sch_in, sch_scalars[2], sch_bases[2], sch_endo;
     uint8_t* h_stage = nullptr;
     size_t h_stage_cap = 0;
+    uint8_t* h_down = nullptr;        // page-locked landing block of the from-bytes call's downloads (csrc/verifier.inc)
+    size_t h_down_cap = 0;
     const void* sch_owner = nullptr;  // the schema whose tape sch_regs reflects
     struct AggPlanCache* agg_plans = nullptr;   // recorded aggregations kept for the next call of the same shape (csrc/verifier.inc)
 
@@ -1336,6 +1338,7 @@ void h2agg_destroy(h2agg_ctx* c) {
     }
     if (c->h_pinned) hipHostFree(c->h_pinned);
     if (c->h_stage) hipHostFree(c->h_stage);
+    if (c->h_down) hipHostFree(c->h_down);
     if (c->copy_stream) {
         hipStreamSynchronize(c->copy_stream);
         for (int k = 0; k < MSM_MAX_SLICES; ++k) {
