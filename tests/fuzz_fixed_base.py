@@ -16,6 +16,8 @@ cases = 0
 while time.time() < t_end:
     big = rng.next() % 6 == 0                                  # now and then a table whose levels take the (level, point) sort (c = 20)
     n = (1 << 18) + 1 + rng.next() % (1 << 17) if big else 1 + rng.next() % (1 << (1 + rng.next() % 12))
+    if big and rng.next() % 4 == 0:
+        n = (1 << 20) + (1 << 18) + rng.next() % (1 << 20)     # enough level-1 tiles for the key-major shape of the over-long path
     cw = (0 if rng.next() % 2 else 20) if big else (0 if rng.next() % 3 == 0 else 4 + rng.next() % 17)
     ks = b"".join(O.fe_to_bytes(rng.fr()) for _ in range(n))
     d_k = torch.frombuffer(bytearray(ks), dtype=torch.uint8).to(dev)
@@ -28,14 +30,22 @@ while time.time() < t_end:
     for _ in range(4):
         m = 1 + rng.next() % n
         B = 1 + rng.next() % 5
-        pat = rng.next() % 5
+        pat = rng.next() % (10 if big else 5)
         rows = []
         for q in range(B):
             if pat == 0: sc = [rng.fr() for _ in range(m)]
             elif pat == 1: sc = [rng.next() % 3 for _ in range(m)]
             elif pat == 2: sc = [O.R - 1 - rng.next() % 2 for _ in range(m)]
             elif pat == 3: sc = [rng.next() % (1 << 20) for _ in range(m)]
-            else: sc = [rng.fr() if rng.next() % 2 else 0 for _ in range(m)]
+            elif pat == 4: sc = [rng.fr() if rng.next() % 2 else 0 for _ in range(m)]
+            # (big tables) what skews the (level, point) sort: small scalars, a carry into an empty top digit, digits from few partitions
+            elif pat == 5: sc = [rng.next() for _ in range(m)]                                       # 64-bit
+            elif pat == 6: sc = [rng.next() | (rng.next() << 64) for _ in range(m)]                  # 128-bit
+            elif pat == 7: sc = [rng.fr() >> 14 for _ in range(m)]                                   # uniform below ~2^240
+            elif pat == 8:
+                nparts = 1 + rng.next() % 900
+                sc = [sum(((v % nparts) * 256 + 1 + (v >> 12) % 256) << (20 * w) for w in range(12)) for v in (rng.next() for _ in range(m))]
+            else: sc = [(rng.next() % (1 << 13) + 1) << 240 if rng.next() % 3 else rng.next() % 50 for _ in range(m)]   # top digit / tiny
             rows.append(b"".join(O.fe_to_bytes(s) for s in sc))
         d_s = torch.frombuffer(bytearray(b"".join(rows)), dtype=torch.uint8).to(dev)
         d_out = torch.zeros((B, 96), dtype=torch.uint8, device=dev)
