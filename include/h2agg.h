@@ -492,10 +492,13 @@ int h2agg_msm_configure_sort(h2agg_ctx* ctx, int sub_bits, int tile);
  *       "lean_acc" 0|1    bucket accumulation through k_msm_accumulate_lean (default 1; 0 = the generic kernel, which only the
  *                         measure build carries: the shipped library answers H2AGG_ERR_INVALID)
  *       "tape_lds" 0|1    Fr tapes whose live values fit run with the register file in LDS (default 1; 0 = through L2)
- *       "prewake" 0|1     a from-bytes call wakes its sponge workers at entry; they spin until the chains are posted (default 1)
+ *       "prewake" 0|1     a from-bytes call wakes its sponge workers at entry (they spin until the chains are posted), one more
+ *                         for the pairing's second Miller loop, and waits only for the element streams in front of the sponges
+ *                         (default 1; 0: the three latency measures of round 6 off, for an A/B)
  *       "phases" 0|1      keep every aggregation call's wall-clock split for h2agg_last_phases
  *       "pre_big" 0|1     h2agg_bases_precompute takes any explicit width (1: levels through the two-array sort, A/B only)
- *       "shard_fail" 0|1|2  this rank of h2agg_verify_aggregation_sharded fails before (1) / between (2) its exchanges */
+ *       "shard_fail" 0..4  this rank of h2agg_verify_aggregation_sharded fails before (1) / between (2) its exchanges, or inside
+ *                         exchange 1 (3) / 2 (4) before its all-gather */
 int h2agg_debug_configure(h2agg_ctx* ctx, const char* key, int value);
 /* Overlap the latency-shaped tail of one MSM (enable = 1: the Horner kernel, one wave; 2: bucket reduction + window
  * sums + Horner; 3: as 2, and the bucket accumulation itself leaves the context's stream, so that the NEXT MSM's sort runs
