@@ -1,19 +1,18 @@
 #!/bin/bash
-# profiles/r06_gpu_suite.txt from the three evidence leases (tools/evidence_job.sh) — run in the repo root after merging gpurun_out/
+# profiles/r06_gpu_suite.txt from the evidence leases (tools/evidence_job.sh) — run in the repo root after merging gpurun_out/
 o=profiles/r06_gpu_suite.txt; d=gpurun_out/r06_final
 {
 echo "# Round 6: the GPU suite and the soaks of the FINAL tree, each block one fresh gpurun lease (one MI355X box, nothing kept between"
-echo "# leases).  Complete output of \`python -m pytest tests/ -x -q -m gpu -rs\` three times, then the tallies of the stand-in soaks"
+echo "# leases).  Complete output of \`python -m pytest tests/ -x -q -m gpu -rs\` of every lease, then the tallies of the stand-in soaks"
 echo "# (tools/soak_standins.sh: fresh processes of tests/rccl_stub_ranks.py; tools/soak_bench_ranks.py: bench.py --gpus 2 over the"
-echo "# library's communicator).  Collected: 375 GPU tests; 373 run on a one-GPU box (2 skipped: needs two GPUs; reference fixtures absent)."
+echo "# library's communicator) and the offline fuzzers.  Collected: 375 GPU tests; 373 run on a one-GPU box (2 skipped: needs two"
+echo "# GPUs; reference-made fixtures absent).  The sha256 in every block's header is over csrc/* + tests/cpp/rccl_stub.cpp."
+echo "# (Logs of earlier leases of this round — round 5's stand-in under round 6's library, 150 of 150; mid-round soaks — went with the"
+echo "# container they were kept in; their tallies are quoted in profiles/r06_sweeps.txt section 1 and not repeated here.)"
 echo
-for r in 1 2 3; do cat $d/suite_run$r.txt; echo; done
-echo "===== stand-in soak, lease 1 (behind suite run 1)"; cat $d/soak_standins.txt
-echo; echo "===== stand-in soak, lease 3 (behind suite run 3)"; cat $d/soak_standins_lease3.txt
-echo; echo "===== bench.py --gpus 2 soak, lease 2 (behind suite run 2)"; cat $d/soak_bench_ranks.txt
-echo; echo "===== earlier in the round, tree of commit ec228ba + pool fix (before the download split), one lease: suite 372 passed, 2 skipped;"
-cat gpurun_out/r06f/soak_standins_1.txt gpurun_out/r06f/soak_bench_ranks_1.txt
-echo; echo "===== round 5's stand-in under round 6's library (reproduction attempt of GPUTEST_r05's failure), one lease"; cat gpurun_out/r06a/old_stub_tally.txt
-echo; echo "===== tests/fuzz_fixed_base.py 300 61 (lease 3; small / carry / few-partition scalar patterns over c = 20 levels included)"; cat $d/fuzz_fixed_base.txt
+for f in $d/suite_run*.txt; do cat $f; echo; done
+for f in $d/soak_standins_lease*.txt; do echo "===== stand-in soak ($(basename $f .txt): behind that lease's suite run)"; cat $f; echo; done
+[ -f $d/soak_bench_ranks.txt ] && { echo "===== bench.py --gpus 2 soak (behind a suite run, same lease)"; cat $d/soak_bench_ranks.txt; echo; }
+for f in $d/fuzz_*.txt; do [ -f $f ] && { echo "===== $(basename $f .txt) (offline randomised differential run against the C oracle; command in its first line)"; cat $f; echo; }; done
 } > $o
 wc -l $o
