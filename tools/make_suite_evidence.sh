@@ -13,6 +13,7 @@ echo
 for f in $d/suite_run*.txt; do cat $f; echo; done
 for f in $d/soak_standins_lease*.txt; do echo "===== stand-in soak ($(basename $f .txt): behind that lease's suite run)"; cat $f; echo; done
 [ -f $d/soak_bench_ranks.txt ] && { echo "===== bench.py --gpus 2 soak (behind a suite run, same lease)"; cat $d/soak_bench_ranks.txt; echo; }
+[ -f $d/suite_durations.txt ] && { echo "===== a fifth fresh lease, the same tree: python -m pytest tests/ -x -q -m gpu --durations=60 (where the ten and a half minutes go)"; cat $d/suite_durations.txt; echo; }
 for f in $d/fuzz_*.txt; do [ -f $f ] && { echo "===== $(basename $f .txt) (offline randomised differential run against the C oracle; command in its first line)"; cat $f; echo; }; done
 } > $o
 wc -l $o
